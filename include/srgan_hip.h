@@ -1,0 +1,136 @@
+/* srgan_hip.h -- C ABI of libsrgan_hip.so: the MI355X (gfx950) compute layer of the SRGAN/SGAN training step.
+ *
+ * The reference (golmschenk/sr-gan) is pure Python on PyTorch and has NO FFI of its own: its
+ * arithmetic is reached through torch.nn / torch.nn.functional / torch.optim call sites.  Each entry point
+ * below therefore cites the reference call site(s) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, < 0 = argument / shape error (-1 invalid, -2 unsupported,
+ *     -3 out of range), > 0 = hipError_t.  srgan_last_error() returns a thread-local message.
+ *   - pointers are DEVICE pointers to contiguous fp32 (int32 for arg-max), borrowed for the call only;
+ *     nothing is allocated, retained or freed.  Activations are NCHW, conv weights [K, C, R, S],
+ *     transposed-conv weights [Cin, Cout, R, S] (torch layouts).
+ *   - `stream` is a hipStream_t (NULL = default stream); every call is asynchronous on it.
+ *   - `accumulate` != 0 adds into the existing output (gradient accumulation across the four
+ *     discriminator backward passes, reference srgan.py:280-295) instead of overwriting it.
+ *   - tensors are limited to < 2^31 elements.
+ *   - `force_kernel`: 0 = automatic choice, 1 = direct VALU form, 2 = MFMA form (used by tests to
+ *     cross-check the two implementations).
+ */
+#ifndef SRGAN_HIP_H
+#define SRGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int srgan_version(void);               /* 100 = ABI 1.0 */
+const char* srgan_last_error(void);
+
+/* ---- convolution ------------------------------------------------------------------------------------------
+ * Geometry of y = conv2d(x, w): x [N,C,H,W], w [K,C,R,S], y [N,K,OH,OW].  Batch strides (elements) allow a
+ * channel-slice view of a wider buffer; 0 means dense. */
+typedef struct srgan_conv_desc {
+  int32_t N, C, H, W;
+  int32_t K, R, S;
+  int32_t stride_h, stride_w, pad_h, pad_w;
+  int32_t OH, OW;
+  int64_t x_batch_stride, y_batch_stride;
+} srgan_conv_desc;
+
+/* y = conv2d(x, w) + bias[k] (bias may be NULL).
+ * Replaces torch.nn.Conv2d.forward at reference crowd/models.py:340-345,369,770-775,1072,1134-1135;
+ * age/models.py:24,61-65; age/vgg.py:78. */
+int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w, const float* bias, float* y,
+                     int force_kernel, void* stream);
+
+/* gx = d(conv2d)/dx applied to gy, + bias[c] (bias may be NULL).  Also IS the forward of
+ * torch.nn.ConvTranspose2d (weight [Cin=K, Cout=C, R, S], input = gy, output = gx): reference
+ * age/models.py:16-21,37-41, crowd/models.py:132-136,768-769.  As a backward pass it replaces autograd's
+ * conv backward-to-input reached from reference srgan.py:280-295,304 and the create_graph pass of
+ * srgan.py:368-370. */
+int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const float* w, const float* bias, float* gx,
+                          int accumulate, int force_kernel, void* stream);
+
+/* gw = d(conv2d)/dw applied to gy (reduction over batch and output pixels). */
+int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const float* gy, float* gw, int accumulate,
+                            int force_kernel, void* stream);
+
+/* ---- strided GEMM  C[i*sci + j*scj] (=,+=) sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] + bias ----------------
+ * C must be a dense M x N matrix (row- or column-major).  bias is indexed by row i, or by column j when
+ * bias_on_columns != 0.  Replaces torch.nn.Linear forward/backward at reference coefficient/models.py:17-27,
+ * 36-49,80-92 and age/vgg.py:33-41. */
+int srgan_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,
+                   int64_t sbk, int64_t sbj, float* C, int64_t sci, int64_t scj, const float* bias,
+                   int32_t bias_on_columns, int accumulate, int force_kernel, void* stream);
+
+/* ---- elementwise ------------------------------------------------------------------------------------------
+ * Unary op codes: 0 copy, 1 neg, 2 abs, 3 sign, 4 sqrt, 5 exp, 6 log, 7 log1p, 8 square, 9 reciprocal, 10 tanh,
+ * 11 relu, 12 step (x > 0), 13 affine (p0*x + p1), 14 pow (x^p0), 15 leaky_relu (slope p0), 16 sigmoid,
+ * 17 softplus, 18 one_minus_square, 19 rsqrt.
+ * Binary op codes: 0 add, 1 sub, 2 mul, 3 div, 4 div_safe (0 where b == 0), 5 max,
+ * 6 leaky_mask_mul (a where b > 0 else p0*a: the backward of leaky_relu / relu), 7 axpy (a + p0*b).
+ * Replace torch elementwise call sites: leaky_relu/relu/tanh (reference coefficient/models.py:24-26;
+ * age/models.py:47-51,70-73; crowd/models.py:339,343,780-784,1150,1154), the distance functions
+ * (utility.py:201-243), logsumexp / BCE / CE pieces (utility.py:161-182, sgan.py:14-15). */
+int srgan_ew_unary(int op, const float* x, float* y, int64_t n, float p0, float p1, void* stream);
+int srgan_ew_binary(int op, const float* a, const float* b, float* y, int64_t n, float p0, void* stream);
+int srgan_fill(float* y, int64_t n, float value, void* stream);
+
+/* y[n,c,i] = ((x ? x[n,c,i] : 1) - mean[c]) * scale_a[c] * scale_b[c] + shift[c], i < HW; every vector optional.
+ * Frozen (eval-mode) batch-norm in one pass (mean = running_mean, scale_a = 1/sqrt(running_var + eps),
+ * scale_b = gamma, shift = beta: reference srgan.py:538-542 + crowd/models.py:338,342,367,1073,1091) and every
+ * broadcast: with N = 1 a per-row scale (gradient-penalty norms), with HW = 1 a per-column one. */
+int srgan_chan_affine(const float* x, const float* mean, const float* scale_a, const float* scale_b, const float* shift,
+                      float* y, int32_t N, int32_t C, int64_t HW, void* stream);
+
+/* out[c] (=,+=) scale[c] * sum_{n,i} a[n,c,i] * ((b ? b[n,c,i] : 1) - mean[c])  (b, mean, scale optional).
+ * Bias / batch-norm parameter gradients; with N = 1, C = batch it is the per-example dot product over C*H*W of
+ * the gradient penalty (reference srgan.py:371,381); with HW = 1 the batch sum behind feature means
+ * (srgan.py:442-443); with N = C = 1 a full sum. */
+int srgan_chan_reduce(const float* a, const float* b, const float* mean, const float* scale, float* out, int32_t N,
+                      int32_t C, int64_t HW, int accumulate, void* stream);
+/* out[b] = max_f x[b,f] (logsumexp stabiliser, reference utility.py:179) and the one-hot of the nearest bin
+ * (reference utility.py:141-144). */
+int srgan_row_max(const float* x, float* out, int32_t B, int32_t F, void* stream);
+int srgan_nearest_bin_onehot(const float* y, const float* bins, float* onehot, int32_t B, int32_t K, void* stream);
+
+/* dst[n, dst_first + c, :] (=,+=) src[n, src_first + c, :], c < count: channel concat / slice
+ * (reference crowd/models.py:353,1159-1165). */
+int srgan_copy_channels(const float* src, int32_t src_channels, int32_t src_first, float* dst, int32_t dst_channels,
+                        int32_t dst_first, int32_t count, int32_t N, int64_t HW, int accumulate, void* stream);
+
+/* ---- pooling (planes = N*C) --------------------------------------------------------------------------------
+ * reference crowd/models.py:371,1075,1151; age/vgg.py:76. */
+int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t planes, int32_t H, int32_t W, int32_t k,
+                        int32_t s, int32_t p, int32_t OH, int32_t OW, void* stream);
+int srgan_pool_scatter(const float* g, const int32_t* argmax, float* out, int32_t planes, int64_t in_plane,
+                       int64_t out_plane, void* stream);      /* max-pool backward (out is zero-filled first) */
+int srgan_pool_gather(const float* src, const int32_t* argmax, float* out, int32_t planes, int64_t in_plane,
+                      int64_t out_plane, void* stream);       /* max-pool double-backward */
+int srgan_avgpool2d_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t k, int32_t s,
+                        int32_t OH, int32_t OW, void* stream);
+int srgan_avgpool2d_bwd(const float* g, float* gx, int32_t planes, int32_t H, int32_t W, int32_t k, int32_t s,
+                        int32_t OH, int32_t OW, void* stream);
+
+/* ---- fused pieces of the step ------------------------------------------------------------------------------
+ * out = alpha[b]*u + (1 - alpha[b])*fake (reference srgan.py:365-366). */
+int srgan_gp_interpolate(const float* unlabeled, const float* fake, const float* alpha, float* out, int32_t B,
+                         int64_t F, void* stream);
+/* rows[b] = sum_{hw} mean_c |maps[b,c,hw] - target[b,hw]| and its backward (reference crowd/srgan.py:252). */
+int srgan_crowd_map_l1_fwd(const float* maps, const float* target, float* rows, int32_t B, int32_t Cm, int64_t HW,
+                           void* stream);
+int srgan_crowd_map_l1_bwd(const float* maps, const float* target, const float* g_rows, float* g_maps, int32_t B,
+                           int32_t Cm, int64_t HW, void* stream);
+/* Adam on a flat arena, torch.optim.Adam defaults and operation order (reference srgan.py:131-138,266,297,305);
+ * `step` is the 1-based update count. */
+int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRGAN_HIP_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libsrgan_hip.so (include/srgan_hip.h).  There is no fallback: if the library is
+missing or a call fails, an exception is raised."""
+import ctypes
+import os
+
+from ._build import LIBRARY
+
+c_float_p = ctypes.c_void_p
+i32, i64, f32, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``srgan_conv_desc``."""
+    _fields_ = [(name, i32) for name in ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride_h', 'stride_w', 'pad_h', 'pad_w',
+                                         'OH', 'OW')] + [('x_batch_stride', i64), ('y_batch_stride', i64)]
+
+
+SIGNATURES = {
+    'srgan_version': ([], ctypes.c_int),
+    'srgan_last_error': ([], ctypes.c_char_p),
+    'srgan_conv2d_fwd': ([ctypes.POINTER(ConvDesc), vp, vp, vp, vp, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_conv2d_bwd_data': ([ctypes.POINTER(ConvDesc), vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp],
+                              ctypes.c_int),
+    'srgan_conv2d_bwd_weight': ([ctypes.POINTER(ConvDesc), vp, vp, vp, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_gemm_f32': ([i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i32, ctypes.c_int, ctypes.c_int,
+                        vp], ctypes.c_int),
+    'srgan_ew_unary': ([ctypes.c_int, vp, vp, i64, f32, f32, vp], ctypes.c_int),
+    'srgan_ew_binary': ([ctypes.c_int, vp, vp, vp, i64, f32, vp], ctypes.c_int),
+    'srgan_fill': ([vp, i64, f32, vp], ctypes.c_int),
+    'srgan_chan_affine': ([vp, vp, vp, vp, vp, vp, i32, i32, i64, vp], ctypes.c_int),
+    'srgan_chan_reduce': ([vp, vp, vp, vp, vp, i32, i32, i64, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_row_max': ([vp, vp, i32, i32, vp], ctypes.c_int),
+    'srgan_nearest_bin_onehot': ([vp, vp, vp, i32, i32, vp], ctypes.c_int),
+    'srgan_copy_channels': ([vp, i32, i32, vp, i32, i32, i32, i32, i64, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_maxpool2d_fwd': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], ctypes.c_int),
+    'srgan_pool_scatter': ([vp, vp, vp, i32, i64, i64, vp], ctypes.c_int),
+    'srgan_pool_gather': ([vp, vp, vp, i32, i64, i64, vp], ctypes.c_int),
+    'srgan_avgpool2d_fwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], ctypes.c_int),
+    'srgan_avgpool2d_bwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], ctypes.c_int),
+    'srgan_gp_interpolate': ([vp, vp, vp, vp, i32, i64, vp], ctypes.c_int),
+    'srgan_crowd_map_l1_fwd': ([vp, vp, vp, i32, i32, i64, vp], ctypes.c_int),
+    'srgan_crowd_map_l1_bwd': ([vp, vp, vp, vp, i32, i32, i64, vp], ctypes.c_int),
+    'srgan_adam_step': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp], ctypes.c_int),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_library = None
+
+
+def library():
+    """The loaded shared object with typed entry points; raises if it has not been built."""
+    global _library
+    if _library is None:
+        if not os.path.exists(LIBRARY):
+            raise HipLibraryError(f'{LIBRARY} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                                  '(there is no CPU fallback)')
+        lib = ctypes.CDLL(LIBRARY)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            function = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+            function.argtypes = argtypes
+            function.restype = restype
+        _library = lib
+    return _library
+
+
+def check(status, what):
+    if status != 0:
+        message = library().srgan_last_error()
+        raise HipLibraryError(f'{what} failed with status {status}: {message.decode() if message else ""}')

@@ -1,0 +1,66 @@
+// common.h -- error plumbing and small device helpers shared by every translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace srgan {
+
+// Status convention of the C ABI (include/srgan_hip.h): 0 ok, <0 argument/shape error, >0 hipError_t.
+enum { SRGAN_OK = 0, SRGAN_EINVAL = -1, SRGAN_EUNSUPPORTED = -2, SRGAN_ERANGE = -3 };
+
+void set_error(const char* fmt, ...);
+
+#define SRGAN_HIP(expr)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ::srgan::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return (int)e_;                                                                    \
+    }                                                                                    \
+  } while (0)
+
+#define SRGAN_REQUIRE(cond, code, msg)                                                   \
+  do {                                                                                   \
+    if (!(cond)) {                                                                       \
+      ::srgan::set_error("%s: requirement (%s) failed", msg, #cond);                     \
+      return code;                                                                       \
+    }                                                                                    \
+  } while (0)
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("kernel launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return SRGAN_OK;
+}
+
+// Grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs x 8, never more than the work.
+inline unsigned stream_grid(int64_t work_items, int per_block) {
+  int64_t blocks = (work_items + per_block - 1) / per_block;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (unsigned)blocks;
+}
+
+// Sum across the 64 lanes of a wavefront (DPP/shuffle butterfly); every lane returns the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int offset = 32; offset > 0; offset >>= 1) v += __shfl_xor(v, offset, 64);
+  return v;
+}
+
+// Block-wide sum for 256-thread blocks; result valid in thread 0.
+__device__ __forceinline__ float block_sum_256(float v, float* scratch4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) scratch4[wave] = v;
+  __syncthreads();
+  float total = 0.f;
+  if (threadIdx.x == 0) total = scratch4[0] + scratch4[1] + scratch4[2] + scratch4[3];
+  return total;
+}
+
+}  // namespace srgan

@@ -1,0 +1,285 @@
+// elementwise.hip -- HBM-bound streaming kernels: unary / binary maps, per-channel affine broadcast
+// (frozen batch-norm, bias, row / column / scalar broadcasts) and channel-range copies (concat / slice).
+// All are one read + one write per element (roofline: HBM ~6.3 TB/s achievable), float4 wide, grid-stride
+// over at most 2048 workgroups.
+#include "common.h"
+
+namespace srgan {
+
+enum UnaryOp { U_COPY = 0, U_NEG, U_ABS, U_SIGN, U_SQRT, U_EXP, U_LOG, U_LOG1P, U_SQUARE, U_RECIP, U_TANH, U_RELU,
+               U_STEP, U_AFFINE, U_POW, U_LEAKY, U_SIGMOID, U_SOFTPLUS, U_ONE_MINUS_SQ, U_RSQRT, U_COUNT };
+enum BinaryOp { B_ADD = 0, B_SUB, B_MUL, B_DIV, B_DIV_SAFE, B_MAX, B_LEAKY_MASK_MUL, B_AXPY, B_COUNT };
+
+template <int OP>
+__device__ __forceinline__ float unary(float x, float p0, float p1) {
+  switch (OP) {
+    case U_COPY: return x;
+    case U_NEG: return -x;
+    case U_ABS: return fabsf(x);
+    case U_SIGN: return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+    case U_SQRT: return sqrtf(x);
+    case U_EXP: return expf(x);
+    case U_LOG: return logf(x);
+    case U_LOG1P: return log1pf(x);
+    case U_SQUARE: return x * x;
+    case U_RECIP: return 1.f / x;
+    case U_TANH: return tanhf(x);
+    case U_RELU: return x > 0.f ? x : 0.f;
+    case U_STEP: return x > 0.f ? 1.f : 0.f;
+    case U_AFFINE: return p0 * x + p1;
+    case U_POW: return powf(x, p0);
+    case U_LEAKY: return x > 0.f ? x : p0 * x;
+    case U_SIGMOID: return 1.f / (1.f + expf(-x));
+    case U_SOFTPLUS: return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+    case U_ONE_MINUS_SQ: return 1.f - x * x;
+    case U_RSQRT: return 1.f / sqrtf(x);
+  }
+  return x;
+}
+
+template <int OP>
+__device__ __forceinline__ float binary(float a, float b, float p0) {
+  switch (OP) {
+    case B_ADD: return a + b;
+    case B_SUB: return a - b;
+    case B_MUL: return a * b;
+    case B_DIV: return a / b;
+    case B_DIV_SAFE: return b == 0.f ? 0.f : a / b;
+    case B_MAX: return fmaxf(a, b);
+    case B_LEAKY_MASK_MUL: return b > 0.f ? a : p0 * a;
+    case B_AXPY: return a + p0 * b;
+  }
+  return a;
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                    float p0, float p1) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 v = x4[i];
+    v.x = unary<OP>(v.x, p0, p1); v.y = unary<OP>(v.y, p0, p1);
+    v.z = unary<OP>(v.z, p0, p1); v.w = unary<OP>(v.w, p0, p1);
+    y4[i] = v;
+  }
+  const int64_t tail = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (tail < n) y[tail] = unary<OP>(x[tail], p0, p1);
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ y, int64_t n, float p0) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 u = a4[i], v = b4[i];
+    float4 r;
+    r.x = binary<OP>(u.x, v.x, p0); r.y = binary<OP>(u.y, v.y, p0);
+    r.z = binary<OP>(u.z, v.z, p0); r.w = binary<OP>(u.w, v.w, p0);
+    y4[i] = r;
+  }
+  const int64_t tail = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (tail < n) y[tail] = binary<OP>(a[tail], b[tail], p0);
+}
+
+template <int OP>
+static int launch_unary(const float* x, float* y, int64_t n, float p0, float p1, hipStream_t s) {
+  hipLaunchKernelGGL(unary_kernel<OP>, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, s, x, y, n, p0, p1);
+  return launch_status();
+}
+
+template <int OP>
+static int launch_binary(const float* a, const float* b, float* y, int64_t n, float p0, hipStream_t s) {
+  hipLaunchKernelGGL(binary_kernel<OP>, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, s, a, b, y, n, p0);
+  return launch_status();
+}
+
+// y[r, i] = (x[r, i] - mean[c]) * scale_a[c] * scale_b[c] + shift[c],  c = r % C, rows of length HW >= 1; every
+// vector is optional (x defaults to 1).  Frozen batch-norm is ONE pass: mean = running mean, scale_a =
+// 1/sqrt(var + eps), scale_b = gamma, shift = beta.  One workgroup per (row, segment): no per-element index math.
+constexpr int AFF_SEG = 256 * 4 * 4;
+__device__ __forceinline__ void chan_coefficients(const float* mean, const float* scale_a, const float* scale_b,
+                                                  const float* shift, int c, float& a, float& b) {
+  a = (scale_a ? scale_a[c] : 1.f) * (scale_b ? scale_b[c] : 1.f);
+  b = (shift ? shift[c] : 0.f) - (mean ? mean[c] * a : 0.f);
+}
+
+__global__ __launch_bounds__(256) void chan_affine_rows_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ scale_a,
+                                                               const float* __restrict__ scale_b,
+                                                               const float* __restrict__ shift, float* __restrict__ y,
+                                                               int C, int64_t HW, int segs, int64_t total_blocks) {
+  for (int64_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+    const int64_t row = blk / segs;
+    const int seg = (int)(blk - row * segs);
+    const int c = (int)(row % C);
+    float a, b;
+    chan_coefficients(mean, scale_a, scale_b, shift, c, a, b);
+    const int64_t base = row * HW, beg = (int64_t)seg * AFF_SEG;
+    const int64_t end = beg + AFF_SEG < HW ? beg + AFF_SEG : HW;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) y[base + i] = (x ? x[base + i] : 1.f) * a + b;
+  }
+}
+
+__global__ __launch_bounds__(256) void chan_affine_flat_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ scale_a,
+                                                               const float* __restrict__ scale_b,
+                                                               const float* __restrict__ shift, float* __restrict__ y,
+                                                               int C, int HW, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int c = (int)((i / HW) % C);
+    float a, b;
+    chan_coefficients(mean, scale_a, scale_b, shift, c, a, b);
+    y[i] = (x ? x[i] : 1.f) * a + b;
+  }
+}
+
+// dst[n, d0 + c, :] (=, +=) src[n, s0 + c, :] for c < count: a contiguous run of count*HW floats per image.
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int64_t src_image, int64_t dst_image, int64_t src_off,
+                                                            int64_t dst_off, int64_t run, int N, int accumulate) {
+  const int64_t total = run * N, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t n = i / run, r = i - n * run;
+    const float v = src[n * src_image + src_off + r];
+    float* d = dst + n * dst_image + dst_off + r;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// out[b, f] = alpha[b] * u[b, f] + (1 - alpha[b]) * fake[b, f]   (reference srgan.py:365-366)
+__global__ __launch_bounds__(256) void gp_interpolate_kernel(const float* __restrict__ u, const float* __restrict__ fake,
+                                                             const float* __restrict__ alpha, float* __restrict__ out,
+                                                             int64_t F, int segs, int64_t total_blocks) {
+  for (int64_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+    const int64_t b = blk / segs;
+    const int seg = (int)(blk - b * segs);
+    const float a = alpha[b], na = 1.f - a;
+    const int64_t base = b * F, beg = (int64_t)seg * AFF_SEG;
+    const int64_t end = beg + AFF_SEG < F ? beg + AFF_SEG : F;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) out[base + i] = a * u[base + i] + na * fake[base + i];
+  }
+}
+
+// Adam on a flat parameter arena, same operation order as torch.optim.Adam (single tensor path):
+// g += wd * p;  m = lerp(m, g, 1 - b1);  v = b2 * v + (1 - b2) * g * g;
+// p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)      (reference srgan.py:131-138 -> torch Adam defaults)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float beta1, float beta2, float eps, float weight_decay,
+                                                   float bias_correction1, float bias_correction2_sqrt) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const float step_size = lr / bias_correction1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float grad = g[i];
+    const float param = p[i];
+    if (weight_decay != 0.f) grad = grad + weight_decay * param;
+    float mi = m[i], vi = v[i];
+    mi = mi + (grad - mi) * (1.f - beta1);
+    vi = vi * beta2 + (1.f - beta2) * grad * grad;
+    const float denom = sqrtf(vi) / bias_correction2_sqrt + eps;
+    p[i] = param - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+}  // namespace srgan
+
+using namespace srgan;
+
+extern "C" {
+
+int srgan_ew_unary(int op, const float* x, float* y, int64_t n, float p0, float p1, void* stream) {
+  SRGAN_REQUIRE(x && y && n >= 0 && op >= 0 && op < U_COUNT, SRGAN_EINVAL, "srgan_ew_unary arguments");
+  if (n == 0) return SRGAN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (op) {
+#define CASE(OP) case OP: return launch_unary<OP>(x, y, n, p0, p1, s);
+    CASE(U_COPY) CASE(U_NEG) CASE(U_ABS) CASE(U_SIGN) CASE(U_SQRT) CASE(U_EXP) CASE(U_LOG) CASE(U_LOG1P)
+    CASE(U_SQUARE) CASE(U_RECIP) CASE(U_TANH) CASE(U_RELU) CASE(U_STEP) CASE(U_AFFINE) CASE(U_POW) CASE(U_LEAKY)
+    CASE(U_SIGMOID) CASE(U_SOFTPLUS) CASE(U_ONE_MINUS_SQ) CASE(U_RSQRT)
+#undef CASE
+  }
+  return SRGAN_EINVAL;
+}
+
+int srgan_ew_binary(int op, const float* a, const float* b, float* y, int64_t n, float p0, void* stream) {
+  SRGAN_REQUIRE(a && b && y && n >= 0 && op >= 0 && op < B_COUNT, SRGAN_EINVAL, "srgan_ew_binary arguments");
+  if (n == 0) return SRGAN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (op) {
+#define CASE(OP) case OP: return launch_binary<OP>(a, b, y, n, p0, s);
+    CASE(B_ADD) CASE(B_SUB) CASE(B_MUL) CASE(B_DIV) CASE(B_DIV_SAFE) CASE(B_MAX) CASE(B_LEAKY_MASK_MUL) CASE(B_AXPY)
+#undef CASE
+  }
+  return SRGAN_EINVAL;
+}
+
+int srgan_fill(float* y, int64_t n, float value, void* stream) {
+  SRGAN_REQUIRE(y && n >= 0, SRGAN_EINVAL, "srgan_fill arguments");
+  if (n == 0) return SRGAN_OK;
+  if (value == 0.f) { SRGAN_HIP(hipMemsetAsync(y, 0, (size_t)n * sizeof(float), (hipStream_t)stream)); return SRGAN_OK; }
+  return launch_unary<U_AFFINE>(y, y, n, 0.f, value, (hipStream_t)stream);
+}
+
+int srgan_chan_affine(const float* x, const float* mean, const float* scale_a, const float* scale_b, const float* shift,
+                      float* y, int32_t N, int32_t C, int64_t HW, void* stream) {
+  SRGAN_REQUIRE(y && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_affine arguments");
+  const int64_t n = (int64_t)N * C * HW;
+  hipStream_t s = (hipStream_t)stream;
+  if (HW >= 256) {
+    const int segs = (int)((HW + AFF_SEG - 1) / AFF_SEG);
+    const int64_t blocks = (int64_t)N * C * segs;
+    const unsigned grid = (unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16);
+    hipLaunchKernelGGL(chan_affine_rows_kernel, dim3(grid), dim3(256), 0, s, x, mean, scale_a, scale_b, shift, y, C, HW, segs,
+                       blocks);
+  } else {
+    hipLaunchKernelGGL(chan_affine_flat_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, mean, scale_a, scale_b, shift,
+                       y, C, (int)HW, n);
+  }
+  return launch_status();
+}
+
+int srgan_copy_channels(const float* src, int32_t src_channels, int32_t src_first, float* dst, int32_t dst_channels,
+                        int32_t dst_first, int32_t count, int32_t N, int64_t HW, int accumulate, void* stream) {
+  SRGAN_REQUIRE(src && dst && N > 0 && HW > 0 && count > 0, SRGAN_EINVAL, "srgan_copy_channels arguments");
+  SRGAN_REQUIRE(src_first >= 0 && dst_first >= 0 && src_first + count <= src_channels &&
+                dst_first + count <= dst_channels, SRGAN_EINVAL, "srgan_copy_channels channel ranges");
+  const int64_t run = (int64_t)count * HW;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid(run * N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, (int64_t)src_channels * HW, (int64_t)dst_channels * HW, (int64_t)src_first * HW,
+                     (int64_t)dst_first * HW, run, N, accumulate);
+  return launch_status();
+}
+
+int srgan_gp_interpolate(const float* unlabeled, const float* fake, const float* alpha, float* out, int32_t B,
+                         int64_t F, void* stream) {
+  SRGAN_REQUIRE(unlabeled && fake && alpha && out && B > 0 && F > 0, SRGAN_EINVAL, "srgan_gp_interpolate arguments");
+  const int segs = (int)((F + AFF_SEG - 1) / AFF_SEG);
+  const int64_t blocks = (int64_t)B * segs;
+  const unsigned grid = (unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16);
+  hipLaunchKernelGGL(gp_interpolate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, unlabeled, fake, alpha, out,
+                     F, segs, blocks);
+  return launch_status();
+}
+
+int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, void* stream) {
+  SRGAN_REQUIRE(p && g && m && v && n >= 0 && step >= 1, SRGAN_EINVAL, "srgan_adam_step arguments");
+  if (n == 0) return SRGAN_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
+                     beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,373 @@
+// gather_gemm_kernels.hip -- the MFMA contraction kernel behind every convolution / linear pass.
+//
+// One 256-thread workgroup (4 wavefronts of 64) owns a BM x BN tile of C.  Per K-step of 16 the tile's A
+// (BM x 16) and B (16 x BN) slices are gathered from HBM into registers (next step's loads are issued
+// before the current step's MFMAs so HBM latency hides under the matrix pipe), written to LDS as
+// [k][m] / [k][n] rows padded by one word (conflict-free ds_read_b32 for the MFMA operand pattern), and
+// consumed by v_mfma_f32_32x32x2_f32: exact fp32, 157 TF/s peak on gfx950.  Lanes map to C columns, so
+// stores are 128-byte runs along the contiguous (pixel) dimension of NCHW.
+//
+// Roofline (MI355X_MICROARCH.md): fp32 MFMA 157.3 TF/s; the gather adds ~30 VALU ops per staged element,
+// which overlaps with the 64-cycle MFMAs of the other waves on the SIMD.
+#include "common.h"
+#include "gather_gemm.h"
+#include "conv_plan.h"
+#include <stdarg.h>
+#include <string.h>
+
+namespace srgan {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+const char* last_error() { return g_error; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GG_BK = 16;
+
+template <int BM, int BN, int WGM, bool AKF, bool BKF>
+__global__ __launch_bounds__(256) void gg_mfma_kernel(const GatherGemm p) {
+  constexpr int BK = GG_BK;
+  constexpr int WGN = 4 / WGM;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+  constexpr int LDA = BM + 1, LDB = BN + 1;
+  static_assert(MI >= 1 && NI >= 1 && EA >= 1 && EB >= 1, "tile too small for 4 waves");
+  __shared__ float lds[BK * LDA + BK * LDB];
+  float* As = lds;
+  float* Bs = lds + BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int m0 = (int)(blockIdx.x % tiles_m) * BM, n0 = (int)(blockIdx.x / tiles_m) * BN;
+  const int kbeg = (int)blockIdx.y * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+
+  // Per-thread staging coordinates.  With k-fast staging consecutive lanes walk k (the operand's contiguous
+  // direction), otherwise they walk m / n.
+  int a_kk[EA], a_ml[EA], b_kk[EB], b_nl[EB];
+#pragma unroll
+  for (int e = 0; e < EA; ++e) {
+    const int flat = e * 256 + tid;
+    a_kk[e] = AKF ? flat % BK : flat / BM;
+    a_ml[e] = AKF ? flat / BK : flat % BM;
+  }
+#pragma unroll
+  for (int e = 0; e < EB; ++e) {
+    const int flat = e * 256 + tid;
+    b_kk[e] = BKF ? flat % BK : flat / BN;
+    b_nl[e] = BKF ? flat / BK : flat % BN;
+  }
+  // Loop-invariant halves of the address computation.
+  Side a_m[AKF ? EA : 1], b_n[BKF ? EB : 1];
+#pragma unroll
+  for (int e = 0; e < (AKF ? EA : 1); ++e) a_m[e] = decode(p.am, m0 + a_ml[e]);
+#pragma unroll
+  for (int e = 0; e < (BKF ? EB : 1); ++e) b_n[e] = decode(p.bn, n0 + b_nl[e]);
+
+  float ra[EA], rb[EB];
+  auto fetch = [&](int k0) {
+    if (AKF) {
+      const int k = k0 + a_kk[0];
+      const Side sk = decode(p.ak, k);
+      const bool kok = sk.valid && k < kend;
+#pragma unroll
+      for (int e = 0; e < EA; ++e) ra[e] = (kok && a_m[e].valid) ? p.A[a_m[e].off + sk.off] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < EA; ++e) {
+        const int k = k0 + a_kk[e];
+        const Side sk = decode(p.ak, k);
+        ra[e] = (sk.valid && k < kend && a_m[0].valid) ? p.A[a_m[0].off + sk.off] : 0.f;
+      }
+    }
+    if (BKF) {
+      const int k = k0 + b_kk[0];
+      const Side sk = decode(p.bk, k);
+      const bool kok = sk.valid && k < kend;
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const Side sn = b_n[e];
+        const bool ok = kok && sn.valid && (uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim &&
+                        (uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim;
+        rb[e] = ok ? p.B[sk.off + sn.off] : 0.f;
+      }
+    } else {
+      const Side sn = b_n[0];
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const int k = k0 + b_kk[e];
+        const Side sk = decode(p.bk, k);
+        const bool ok = sk.valid && k < kend && sn.valid && (uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim &&
+                        (uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim;
+        rb[e] = ok ? p.B[sk.off + sn.off] : 0.f;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) As[a_kk[e] * LDA + a_ml[e]] = ra[e];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) Bs[b_kk[e] * LDB + b_nl[e]] = rb[e];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  if (kbeg < kend) {
+    fetch(kbeg);
+    stage();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = k0 + BK < kend;
+      if (more) fetch(k0 + BK);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = As[(kk + lhi) * LDA + wm0 + mi * 32 + l31];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = Bs[(kk + lhi) * LDB + wn0 + ni * 32 + l31];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        stage();
+        __syncthreads();
+      }
+    }
+  }
+
+  // Epilogue: C/D fragment of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const Side sn = decode(p.cn, n0 + wn0 + ni * 32 + l31);
+    if (!sn.valid) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const Side sm = decode(p.cm, i);
+        if (!sm.valid) continue;
+        float v = acc[mi][ni][r];
+        if (add_bias) v += p.bias[p.bias_cols ? sn.c : sm.c];
+        float* dst = p.C + (uint32_t)(sm.off + sn.off);
+        if (p.mode == GG_STORE) *dst = v;
+        else if (p.mode == GG_ACCUMULATE) *dst += v;
+        else unsafeAtomicAdd(dst, v);
+      }
+    }
+  }
+}
+
+// Direct form for very skinny outputs (M <= 4: single-channel map heads, RGB generator output, count
+// layers): one thread per C element, lanes along columns, A broadcast.  HBM/L2-bound, no matrix core.
+__global__ __launch_bounds__(256) void gg_direct_kernel(const GatherGemm p) {
+  const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int i = (int)blockIdx.y;
+  const int kbeg = (int)blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const Side am = decode(p.am, i), cm = decode(p.cm, i);
+  const Side bn = decode(p.bn, j), cn = decode(p.cn, j);
+  if (!cn.valid || !cm.valid) return;
+  float acc = 0.f;
+  for (int k = kbeg; k < kend; ++k) {
+    const Side ak = decode(p.ak, k), bk = decode(p.bk, k);
+    acc = fmaf(gg_a(p, am, ak), gg_b(p, bk, bn), acc);
+  }
+  if (p.bias != nullptr && blockIdx.z == 0) acc += p.bias[p.bias_cols ? cn.c : cm.c];
+  float* dst = p.C + (uint32_t)(cm.off + cn.off);
+  if (p.mode == GG_STORE) *dst = acc;
+  else if (p.mode == GG_ACCUMULATE) *dst += acc;
+  else unsafeAtomicAdd(dst, acc);
+}
+
+// ------------------------------------------------------------------------------------------- launcher
+struct GGConfig { int kind; int bm, bn; int tiles; };   // kind 0 direct, 1 mfma
+
+static GGConfig choose_config(const GatherGemm& p, int force) {
+  GGConfig c;
+  if ((p.M <= 4 && force != 2) || force == 1) {
+    c.kind = 0; c.bm = 1; c.bn = 256;
+    c.tiles = p.M * ((p.N + 255) / 256);
+    return c;
+  }
+  c.kind = 1;
+  c.bm = p.M > 64 ? 128 : (p.M > 32 ? 64 : 32);
+  const int big = c.bm == 32 ? 256 : 128, small = c.bm == 32 ? 128 : 64;
+  const int tm = (p.M + c.bm - 1) / c.bm;
+  const int tiles_big = tm * ((p.N + big - 1) / big);
+  c.bn = tiles_big >= 512 ? big : small;
+  c.tiles = tm * ((p.N + c.bn - 1) / c.bn);
+  return c;
+}
+
+static void choose_split(GatherGemm& p, const GGConfig& c, bool allow_split) {
+  p.split_k = 1;
+  p.k_per_split = p.K > 0 ? ((p.K + GG_BK - 1) / GG_BK) * GG_BK : GG_BK;
+  if (!allow_split || p.K < 128 || c.tiles >= 256) return;
+  const int want = (512 + c.tiles - 1) / c.tiles;
+  const int max_split = p.K / 64;
+  int split = want < max_split ? want : max_split;
+  if (split <= 1) return;
+  int per = (p.K + split - 1) / split;
+  per = ((per + GG_BK - 1) / GG_BK) * GG_BK;
+  p.k_per_split = per;
+  p.split_k = (p.K + per - 1) / per;
+}
+
+template <int BM, int BN, int WGM>
+static void launch_mfma(const GatherGemm& p, dim3 grid, hipStream_t stream) {
+  if (p.a_kfast && p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, true>), grid, dim3(256), 0, stream, p);
+  else if (p.a_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, false>), grid, dim3(256), 0, stream, p);
+  else if (p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, true>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, false>), grid, dim3(256), 0, stream, p);
+}
+
+// Plans one launch: fills split_k / k_per_split; returns whether the launch needs a zeroed (or live) C because
+// it combines K-slices with atomics.
+bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
+  GGConfig c = choose_config(p, force);
+  choose_split(p, c, true);
+  if (out) *out = c;
+  return p.split_k > 1;
+}
+
+int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0) return SRGAN_OK;
+  if (c.kind == 0) {
+    dim3 grid((p.N + 255) / 256, p.M, p.split_k);
+    SRGAN_REQUIRE(p.M <= 65535 && p.split_k <= 65535, SRGAN_ERANGE, "direct gather-gemm grid");
+    hipLaunchKernelGGL(gg_direct_kernel, grid, dim3(256), 0, stream, p);
+    return launch_status();
+  }
+  dim3 grid(c.tiles, p.split_k, 1);
+  SRGAN_REQUIRE(p.split_k <= 65535, SRGAN_ERANGE, "split-k grid");
+  if (c.bm == 128 && c.bn == 128) launch_mfma<128, 128, 2>(p, grid, stream);
+  else if (c.bm == 128 && c.bn == 64) launch_mfma<128, 64, 2>(p, grid, stream);
+  else if (c.bm == 64 && c.bn == 128) launch_mfma<64, 128, 2>(p, grid, stream);
+  else if (c.bm == 64 && c.bn == 64) launch_mfma<64, 64, 2>(p, grid, stream);
+  else if (c.bm == 32 && c.bn == 256) launch_mfma<32, 256, 1>(p, grid, stream);
+  else launch_mfma<32, 128, 1>(p, grid, stream);
+  return launch_status();
+}
+
+// Runs a group of plans that together define one dense output tensor of c_elems floats.  `accumulate` adds
+// into the existing contents; otherwise the output is (over)written.  force: 0 auto, 1 direct, 2 mfma.
+int gg_run_group(std::vector<GatherGemm>& plans, float* c_base, int64_t c_elems, int accumulate, int force,
+                 hipStream_t stream) {
+  std::vector<GGConfig> configs(plans.size());
+  bool any_atomic = false;
+  for (size_t i = 0; i < plans.size(); ++i) any_atomic |= gg_prepare(plans[i], force, &configs[i]);
+  if (any_atomic && !accumulate) SRGAN_HIP(hipMemsetAsync(c_base, 0, (size_t)c_elems * sizeof(float), stream));
+  for (size_t i = 0; i < plans.size(); ++i) {
+    GatherGemm& p = plans[i];
+    if (p.split_k > 1) p.mode = GG_ATOMIC;
+    else p.mode = accumulate ? GG_ACCUMULATE : GG_STORE;
+    const int status = gg_launch(p, configs[i], stream);
+    if (status != SRGAN_OK) return status;
+  }
+  return SRGAN_OK;
+}
+
+}  // namespace srgan
+
+// ------------------------------------------------------------------------------------------- C ABI
+using namespace srgan;
+
+extern "C" {
+
+struct srgan_conv_desc {
+  int32_t N, C, H, W, K, R, S, stride_h, stride_w, pad_h, pad_w, OH, OW;
+  int64_t x_batch_stride, y_batch_stride;
+};
+
+static bool to_geom(const srgan_conv_desc* d, ConvGeom& g) {
+  if (d == nullptr) return false;
+  g.N = d->N; g.C = d->C; g.H = d->H; g.W = d->W; g.K = d->K; g.R = d->R; g.S = d->S;
+  g.sh = d->stride_h; g.sw = d->stride_w; g.ph = d->pad_h; g.pw = d->pad_w; g.OH = d->OH; g.OW = d->OW;
+  g.x_bs = d->x_batch_stride; g.y_bs = d->y_batch_stride;
+  return geom_ok(g);
+}
+
+const char* srgan_last_error(void) { return last_error(); }
+
+int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w, const float* bias, float* y,
+                     int force_kernel, void* stream) {
+  ConvGeom g;
+  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_fwd geometry");
+  SRGAN_REQUIRE(x && w && y, SRGAN_EINVAL, "srgan_conv2d_fwd pointers");
+  SRGAN_REQUIRE(g.y_bs == (int64_t)g.K * g.OH * g.OW || true, SRGAN_EINVAL, "");
+  std::vector<GatherGemm> plans{plan_conv_fwd(g, x, w, bias, y)};
+  // A strided-batch output view cannot be memset as one block: forbid K-splitting there.
+  const bool dense_out = g.y_bs == (int64_t)g.K * g.OH * g.OW;
+  if (!dense_out) {
+    GGConfig c = choose_config(plans[0], force_kernel);
+    choose_split(plans[0], c, false);
+    plans[0].mode = GG_STORE;
+    return gg_launch(plans[0], c, (hipStream_t)stream);
+  }
+  return gg_run_group(plans, y, (int64_t)g.N * g.y_bs, 0, force_kernel, (hipStream_t)stream);
+}
+
+int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const float* w, const float* bias,
+                          float* gx, int accumulate, int force_kernel, void* stream) {
+  ConvGeom g;
+  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_data geometry");
+  SRGAN_REQUIRE(gy && w && gx, SRGAN_EINVAL, "srgan_conv2d_bwd_data pointers");
+  SRGAN_REQUIRE(g.x_bs == (int64_t)g.C * g.H * g.W, SRGAN_EUNSUPPORTED, "srgan_conv2d_bwd_data dense gx");
+  std::vector<GatherGemm> plans = plan_conv_bwd_data(g, gy, w, bias, gx);
+  return gg_run_group(plans, gx, (int64_t)g.N * g.x_bs, accumulate, force_kernel, (hipStream_t)stream);
+}
+
+int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const float* gy, float* gw,
+                            int accumulate, int force_kernel, void* stream) {
+  ConvGeom g;
+  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_weight geometry");
+  SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
+  std::vector<GatherGemm> plans{plan_conv_bwd_weight(g, x, gy, gw)};
+  return gg_run_group(plans, gw, (int64_t)g.K * g.C * g.R * g.S, accumulate, force_kernel, (hipStream_t)stream);
+}
+
+int srgan_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,
+                   int64_t sbk, int64_t sbj, float* C, int64_t sci, int64_t scj, const float* bias,
+                   int32_t bias_on_columns, int accumulate, int force_kernel, void* stream) {
+  SRGAN_REQUIRE(M > 0 && N > 0 && K >= 0 && A && B && C, SRGAN_EINVAL, "srgan_gemm_f32 arguments");
+  const int64_t lim = (int64_t)1 << 31;
+  SRGAN_REQUIRE(M * sai + K * sak < lim && K * sbk + N * sbj < lim && M * sci + N * scj < lim, SRGAN_ERANGE,
+                "srgan_gemm_f32 extents");
+  // C must be a dense M x N matrix in one of the two orientations so that it can be zeroed for split-K.
+  SRGAN_REQUIRE((scj == 1 && sci == N) || (sci == 1 && scj == M), SRGAN_EUNSUPPORTED, "srgan_gemm_f32 dense C");
+  GatherGemm p = plan_gemm(M, N, K, A, (int32_t)sai, (int32_t)sak, B, (int32_t)sbk, (int32_t)sbj, C, (int32_t)sci,
+                           (int32_t)scj, bias, bias_on_columns);
+  if (sci == 1 && scj != 1) {   // make the lane dimension the contiguous one
+    p = gg_transposed(p);
+    choose_staging(p);
+  }
+  std::vector<GatherGemm> plans{p};
+  return gg_run_group(plans, C, (int64_t)M * N, accumulate, force_kernel, (hipStream_t)stream);
+}
+
+}  // extern "C"

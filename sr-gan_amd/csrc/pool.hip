@@ -1,0 +1,158 @@
+// pool.hip -- max / average pooling for NCHW fp32 (DenseNet stem max-pool k3 s2 p1, VGG k2 s2, transition
+// average pools, final global pool).  HBM-bound gather / scatter kernels, one thread per output element.
+// Max-pool keeps the flat in-plane arg-max so that backward (scatter) and double-backward (gather) reuse
+// the forward's choice; ties resolve to the first maximum in row-major window order, as torch's CPU kernel.
+#include "common.h"
+#include <math.h>
+
+namespace srgan {
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int32_t* __restrict__ idx, int H, int W, int k, int s, int p,
+                                                          int OH, int OW, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
+    const int ow = (int)(o % OW);
+    const int oh = (int)((o / OW) % OH);
+    const int64_t plane = o / ((int64_t)OW * OH);
+    const float* src = x + plane * H * W;
+    const int h0 = oh * s - p, w0 = ow * s - p;
+    float best = -INFINITY;
+    int best_i = -1;
+    for (int r = 0; r < k; ++r) {
+      const int h = h0 + r;
+      if (h < 0 || h >= H) continue;
+      for (int c = 0; c < k; ++c) {
+        const int w = w0 + c;
+        if (w < 0 || w >= W) continue;
+        const float v = src[h * W + w];
+        if (v > best || best_i < 0 || v != v) { best = v; best_i = h * W + w; }
+      }
+    }
+    y[o] = best;
+    idx[o] = best_i;
+  }
+}
+
+// out (zeroed by the caller) [plane, idx[o]] += g[o]
+__global__ __launch_bounds__(256) void pool_scatter_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx,
+                                                           float* __restrict__ out, int64_t in_plane,
+                                                           int64_t out_plane, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
+    const int64_t plane = o / out_plane;
+    unsafeAtomicAdd(out + plane * in_plane + idx[o], g[o]);
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t in_plane, int64_t out_plane,
+                                                          int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
+    const int64_t plane = o / out_plane;
+    out[o] = src[plane * in_plane + idx[o]];
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
+                                                          int W, int k, int s, int OH, int OW, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const float inv = 1.f / (float)(k * k);
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
+    const int ow = (int)(o % OW);
+    const int oh = (int)((o / OW) % OH);
+    const int64_t plane = o / ((int64_t)OW * OH);
+    const float* src = x + plane * H * W + (int64_t)(oh * s) * W + ow * s;
+    float acc = 0.f;
+    for (int r = 0; r < k; ++r)
+      for (int c = 0; c < k; ++c) acc += src[r * W + c];
+    y[o] = acc * inv;
+  }
+}
+
+// gx[h, w] = (1 / k^2) * sum of g over the output windows that contain (h, w)
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int H,
+                                                          int W, int k, int s, int OH, int OW, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const float inv = 1.f / (float)(k * k);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int64_t plane = i / ((int64_t)W * H);
+    const float* src = g + plane * OH * OW;
+    int oh_lo = h - k + 1; oh_lo = oh_lo > 0 ? (oh_lo + s - 1) / s : 0;
+    int ow_lo = w - k + 1; ow_lo = ow_lo > 0 ? (ow_lo + s - 1) / s : 0;
+    int oh_hi = h / s; if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_hi = w / s; if (ow_hi > OW - 1) ow_hi = OW - 1;
+    float acc = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) acc += src[oh * OW + ow];
+    gx[i] = acc * inv;
+  }
+}
+
+}  // namespace srgan
+
+using namespace srgan;
+
+extern "C" {
+
+int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t planes, int32_t H, int32_t W, int32_t k,
+                        int32_t s, int32_t p, int32_t OH, int32_t OW, void* stream) {
+  SRGAN_REQUIRE(x && y && argmax && planes > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0 && OH > 0 && OW > 0,
+                SRGAN_EINVAL, "srgan_maxpool2d_fwd arguments");
+  SRGAN_REQUIRE((OH - 1) * s - p < H && (OW - 1) * s - p < W && p < k, SRGAN_EINVAL, "srgan_maxpool2d_fwd geometry");
+  const int64_t n = (int64_t)planes * OH * OW;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, H,
+                     W, k, s, p, OH, OW, n);
+  return launch_status();
+}
+
+int srgan_pool_scatter(const float* g, const int32_t* argmax, float* out, int32_t planes, int64_t in_plane,
+                       int64_t out_plane, void* stream) {
+  SRGAN_REQUIRE(g && argmax && out && planes > 0 && in_plane > 0 && out_plane > 0, SRGAN_EINVAL,
+                "srgan_pool_scatter arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SRGAN_HIP(hipMemsetAsync(out, 0, (size_t)planes * in_plane * sizeof(float), s));
+  const int64_t n = (int64_t)planes * out_plane;
+  hipLaunchKernelGGL(pool_scatter_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, g, argmax, out, in_plane,
+                     out_plane, n);
+  return launch_status();
+}
+
+int srgan_pool_gather(const float* src, const int32_t* argmax, float* out, int32_t planes, int64_t in_plane,
+                      int64_t out_plane, void* stream) {
+  SRGAN_REQUIRE(src && argmax && out && planes > 0 && in_plane > 0 && out_plane > 0, SRGAN_EINVAL,
+                "srgan_pool_gather arguments");
+  const int64_t n = (int64_t)planes * out_plane;
+  hipLaunchKernelGGL(pool_gather_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, src, argmax, out,
+                     in_plane, out_plane, n);
+  return launch_status();
+}
+
+int srgan_avgpool2d_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t k, int32_t s,
+                        int32_t OH, int32_t OW, void* stream) {
+  SRGAN_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && k > 0 && s > 0 && OH > 0 && OW > 0, SRGAN_EINVAL,
+                "srgan_avgpool2d_fwd arguments");
+  SRGAN_REQUIRE((OH - 1) * s + k <= H && (OW - 1) * s + k <= W, SRGAN_EINVAL, "srgan_avgpool2d_fwd geometry");
+  const int64_t n = (int64_t)planes * OH * OW;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, k, s,
+                     OH, OW, n);
+  return launch_status();
+}
+
+int srgan_avgpool2d_bwd(const float* g, float* gx, int32_t planes, int32_t H, int32_t W, int32_t k, int32_t s,
+                        int32_t OH, int32_t OW, void* stream) {
+  SRGAN_REQUIRE(g && gx && planes > 0 && H > 0 && W > 0 && k > 0 && s > 0 && OH > 0 && OW > 0, SRGAN_EINVAL,
+                "srgan_avgpool2d_bwd arguments");
+  SRGAN_REQUIRE((OH - 1) * s + k <= H && (OW - 1) * s + k <= W, SRGAN_EINVAL, "srgan_avgpool2d_bwd geometry");
+  const int64_t n = (int64_t)planes * H * W;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, H, W, k, s,
+                     OH, OW, n);
+  return launch_status();
+}
+
+int srgan_version(void) { return 100; }
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+// reduce.hip -- HBM-bound reductions.  One primitive covers per-channel sums / dot products over [N, C, HW]
+// (bias and batch-norm parameter gradients), per-example dot products over C*H*W (the gradient-penalty
+// norms: N = 1, C = batch), column sums over the batch (feature means: HW = 1) and full sums (C = 1).
+// Each wavefront reduces with cross-lane shuffles (64 lanes), each workgroup with 4 LDS words, and
+// workgroups combine with one hardware fp32 atomic per (channel, segment).
+// Roofline: HBM; algorithmic bytes = 4 * elements read per operand.
+#include "common.h"
+
+namespace srgan {
+
+constexpr int RED_SEG = 256 * 16;   // elements of one row handled by one workgroup
+
+// out[c] += scale[c] * sum over rows r = n*C + c, i in [0, HW) of a[r, i] * ((b ? b[r, i] : 1) - mean[c])
+// (mean, scale optional: with them this is the batch-norm gamma gradient in one pass).
+__global__ __launch_bounds__(256) void chan_reduce_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ scale,
+                                                               float* __restrict__ out, int C, int64_t HW, int segs) {
+  __shared__ float scratch[4];
+  const int c = blockIdx.x;
+  const int n = blockIdx.y / segs, seg = blockIdx.y - n * segs;
+  const int64_t base = ((int64_t)n * C + c) * HW, beg = (int64_t)seg * RED_SEG;
+  const int64_t end = beg + RED_SEG < HW ? beg + RED_SEG : HW;
+  const float mu = mean ? mean[c] : 0.f;
+  float acc = 0.f;
+  if (((base | beg) & 3) == 0) {       // 16-byte aligned run: float4 loads
+    const int64_t n4 = (end - beg) >> 2;
+    const float4* a4 = reinterpret_cast<const float4*>(a + base + beg);
+    const float4* b4 = b ? reinterpret_cast<const float4*>(b + base + beg) : nullptr;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const float4 u = a4[i];
+      if (b4) {
+        const float4 v = b4[i];
+        acc += u.x * (v.x - mu) + u.y * (v.y - mu) + u.z * (v.z - mu) + u.w * (v.w - mu);
+      } else {
+        acc += (u.x + u.y + u.z + u.w) * (1.f - mu);
+      }
+    }
+    for (int64_t i = beg + (n4 << 2) + threadIdx.x; i < end; i += 256)
+      acc += a[base + i] * ((b ? b[base + i] : 1.f) - mu);
+  } else {
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) acc += a[base + i] * ((b ? b[base + i] : 1.f) - mu);
+  }
+  const float total = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out + c, total * (scale ? scale[c] : 1.f));
+}
+
+// HW == 1: a is [N, C]; lanes along c (coalesced), loop over the rows.
+__global__ __launch_bounds__(256) void chan_reduce_cols_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ scale,
+                                                               float* __restrict__ out, int N, int C, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean ? mean[c] : 0.f;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int64_t i = (int64_t)n * C + c;
+    acc += a[i] * ((b ? b[i] : 1.f) - mu);
+  }
+  acc *= scale ? scale[c] : 1.f;
+  out[c] = accumulate ? out[c] + acc : acc;
+}
+
+// out[b] = max_f x[b, f]  (the stabiliser of logsumexp, reference utility.py:179); F is small (bins).
+__global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int F) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float best = x[(int64_t)b * F];
+  for (int f = 1; f < F; ++f) best = fmaxf(best, x[(int64_t)b * F + f]);
+  out[b] = best;
+}
+
+// onehot[b, k] = 1 at the first k minimising |y[b] - bins[k]|, else 0  (reference utility.py:141-144)
+__global__ __launch_bounds__(256) void nearest_bin_onehot_kernel(const float* __restrict__ y,
+                                                                 const float* __restrict__ bins,
+                                                                 float* __restrict__ onehot, int B, int K) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  int best = 0;
+  float best_d = fabsf(y[b] - bins[0]);
+  for (int k = 1; k < K; ++k) {
+    const float d = fabsf(y[b] - bins[k]);
+    if (d < best_d) { best_d = d; best = k; }
+  }
+  for (int k = 0; k < K; ++k) onehot[(int64_t)b * K + k] = k == best ? 1.f : 0.f;
+}
+
+// rows[b] += sum_{hw} (1/Cm) * sum_c |maps[b,c,hw] - target[b,hw]|      (reference crowd/srgan.py:252)
+__global__ __launch_bounds__(256) void crowd_map_l1_kernel(const float* __restrict__ maps,
+                                                           const float* __restrict__ target, float* __restrict__ rows,
+                                                           int Cm, int64_t HW, int segs) {
+  __shared__ float scratch[4];
+  const int b = blockIdx.x, seg = blockIdx.y;
+  const int64_t beg = (int64_t)seg * RED_SEG, end = beg + RED_SEG < HW ? beg + RED_SEG : HW;
+  float acc = 0.f;
+  for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+    const float t = target[(int64_t)b * HW + i];
+    float s = 0.f;
+    for (int c = 0; c < Cm; ++c) s += fabsf(maps[((int64_t)b * Cm + c) * HW + i] - t);
+    acc += s / (float)Cm;
+  }
+  const float total = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(rows + b, total);
+}
+
+// gmaps[b,c,hw] = g[b] * sign(maps[b,c,hw] - target[b,hw]) / Cm
+__global__ __launch_bounds__(256) void crowd_map_l1_bwd_kernel(const float* __restrict__ maps,
+                                                               const float* __restrict__ target,
+                                                               const float* __restrict__ g, float* __restrict__ gmaps,
+                                                               int Cm, int64_t HW, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256, image = (int64_t)Cm * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int64_t b = i / image, hw = (i - b * image) % HW;
+    const float d = maps[i] - target[b * HW + hw];
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    gmaps[i] = g[b] * sgn / (float)Cm;
+  }
+}
+
+}  // namespace srgan
+
+using namespace srgan;
+
+extern "C" {
+
+int srgan_chan_reduce(const float* a, const float* b, const float* mean, const float* scale, float* out, int32_t N,
+                      int32_t C, int64_t HW, int accumulate, void* stream) {
+  SRGAN_REQUIRE(a && out && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_reduce arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (HW == 1) {
+    hipLaunchKernelGGL(chan_reduce_cols_kernel, dim3((C + 255) / 256), dim3(256), 0, s, a, b, mean, scale, out, N, C,
+                       accumulate);
+    return launch_status();
+  }
+  const int segs = (int)((HW + RED_SEG - 1) / RED_SEG);
+  SRGAN_REQUIRE((int64_t)N * segs <= 65535, SRGAN_ERANGE, "srgan_chan_reduce grid");
+  if (!accumulate) SRGAN_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s));
+  hipLaunchKernelGGL(chan_reduce_rows_kernel, dim3(C, N * segs), dim3(256), 0, s, a, b, mean, scale, out, C, HW,
+                     segs);
+  return launch_status();
+}
+
+int srgan_row_max(const float* x, float* out, int32_t B, int32_t F, void* stream) {
+  SRGAN_REQUIRE(x && out && B > 0 && F > 0, SRGAN_EINVAL, "srgan_row_max arguments");
+  hipLaunchKernelGGL(row_max_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, B, F);
+  return launch_status();
+}
+
+int srgan_nearest_bin_onehot(const float* y, const float* bins, float* onehot, int32_t B, int32_t K, void* stream) {
+  SRGAN_REQUIRE(y && bins && onehot && B > 0 && K > 0, SRGAN_EINVAL, "srgan_nearest_bin_onehot arguments");
+  hipLaunchKernelGGL(nearest_bin_onehot_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, y, bins,
+                     onehot, B, K);
+  return launch_status();
+}
+
+int srgan_crowd_map_l1_fwd(const float* maps, const float* target, float* rows, int32_t B, int32_t Cm, int64_t HW,
+                           void* stream) {
+  SRGAN_REQUIRE(maps && target && rows && B > 0 && Cm > 0 && HW > 0, SRGAN_EINVAL, "srgan_crowd_map_l1_fwd arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int segs = (int)((HW + RED_SEG - 1) / RED_SEG);
+  SRGAN_HIP(hipMemsetAsync(rows, 0, (size_t)B * sizeof(float), s));
+  hipLaunchKernelGGL(crowd_map_l1_kernel, dim3(B, segs), dim3(256), 0, s, maps, target, rows, Cm, HW, segs);
+  return launch_status();
+}
+
+int srgan_crowd_map_l1_bwd(const float* maps, const float* target, const float* g_rows, float* g_maps, int32_t B,
+                           int32_t Cm, int64_t HW, void* stream) {
+  SRGAN_REQUIRE(maps && target && g_rows && g_maps && B > 0 && Cm > 0 && HW > 0, SRGAN_EINVAL,
+                "srgan_crowd_map_l1_bwd arguments");
+  const int64_t n = (int64_t)B * Cm * HW;
+  hipLaunchKernelGGL(crowd_map_l1_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, maps,
+                     target, g_rows, g_maps, Cm, HW, n);
+  return launch_status();
+}
+
+}  // extern "C"
