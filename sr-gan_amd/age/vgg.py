@@ -1,0 +1,70 @@
+"""VGG-16 discriminator on HIP kernels (surface of reference age/vgg.py:28-53,70-92,151-162).
+
+``image_size`` generalises the classifier's ``512*7*7`` input to ``512*(S/32)**2``;
+at 224 it is the reference graph.  The (B, 1) un-squeezed output is kept as in the reference (Appendix A.12).
+Pretrained-weight download is unavailable offline; ``pretrained=True`` raises."""
+import math
+
+from torch import nn as torch_nn
+
+from .. import functional as F
+from .. import nn
+
+cfg = {
+    'A': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+    'B': [64, 64, 'M', 128, 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+    'D': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M'],
+    'E': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M'],
+}
+
+
+def make_layers(cfg_, batch_norm=False):
+    layers, in_channels = [], 3
+    for v in cfg_:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            conv2d = nn.Conv2d(in_channels, v, kernel_size=3, padding=1)
+            layers += [conv2d, nn.BatchNorm2d(v), nn.ReLU(inplace=True)] if batch_norm else [conv2d,
+                                                                                              nn.ReLU(inplace=True)]
+            in_channels = v
+    return nn.Sequential(*layers)
+
+
+class VGG(nn.Module):
+    def __init__(self, feature_layers, num_classes=1000, init_weights=True, image_size=224):
+        super().__init__()
+        self.feature_layers = feature_layers
+        side = image_size // 32
+        self.classifier = nn.Sequential(nn.Linear(512 * side * side, 4096), nn.ReLU(True),
+                                        nn.Linear(4096, 4096), nn.ReLU(True))
+        self.final_layer = nn.Linear(4096, num_classes)
+        self.features = None
+        if init_weights:
+            self._initialize_weights()
+
+    def forward(self, x):
+        h = self.feature_layers(x)
+        h = self.classifier(F.flatten2d(h))
+        self.features = h
+        return self.final_layer(h)
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, torch_nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, torch_nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, torch_nn.Linear):
+                m.weight.data.normal_(0, 0.01)
+                m.bias.data.zero_()
+
+
+def vgg16(pretrained=False, **kwargs):
+    if pretrained:
+        raise RuntimeError('pretrained VGG-16 weights need a download; load a checkpoint with load_state_dict')
+    return VGG(make_layers(cfg['D']), **kwargs)

@@ -1,0 +1,162 @@
+"""Crowd-counting networks on HIP kernels: the DCGAN generator and the DenseNet-201 based
+``KnnDenseNetCat`` discriminator (surface of reference crowd/models.py:127-147,335-371,763-786,1049-1166).
+
+Sizes the reference hard-codes (map-head inputs 28/14/7, the 7x7 final pool) are derived from
+``image_size`` as S/8, S/16, S/32; at 224 it is the reference graph.
+The unused experimental networks of the reference file are out of scope."""
+from collections import OrderedDict
+
+from torch import nn as torch_nn
+
+from .. import functional as F
+from .. import nn
+from ..age.models import Generator as _DCGANGenerator
+
+
+class DCGenerator(_DCGANGenerator):
+    """reference crowd/models.py:127-147 (defaults to 224x224)."""
+
+    def __init__(self, z_dim=256, image_size=224, conv_dim=64):
+        super().__init__(z_dim=z_dim, image_size=image_size, conv_dim=conv_dim)
+
+
+class _DenseLayer(nn.Sequential):
+    """BN-ReLU-conv1x1(bn_size*k)-BN-ReLU-conv3x3(k); output is cat([x, new]) (crowd/models.py:335-353)."""
+
+    def __init__(self, num_input_features, growth_rate, bn_size, drop_rate=0):
+        super().__init__()
+        self.add_module('norm1', nn.BatchNorm2d(num_input_features))
+        self.add_module('relu1', nn.ReLU(inplace=True))
+        self.add_module('conv1', nn.Conv2d(num_input_features, bn_size * growth_rate, kernel_size=1, stride=1,
+                                           bias=False))
+        self.add_module('norm2', nn.BatchNorm2d(bn_size * growth_rate))
+        self.add_module('relu2', nn.ReLU(inplace=True))
+        self.add_module('conv2', nn.Conv2d(bn_size * growth_rate, growth_rate, kernel_size=3, stride=1, padding=1,
+                                           bias=False))
+        if drop_rate:
+            raise NotImplementedError('drop_rate > 0 is never used on the hot path (crowd/models.py:1063)')
+
+    def forward(self, x):
+        return F.cat_channels([x, super().forward(x)])
+
+
+class _DenseBlock(nn.Sequential):
+    def __init__(self, num_layers, num_input_features, bn_size, growth_rate, drop_rate=0):
+        super().__init__()
+        for i in range(num_layers):
+            self.add_module('denselayer%d' % (i + 1),
+                            _DenseLayer(num_input_features + i * growth_rate, growth_rate, bn_size, drop_rate))
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, num_input_features, num_output_features):
+        super().__init__()
+        self.add_module('norm', nn.BatchNorm2d(num_input_features))
+        self.add_module('relu', nn.ReLU(inplace=True))
+        self.add_module('conv', nn.Conv2d(num_input_features, num_output_features, kernel_size=1, stride=1,
+                                          bias=False))
+        self.add_module('pool', nn.AvgPool2d(kernel_size=2, stride=2))
+
+
+class MapModule(nn.Module):
+    """Transposed conv to the label size, then conv k2 s2 x3, a whole-map "linear" conv and a count layer,
+    leaky_relu 0.01 throughout (reference crowd/models.py:763-786)."""
+
+    def __init__(self, in_features, input_size, label_size):
+        super().__init__()
+        kernel_size = label_size // input_size
+        self.map_transposed_conv_layer = nn.ConvTranspose2d(in_channels=in_features, out_channels=1,
+                                                            kernel_size=kernel_size, stride=kernel_size)
+        self.conv1 = nn.Conv2d(in_channels=1, out_channels=8, kernel_size=2, stride=2)
+        self.conv2 = nn.Conv2d(in_channels=8, out_channels=16, kernel_size=2, stride=2)
+        self.conv3 = nn.Conv2d(in_channels=16, out_channels=32, kernel_size=2, stride=2)
+        self.linear1 = nn.Conv2d(in_channels=32, out_channels=20, kernel_size=label_size // (2 ** 3))
+        self.count_layer = nn.Conv2d(in_channels=20, out_channels=1, kernel_size=1)
+
+    def forward(self, x):
+        map_ = F.leaky_relu(self.map_transposed_conv_layer(x))
+        out = F.leaky_relu(self.conv1(map_))
+        out = F.leaky_relu(self.conv2(out))
+        out = F.leaky_relu(self.conv3(out))
+        out = F.leaky_relu(self.linear1(out))
+        return map_, self.count_layer(out), out
+
+
+class KnnDenseNetCat(nn.Module):
+    """DenseNet-201 trunk, three map heads on the transition outputs and a count head; ``features`` is the
+    concatenation of the four 20-d hidden vectors, shape (B, 80, 1, 1) (reference crowd/models.py:1049-1166).
+
+    Returns ``(density, count, maps)`` like the reference; ``density`` is the reference's all-zero
+    (B, S, S) placeholder, produced once per shape and reused (Appendix A.11)."""
+
+    def __init__(self, growth_rate=32, block_config=(6, 12, 48, 32), num_init_features=64, bn_size=4, drop_rate=0,
+                 pretrained=False, label_patch_size=224, image_size=None):
+        super().__init__()
+        if pretrained:
+            raise RuntimeError('torchvision densenet201 weights need a download; use load_state_dict instead')
+        image_size = image_size or label_patch_size
+        self.label_patch_size = image_size
+        self.dense_blocks = nn.ModuleList()
+        self.transition_layers = nn.ModuleList()
+        self.conv_layer1 = nn.Sequential(OrderedDict([
+            ('conv0', nn.Conv2d(3, num_init_features, kernel_size=7, stride=2, padding=3, bias=False)),
+            ('norm0', nn.BatchNorm2d(num_init_features)),
+            ('relu0', nn.ReLU(inplace=True)),
+            ('pool0', nn.MaxPool2d(kernel_size=3, stride=2, padding=1))]))
+        num_features = num_init_features
+        widths = []
+        for i, num_layers in enumerate(block_config):
+            block = _DenseBlock(num_layers=num_layers, num_input_features=num_features, bn_size=bn_size,
+                                growth_rate=growth_rate, drop_rate=drop_rate)
+            self.dense_blocks.add_module('denseblock%d' % (i + 1), block)
+            num_features = num_features + num_layers * growth_rate
+            if i != len(block_config) - 1:
+                self.transition_layers.add_module('transition%d' % (i + 1),
+                                                  _Transition(num_features, num_features // 2))
+                num_features = num_features // 2
+                widths.append(num_features)
+        self.norm5 = nn.BatchNorm2d(num_features)
+        for m in self.modules():      # "official init from torch repo" (crowd/models.py:1094-1101)
+            if isinstance(m, torch_nn.Conv2d):
+                torch_nn.init.kaiming_normal_(m.weight.data)
+            elif isinstance(m, torch_nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, torch_nn.Linear):
+                m.bias.data.zero_()
+        self.map_module1 = MapModule(in_features=widths[0], input_size=image_size // 8, label_size=image_size)
+        self.map_module2 = MapModule(in_features=widths[1], input_size=image_size // 16, label_size=image_size)
+        self.map_module3 = MapModule(in_features=widths[2], input_size=image_size // 32, label_size=image_size)
+        self.final_count_feature_layer = nn.Conv2d(in_channels=num_features, out_channels=20, kernel_size=1)
+        self.count_layer = nn.Conv2d(in_channels=20, out_channels=1, kernel_size=1)
+        self.final_pool_size = image_size // 32
+        self.features = None
+        self._density_cache = None
+
+    def _density(self, batch_size, like):
+        cache = self._density_cache
+        if cache is None or cache.shape[0] != batch_size or cache.data.device != like.data.device:
+            cache = F.full((batch_size, self.label_patch_size, self.label_patch_size), 0.0, like)
+            self._density_cache = cache
+        return cache
+
+    def forward(self, x):
+        batch_size = x.shape[0]
+        out = self.conv_layer1(x)
+        t1_out = self.transition_layers.transition1(self.dense_blocks.denseblock1(out))
+        t2_out = self.transition_layers.transition2(self.dense_blocks.denseblock2(t1_out))
+        t3_out = self.transition_layers.transition3(self.dense_blocks.denseblock3(t2_out))
+        db4_out = self.dense_blocks.denseblock4(t3_out)
+        n5_relu_out = F.relu(self.norm5(db4_out))
+        final_pool = F.avg_pool2d(n5_relu_out, kernel_size=self.final_pool_size, stride=1)
+        final_count_features = F.leaky_relu(self.final_count_feature_layer(final_pool))
+        final_count = self.count_layer(final_count_features)
+        map1, count1, h1 = self.map_module1(t1_out)
+        map2, count2, h2 = self.map_module2(t2_out)
+        map3, count3, h3 = self.map_module3(t3_out)
+        self.features = F.cat_channels([F.view(t, (batch_size, -1, 1, 1))
+                                        for t in (h1, h2, h3, final_count_features)])
+        count = F.add(F.add(F.add(count1, count2), count3), final_count)
+        count = F.view(count, (batch_size,))
+        map_ = F.cat_channels([map1, map2, map3])
+        return self._density(batch_size, x), count, map_

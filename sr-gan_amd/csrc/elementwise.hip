@@ -53,8 +53,8 @@ __device__ __forceinline__ float binary(float a, float b, float p0) {
 }
 
 template <int OP>
-__global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
-                                                    float p0, float p1) {
+// (no __restrict__: these run in place for gradient accumulation and fills)
+__global__ __launch_bounds__(256) void unary_kernel(const float* x, float* y, int64_t n, float p0, float p1) {
   const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   float4* y4 = reinterpret_cast<float4*>(y);
@@ -69,8 +69,7 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ x,
 }
 
 template <int OP>
-__global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                     float* __restrict__ y, int64_t n, float p0) {
+__global__ __launch_bounds__(256) void binary_kernel(const float* a, const float* b, float* y, int64_t n, float p0) {
   const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
   const float4* a4 = reinterpret_cast<const float4*>(a);
   const float4* b4 = reinterpret_cast<const float4*>(b);

@@ -1,0 +1,542 @@
+"""Semi-supervised regression GAN training on MI355X: the ``Experiment`` surface of reference srgan.py with
+the training step (dnn_training_step / gan_training_step and the loss calculations, srgan.py:259-391)
+running on the HIP tape.
+
+Differences from the reference that are deliberate (each keeps results identical to 1e-3):
+
+* ``settings.reference_schedule = False`` (default) shares the discriminator forward of the labeled batch
+  between the labeled and unlabeled losses and that of the unlabeled batch between the unlabeled and fake
+  losses, and back-propagates their sum once: the reference recomputes those forwards (Appendix A.2).
+  ``True`` replays the reference's exact forward / backward order.
+* the discriminator's weight gradients are not computed during the generator update (the reference computes
+  and discards them, srgan.py:304 then :278).
+* one process per GPU: an optional data-parallel context shards the three batches and exchanges feature
+  sums and gradients over RCCL (``parallel.py``).
+"""
+import datetime
+import os
+import re
+import select
+import sys
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+from scipy.stats import norm
+
+from . import functional as F
+from . import nn
+from .optim import Adam
+from .settings import Settings
+from .tape import Var, backward, no_grad
+from .utility import SummaryWriter, MixtureModel, current_device, make_directory_name_unique, seed_all
+
+
+def as_var(value):
+    """Device tensors from the data pipeline enter the tape as constants."""
+    if isinstance(value, Var) or value is None:
+        return value
+    if isinstance(value, (tuple, list)):
+        return tuple(as_var(v) for v in value)
+    if isinstance(value, np.ndarray):
+        value = torch.from_numpy(value)
+    return F.constant(value.to(current_device(), non_blocking=True))
+
+
+class Experiment(ABC):
+    """Manages one experimental trial (reference srgan.py:24-469)."""
+
+    def __init__(self, settings: Settings):
+        self.settings = settings
+        self.trial_directory = None
+        self.dnn_summary_writer = None
+        self.gan_summary_writer = None
+        self.dataset_class = None
+        self.train_dataset = None
+        self.train_dataset_loader = None
+        self.unlabeled_dataset = None
+        self.unlabeled_dataset_loader = None
+        self.validation_dataset = None
+        self.DNN = None
+        self.dnn_optimizer = None
+        self.D = None
+        self.d_optimizer = None
+        self.G = None
+        self.g_optimizer = None
+        self.signal_quit = False
+        self.starting_step = 0
+
+        self.labeled_features = None
+        self.unlabeled_features = None
+        self.fake_features = None
+        self.interpolates_features = None
+        self.gradient_norm = None
+
+        self.dp = None                 # optional parallel.DataParallel context
+        self.injected_draws = None     # tests: dict with 'z_d', 'z_g', 'alpha' device/CPU tensors, used once
+        self.last_losses = {}          # device scalars of the latest step (no host sync)
+
+    # ------------------------------------------------------------------------------------------ lifecycle
+    def train(self):
+        """Run the SRGAN training for the experiment (reference srgan.py:52-86)."""
+        settings = self.settings
+        self.trial_directory = os.path.join(settings.logs_directory, settings.trial_name)
+        if (settings.skip_completed_experiment and os.path.exists(self.trial_directory) and
+                '/check' not in self.trial_directory and not settings.continue_existing_experiments):
+            print('`{}` experiment already exists. Skipping...'.format(self.trial_directory))
+            return
+        if not settings.continue_existing_experiments:
+            self.trial_directory = make_directory_name_unique(self.trial_directory)
+        else:
+            if os.path.exists(self.trial_directory) and settings.load_model_path is not None:
+                raise ValueError('Cannot load from path and continue existing at the same time.')
+            elif settings.load_model_path is None:
+                settings.load_model_path = self.trial_directory
+            elif not os.path.exists(self.trial_directory):
+                settings.continue_existing_experiments = False
+        print(self.trial_directory)
+        os.makedirs(os.path.join(self.trial_directory, settings.temporary_directory), exist_ok=True)
+        self.prepare_summary_writers()
+        seed_all(0)
+
+        self.dataset_setup()
+        self.model_setup()
+        self.gpu_mode()              # parameters move into flat device arenas before the optimizers bind
+        self.prepare_optimizers()
+        self.load_models()
+        self.train_mode()
+
+        self.training_loop()
+
+        print('Completed {}'.format(self.trial_directory))
+        if settings.should_save_models:
+            self.save_models(step=settings.steps_to_run)
+
+    def save_models(self, step):
+        """One torch.save dict with the reference's keys (srgan.py:88-97); written by rank 0 only."""
+        if self.dp is not None and self.dp.rank != 0:
+            return
+        model = {'DNN': self.DNN.state_dict(), 'dnn_optimizer': self.dnn_optimizer.state_dict(),
+                 'D': self.D.state_dict(), 'd_optimizer': self.d_optimizer.state_dict(),
+                 'G': self.G.state_dict(), 'g_optimizer': self.g_optimizer.state_dict(), 'step': step}
+        torch.save(model, os.path.join(self.trial_directory, f'model_{step}.pth'))
+
+    def training_loop(self):
+        """The per-step hot loop (reference srgan.py:99-129)."""
+        train_dataset_generator = self.infinite_iter(self.train_dataset_loader)
+        unlabeled_dataset_generator = self.infinite_iter(self.unlabeled_dataset_loader)
+        step_time_start = datetime.datetime.now()
+        for step in range(self.starting_step, self.settings.steps_to_run):
+            self.adjust_learning_rate(step)
+            samples = next(train_dataset_generator)
+            if len(samples) == 2:
+                labeled_examples, labels = samples
+            else:
+                labeled_examples, primary_labels, secondary_labels = samples
+                labels = (primary_labels, secondary_labels)
+            labeled_examples, labels = as_var(labeled_examples), as_var(labels)
+            self.dnn_training_step(labeled_examples, labels, step)
+            unlabeled_examples = as_var(next(unlabeled_dataset_generator)[0])
+            self.gan_training_step(labeled_examples, labels, unlabeled_examples, step)
+
+            if self.gan_summary_writer.is_summary_step() or step == self.settings.steps_to_run - 1:
+                print('\rStep {}, {}...'.format(step, datetime.datetime.now() - step_time_start), end='')
+                step_time_start = datetime.datetime.now()
+                self.eval_mode()
+                with no_grad():
+                    self.validation_summaries(step)
+                self.train_mode()
+            self.handle_user_input(step)
+            if self.settings.save_step_period and step % self.settings.save_step_period == 0 and step != 0:
+                self.save_models(step=step)
+
+    def prepare_optimizers(self):
+        """Adam for D (with coupled L2), G and DNN (reference srgan.py:131-138) on the flat arenas."""
+        if getattr(self.D, '_srgan_arena', None) is None:
+            self.gpu_mode()
+        d_lr = self.settings.learning_rate
+        weight_decay = self.settings.weight_decay
+        self.d_optimizer = Adam(self.D._srgan_arena, lr=d_lr, weight_decay=weight_decay)
+        self.g_optimizer = Adam(self.G._srgan_arena, lr=d_lr)
+        self.dnn_optimizer = Adam(self.DNN._srgan_arena, lr=d_lr, weight_decay=weight_decay)
+
+    def prepare_summary_writers(self):
+        self.dnn_summary_writer = SummaryWriter(os.path.join(self.trial_directory, 'DNN'))
+        self.gan_summary_writer = SummaryWriter(os.path.join(self.trial_directory, 'GAN'))
+        for writer in (self.dnn_summary_writer, self.gan_summary_writer):
+            writer.summary_period = self.settings.summary_step_period
+            writer.steps_to_run = self.settings.steps_to_run
+
+    def handle_user_input(self, step):
+        """'save' / 'quit' typed on stdin, polled without blocking (reference srgan.py:149-163); rank 0 only."""
+        if self.dp is not None and self.dp.rank != 0:
+            return
+        try:
+            ready = sys.stdin in select.select([sys.stdin], [], [], 0)[0]
+        except (ValueError, OSError):
+            return
+        while ready:
+            line = sys.stdin.readline()
+            if not line:
+                break
+            if 'save' in line:
+                self.save_models(step)
+                print('\rSaved model for step {}...'.format(step))
+            if 'quit' in line:
+                self.signal_quit = True
+                print('\rQuit requested after current experiment...')
+            ready = sys.stdin in select.select([sys.stdin], [], [], 0)[0]
+
+    def train_mode(self):
+        for module in (self.D, self.DNN, self.G):
+            module.train()
+
+    def eval_mode(self):
+        for module in (self.D, self.DNN, self.G):
+            module.eval()
+
+    def gpu_mode(self):
+        """Moves each network into its flat parameter / gradient arena on this rank's device."""
+        device = current_device()
+        for module in (self.D, self.DNN, self.G):
+            if getattr(module, '_srgan_arena', None) is None:
+                nn.flatten_parameters(module, device)
+
+    def cpu_mode(self):
+        raise RuntimeError('the MI355X training step has no CPU mode')
+
+    @staticmethod
+    def compare_model_path_for_latest(model_path1, model_path2):
+        """Later step wins; a file without a step number wins over all (reference srgan.py:197-219)."""
+        if model_path1 is None:
+            return model_path2
+        if model_path1.group(1) is None:
+            return model_path1
+        if model_path2.group(1) is None:
+            return model_path2
+        return model_path1 if int(model_path1.group(1)) > int(model_path2.group(1)) else model_path2
+
+    def load_models(self, with_optimizers=True):
+        """Loads the latest ``model_<step>.pth`` from ``settings.load_model_path`` (reference srgan.py:221-251)."""
+        if not self.settings.load_model_path:
+            return
+        latest_model = None
+        for file_name in os.listdir(self.settings.load_model_path):
+            match = re.search(r'model_?(\d+)?\.pth', file_name)
+            if match:
+                latest_model = self.compare_model_path_for_latest(latest_model, match)
+        if latest_model is None:
+            return
+        model_path = os.path.join(self.settings.load_model_path, latest_model.group(0))
+        loaded_model = torch.load(model_path, map_location='cpu')
+        self.DNN.load_state_dict(loaded_model['DNN'])
+        self.D.load_state_dict(loaded_model['D'])
+        self.G.load_state_dict(loaded_model['G'])
+        if with_optimizers:
+            self.dnn_optimizer.load_state_dict(loaded_model['dnn_optimizer'])
+            self.d_optimizer.load_state_dict(loaded_model['d_optimizer'])
+            self.g_optimizer.load_state_dict(loaded_model['g_optimizer'])
+        print('Model loaded from `{}`.'.format(model_path))
+        if self.settings.continue_existing_experiments:
+            self.starting_step = loaded_model['step'] + 1
+            print(f'Continuing from step {self.starting_step}')
+
+    # ------------------------------------------------------------------------------------------ random draws
+    def _take_draw(self, key):
+        if self.injected_draws is not None and self.injected_draws.get(key) is not None:
+            value = self.injected_draws[key]
+            self.injected_draws[key] = None
+            return value
+        return None
+
+    def sample_discriminator_noise(self, batch_size):
+        """float64 two-Gaussian mixture from NumPy's global stream cast to float32 (srgan.py:286-289)."""
+        z = self._take_draw('z_d')
+        if z is None:
+            offset = self.settings.mean_offset
+            z = torch.tensor(MixtureModel([norm(-offset, 1), norm(offset, 1)]).rvs(
+                size=[batch_size, self.G.input_size]).astype(np.float32))
+        return as_var(z)
+
+    def sample_generator_noise(self, batch_size):
+        """N(0, 1) from torch's CPU stream (srgan.py:301)."""
+        z = self._take_draw('z_g')
+        if z is None:
+            z = torch.randn(batch_size, self.G.input_size)
+        return as_var(z)
+
+    def sample_interpolation_alpha(self, batch_size):
+        """U[0, 1) per example.  The reference draws on the device (srgan.py:364), which is not reproducible
+        across devices; here it comes from torch's CPU stream and is copied over."""
+        alpha = self._take_draw('alpha')
+        if alpha is None:
+            alpha = torch.rand(batch_size)
+        return as_var(alpha.reshape(-1))
+
+    # ------------------------------------------------------------------------------------------ batch reductions
+    def _global_batch(self, local):
+        return local if self.dp is None else self.dp.global_batch(local)
+
+    def batch_mean_of_features(self, features):
+        """Mean over the (global) batch -> shape features.shape[1:] (the ``mean(0)`` of srgan.py:442-443)."""
+        sums = F.col_sum(features)
+        if self.dp is not None and self.dp.world_size > 1:
+            sums = self.dp.all_reduce_sum_var(sums)
+        return F.scale(sums, 1.0 / self._global_batch(features.shape[0]))
+
+    def batch_mean_of_examples(self, per_example):
+        """Mean over the (global) batch of per-example scalars.  Under data parallelism this is the rank's
+        partial sum / global batch: gradients add up over ranks, and logged values are summed over ranks."""
+        return F.scale(F.sum_all(per_example), 1.0 / self._global_batch(per_example.shape[0]))
+
+    # ------------------------------------------------------------------------------------------ the hot path
+    def dnn_training_step(self, examples, labels, step):
+        """One round of DNN training (reference srgan.py:259-271)."""
+        examples, labels = as_var(examples), as_var(labels)
+        self.DNN.apply(disable_batch_norm_updates)
+        self.dnn_summary_writer.step = step
+        self.dnn_optimizer.zero_grad()
+        dnn_loss = self.dnn_loss_calculation(examples, labels)
+        backward(dnn_loss)
+        self.synchronize_gradients(self.DNN)
+        self.dnn_optimizer.step()
+        self.last_losses['dnn_loss'] = dnn_loss
+        if self.dnn_summary_writer.is_summary_step():
+            self.dnn_summary_writer.add_scalar('Discriminator/Labeled Loss', self.loss_value(dnn_loss, partial=True))
+            if getattr(self.DNN, 'features', None) is not None:
+                norms = F.row_norm(F.flatten2d(self.DNN.features.detach()))
+                self.dnn_summary_writer.add_scalar('Feature Norm/Labeled', F.mean_all(norms).item())
+
+    def gan_training_step(self, labeled_examples, labels, unlabeled_examples, step):
+        """One round of GAN training (reference srgan.py:273-320)."""
+        settings = self.settings
+        labeled_examples, labels = as_var(labeled_examples), as_var(labels)
+        unlabeled_examples = as_var(unlabeled_examples)
+        self.D.apply(disable_batch_norm_updates)
+        self.gan_summary_writer.step = step
+        self.d_optimizer.zero_grad()
+        batch_size = unlabeled_examples.shape[0]
+        if getattr(settings, 'reference_schedule', False):
+            labeled_loss = self.labeled_loss_calculation(labeled_examples, labels)
+            backward(labeled_loss)
+            unlabeled_loss = self.unlabeled_loss_calculation(labeled_examples, unlabeled_examples)
+            backward(unlabeled_loss)
+            z = self.sample_discriminator_noise(batch_size)
+            with no_grad():
+                fake_examples = self.G(z)
+            fake_loss = self.fake_loss_calculation(unlabeled_examples, fake_examples)
+            backward(fake_loss)
+        else:
+            z = self.sample_discriminator_noise(batch_size)
+            with no_grad():
+                fake_examples = self.G(z)
+            labeled_loss, unlabeled_loss, fake_loss = self.discriminator_losses_shared_forwards(
+                labeled_examples, labels, unlabeled_examples, fake_examples)
+            backward(F.add(F.add(labeled_loss, unlabeled_loss), fake_loss))
+        gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
+        backward(gradient_penalty)
+        self.synchronize_gradients(self.D)
+        self.d_optimizer.step()
+        generator_loss = None
+        if step % settings.generator_training_step_period == 0:
+            self.g_optimizer.zero_grad()
+            z = self.sample_generator_noise(batch_size)
+            fake_examples = self.G(z)
+            generator_loss = self.generator_loss_calculation(fake_examples, unlabeled_examples)
+            backward(generator_loss)
+            self.synchronize_gradients(self.G)
+            self.g_optimizer.step()
+        self.last_losses.update(labeled_loss=labeled_loss, unlabeled_loss=unlabeled_loss, fake_loss=fake_loss,
+                                gradient_penalty=gradient_penalty, generator_loss=generator_loss)
+        if self.gan_summary_writer.is_summary_step():
+            writer = self.gan_summary_writer
+            if generator_loss is not None:
+                writer.add_scalar('Generator/Loss', self.loss_value(generator_loss))
+            writer.add_scalar('Discriminator/Labeled Loss', self.loss_value(labeled_loss, partial=True))
+            writer.add_scalar('Discriminator/Unlabeled Loss', self.loss_value(unlabeled_loss))
+            writer.add_scalar('Discriminator/Fake Loss', self.loss_value(fake_loss))
+            writer.add_scalar('Discriminator/Gradient Penalty', self.loss_value(gradient_penalty, partial=True))
+            writer.add_scalar('Discriminator/Gradient Norm', self.loss_value(
+                self.batch_mean_of_examples(self.gradient_norm.detach()), partial=True))
+            if self.labeled_features is not None and self.unlabeled_features is not None:
+                with no_grad():
+                    for tag, features in (('Labeled', self.labeled_features), ('Unlabeled', self.unlabeled_features)):
+                        mean = self.batch_mean_of_features(features.detach())
+                        writer.add_scalar('Feature Norm/' + tag, F.sqrt(F.sum_all(F.square(mean))).item())
+
+    def loss_value(self, loss, partial=False):
+        """Host value of a device scalar; ``partial`` scalars are per-rank partial sums under data parallelism."""
+        value = float(loss.item())
+        if partial and self.dp is not None and self.dp.world_size > 1:
+            value = self.dp.all_reduce_sum_float(value)
+        return value
+
+    def synchronize_gradients(self, module):
+        if self.dp is not None and self.dp.world_size > 1:
+            self.dp.all_reduce_gradients(module._srgan_arena)
+
+    def discriminator_losses_shared_forwards(self, labeled_examples, labels, unlabeled_examples, fake_examples):
+        """Labeled + unlabeled + fake losses from ONE discriminator forward per batch (labeled, unlabeled,
+        fake); same mathematics as srgan.py:329-358, which runs five forwards."""
+        settings = self.settings
+        predicted_labels = self.D(labeled_examples)
+        self.labeled_features = self.D.features
+        labeled_loss = self.labeled_loss_function(predicted_labels, labels, order=settings.labeled_loss_order)
+        labeled_loss = F.scale(labeled_loss, settings.labeled_loss_multiplier)
+        _ = self.D(unlabeled_examples)
+        self.unlabeled_features = self.D.features
+        unlabeled_loss = self.feature_distance_loss(self.unlabeled_features, self.labeled_features)
+        unlabeled_loss = F.scale(unlabeled_loss, settings.matching_loss_multiplier * settings.srgan_loss_multiplier)
+        _ = self.D(fake_examples.detach())
+        self.fake_features = self.D.features
+        fake_loss = self.feature_distance_loss(self.unlabeled_features, self.fake_features,
+                                               distance_function=settings.contrasting_distance_function)
+        fake_loss = F.scale(fake_loss, settings.contrasting_loss_multiplier * settings.srgan_loss_multiplier)
+        return labeled_loss, unlabeled_loss, fake_loss
+
+    def dnn_loss_calculation(self, labeled_examples, labels):
+        """reference srgan.py:322-327."""
+        predicted_labels = self.DNN(labeled_examples)
+        labeled_loss = self.labeled_loss_function(predicted_labels, labels, order=self.settings.labeled_loss_order)
+        return F.scale(labeled_loss, self.settings.labeled_loss_multiplier)
+
+    def labeled_loss_calculation(self, labeled_examples, labels):
+        """reference srgan.py:329-335."""
+        predicted_labels = self.D(labeled_examples)
+        self.labeled_features = self.D.features
+        labeled_loss = self.labeled_loss_function(predicted_labels, labels, order=self.settings.labeled_loss_order)
+        return F.scale(labeled_loss, self.settings.labeled_loss_multiplier)
+
+    def unlabeled_loss_calculation(self, labeled_examples, unlabeled_examples):
+        """reference srgan.py:337-346."""
+        _ = self.D(labeled_examples)
+        self.labeled_features = self.D.features
+        _ = self.D(unlabeled_examples)
+        self.unlabeled_features = self.D.features
+        unlabeled_loss = self.feature_distance_loss(self.unlabeled_features, self.labeled_features)
+        return F.scale(unlabeled_loss, self.settings.matching_loss_multiplier * self.settings.srgan_loss_multiplier)
+
+    def fake_loss_calculation(self, unlabeled_examples, fake_examples):
+        """reference srgan.py:348-358."""
+        _ = self.D(unlabeled_examples)
+        self.unlabeled_features = self.D.features
+        _ = self.D(fake_examples.detach())
+        self.fake_features = self.D.features
+        fake_loss = self.feature_distance_loss(self.unlabeled_features, self.fake_features,
+                                               distance_function=self.settings.contrasting_distance_function)
+        return F.scale(fake_loss, self.settings.contrasting_loss_multiplier * self.settings.srgan_loss_multiplier)
+
+    def gradient_penalty_calculation(self, fake_examples, unlabeled_examples):
+        """Interpolated-sample gradient penalty with its double backward (reference srgan.py:360-375).
+        alpha has ``settings.batch_size`` entries as in the reference (:363), i.e. the unlabeled batch must
+        have exactly that many examples (per rank under data parallelism)."""
+        settings = self.settings
+        expected = settings.batch_size if self.dp is None else self.dp.local_batch(settings.batch_size)
+        alpha = self.sample_interpolation_alpha(expected)
+        interpolates = F.gp_interpolate(unlabeled_examples.detach(), fake_examples.detach(), alpha)
+        interpolates_loss = self.interpolate_loss_calculation(interpolates)
+        gradients, = backward(interpolates_loss, grad=F.full_like(interpolates_loss, 1.0), inputs=[interpolates],
+                              create_graph=True)
+        gradient_norm = F.row_norm(F.flatten2d(gradients))
+        self.gradient_norm = gradient_norm
+        norm_excesses = F.relu(F.add_scalar(gradient_norm, -1.0))
+        penalty = self.batch_mean_of_examples(F.square(norm_excesses))
+        return F.scale(penalty, settings.gradient_penalty_multiplier)
+
+    def interpolate_loss_calculation(self, interpolates):
+        """Per-example feature norm of the interpolates (reference srgan.py:377-381)."""
+        _ = self.D(interpolates)
+        self.interpolates_features = self.D.features
+        return F.row_norm(F.flatten2d(self.interpolates_features))
+
+    def generator_loss_calculation(self, fake_examples, unlabeled_examples):
+        """reference srgan.py:383-391 (no srgan_loss_multiplier, Appendix A.4)."""
+        with nn.frozen_parameters(self.D):
+            _ = self.D(fake_examples)
+            self.fake_features = self.D.features
+            with no_grad():
+                _ = self.D(unlabeled_examples)
+                detached_unlabeled_features = self.D.features.detach()
+        generator_loss = self.feature_distance_loss(detached_unlabeled_features, self.fake_features)
+        return F.scale(generator_loss, self.settings.matching_loss_multiplier)
+
+    # ------------------------------------------------------------------------------------------ plug-in hooks
+    @abstractmethod
+    def dataset_setup(self):
+        """Prepares the datasets and loaders (reference srgan.py:393-400)."""
+
+    @abstractmethod
+    def model_setup(self):
+        """Assigns self.DNN, self.D and self.G (reference srgan.py:402-407)."""
+
+    @abstractmethod
+    def validation_summaries(self, step: int):
+        """Per-application evaluation summaries (reference srgan.py:409-412)."""
+
+    def labeled_loss_function(self, predicted_labels, labels, order=2):
+        """mean(|p - y| ** order) (reference srgan.py:414-417).  A (B, 1) prediction against (B) labels
+        broadcasts to (B, B) exactly as in the reference's VGG path (Appendix A.12)."""
+        if len(predicted_labels.shape) == 2 and predicted_labels.shape[1] == 1 and len(labels.shape) == 1:
+            batch = predicted_labels.shape[0]
+            rows = F.row_broadcast(F.view(predicted_labels, (batch,)), (batch, batch))
+            columns = F.chan_affine(None, None, None, None, labels, dims=(batch, batch, 1), out_shape=(batch, batch))
+            difference = F.sub(rows, columns)
+            return F.scale(F.sum_all(F.pow_scalar(F.abs_(difference), order)),
+                           1.0 / (batch * self._global_batch(batch)))
+        difference = F.sub(predicted_labels, F.view(labels, predicted_labels.shape))
+        return self.batch_mean_of_examples(F.pow_scalar(F.abs_(difference), order))
+
+    def evaluate(self):
+        self.model_setup()
+        self.gpu_mode()
+        self.load_models(with_optimizers=False)
+        self.eval_mode()
+
+    @staticmethod
+    def infinite_iter(dataset):
+        while True:
+            for examples in dataset:
+                yield examples
+
+    def adjust_learning_rate(self, step):
+        """lr * 0.1 ** (step // 100000), applied to the DNN optimizer only (reference srgan.py:432-436)."""
+        lr = self.settings.learning_rate * (0.1 ** (step // 100000))
+        for param_group in self.dnn_optimizer.param_groups:
+            param_group['lr'] = lr
+
+    def feature_distance_loss(self, base_features, other_features, distance_function=None):
+        """distance(mean_b(base) - mean_b(other)) (reference srgan.py:438-449)."""
+        if distance_function is None:
+            distance_function = self.settings.matching_distance_function
+        if self.settings.normalize_feature_norm:
+            raise NotImplementedError('normalize_feature_norm=True (off by default, and broadcasting un-meaned '
+                                      'features in the reference, srgan.py:447) is not implemented')
+        base_mean_features = self.batch_mean_of_features(base_features)
+        other_mean_features = self.batch_mean_of_features(other_features)
+        return distance_function(F.sub(base_mean_features, other_mean_features))
+
+    @property
+    def inference_network(self):
+        return self.D
+
+    def inference_setup(self):
+        self.model_setup()
+        self.gpu_mode()
+        self.load_models(with_optimizers=False)
+        self.eval_mode()
+
+    def inference(self, input_):
+        raise NotImplementedError
+
+
+def disable_batch_norm_updates(module):
+    """Every batch-norm layer in eval mode (reference srgan.py:538-542).  The HIP batch-norm always uses the
+    running statistics, so this only keeps ``module.training`` flags consistent with the reference."""
+    if isinstance(module, torch.nn.modules.batchnorm._BatchNorm):
+        module.eval()
+
+
+def enable_batch_norm_updates(module):
+    """reference srgan.py:545-549 (never used on the hot path: the re-enable is commented out upstream)."""
+    if isinstance(module, torch.nn.modules.batchnorm._BatchNorm):
+        module.train()

@@ -1,0 +1,192 @@
+"""A small reverse-mode tape with differentiable backward passes.
+
+The reference relies on torch.autograd for ``loss.backward()`` (srgan.py:264,280-295,304) and for the
+double backward of the gradient penalty (``autograd.grad(..., create_graph=True)``, srgan.py:368-370).
+Here every differentiable operation is a HIP kernel launch recorded on this tape; each operation's
+backward is itself written with tape operations, so differentiating a gradient (the penalty) needs nothing
+special.  torch is used only as the device allocator behind ``Var.data``.
+"""
+import contextlib
+
+import torch
+
+_grad_enabled = True
+
+
+def grad_enabled():
+    return _grad_enabled
+
+
+@contextlib.contextmanager
+def no_grad():
+    global _grad_enabled
+    previous, _grad_enabled = _grad_enabled, False
+    try:
+        yield
+    finally:
+        _grad_enabled = previous
+
+
+@contextlib.contextmanager
+def enable_grad():
+    global _grad_enabled
+    previous, _grad_enabled = _grad_enabled, True
+    try:
+        yield
+    finally:
+        _grad_enabled = previous
+
+
+class Node:
+    """One recorded operation: its inputs and a function mapping the output gradient to input gradients."""
+    __slots__ = ('inputs', 'backward', 'name')
+
+    def __init__(self, inputs, backward, name=''):
+        self.inputs = inputs
+        self.backward = backward
+        self.name = name
+
+
+class Var:
+    """A device tensor (contiguous fp32) with an optional producer node.
+
+    Leaves created from parameters carry ``grad_buffer``: a view of the network's flat gradient arena into
+    which ``backward`` accumulates."""
+    __slots__ = ('data', 'node', 'requires_grad', 'grad_buffer', 'grad', '__weakref__')
+
+    def __init__(self, data, requires_grad=False, node=None):
+        self.data = data
+        self.requires_grad = requires_grad
+        self.node = node
+        self.grad_buffer = None
+        self.grad = None
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    def numel(self):
+        return self.data.numel()
+
+    def detach(self):
+        return Var(self.data)
+
+    def item(self):
+        return self.data.item()
+
+    def cpu(self):
+        return self.data.detach().cpu()
+
+    def size(self, dim=None):
+        return self.data.size() if dim is None else self.data.size(dim)
+
+    def __repr__(self):
+        return f'Var(shape={self.shape}, requires_grad={self.requires_grad}, op={self.node.name if self.node else None})'
+
+
+def _topological_order(root, relevant):
+    """Nodes reachable from ``root`` through vars in ``relevant`` (or all requiring grad), consumers first."""
+    order, visited, stack = [], set(), [(root, False)]
+    while stack:
+        var, expanded = stack.pop()
+        if expanded:
+            order.append(var)
+            continue
+        if id(var) in visited or var.node is None:
+            continue
+        visited.add(id(var))
+        stack.append((var, True))
+        for parent in var.node.inputs:
+            if parent is not None and parent.requires_grad and (relevant is None or id(parent) in relevant):
+                stack.append((parent, False))
+    order.reverse()
+    return order
+
+
+def _relevant_set(root, inputs):
+    """ids of vars on a path from ``root`` down to one of ``inputs``."""
+    wanted = {id(v) for v in inputs}
+    memo = {}
+    stack = [(root, False)]
+    while stack:
+        var, expanded = stack.pop()
+        key = id(var)
+        if expanded:
+            memo[key] = key in wanted or any(p is not None and memo.get(id(p), False) for p in var.node.inputs)
+            continue
+        if key in memo:
+            continue
+        if var.node is None:
+            memo[key] = key in wanted
+            continue
+        memo[key] = key in wanted     # provisional (cycle-free graph: only used before expansion completes)
+        stack.append((var, True))
+        for parent in var.node.inputs:
+            if parent is not None and parent.requires_grad and id(parent) not in memo:
+                stack.append((parent, False))
+    return {key for key, value in memo.items() if value}
+
+
+def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None):
+    """Reverse sweep from ``root``.
+
+    Without ``inputs`` gradients are accumulated into the ``grad_buffer`` (parameters) or ``grad`` (other
+    leaves) of every leaf that requires grad, like ``Tensor.backward``.  With ``inputs`` the gradients of
+    exactly those vars are returned and nothing is accumulated, like ``torch.autograd.grad``; only the part
+    of the graph between ``root`` and ``inputs`` is differentiated (so e.g. no weight gradients are computed
+    for the gradient-penalty's inner gradient).  ``create_graph`` records the backward pass itself.
+    """
+    from . import functional as F   # local import: functional builds on this module
+    if retain_graph is None:
+        retain_graph = create_graph
+    if not root.requires_grad:
+        raise RuntimeError('backward() on a var that does not require grad')
+    if grad is None:
+        if root.numel() != 1:
+            raise RuntimeError('grad can be implicitly created only for scalar outputs')
+        grad = F.full_like(root, 1.0)
+    relevant = _relevant_set(root, inputs) if inputs is not None else None
+    order = _topological_order(root, relevant)
+    grads = {id(root): grad}
+    context = enable_grad() if create_graph else no_grad()
+    results = {}
+    wanted = {id(v): v for v in inputs} if inputs is not None else {}
+    with context:
+        if id(root) in wanted:
+            results[id(root)] = grad
+        for var in order:
+            g = grads.pop(id(var), None)
+            if g is None:
+                continue
+            node = var.node
+            needs = tuple(p is not None and p.requires_grad and (relevant is None or id(p) in relevant)
+                          for p in node.inputs)
+            input_grads = node.backward(g, needs)
+            for parent, need, pg in zip(node.inputs, needs, input_grads):
+                if not need or pg is None:
+                    continue
+                if pg.shape != parent.shape:
+                    raise RuntimeError(f'{node.name}: gradient shape {pg.shape} != input shape {parent.shape}')
+                key = id(parent)
+                if parent.node is None:                      # leaf
+                    if inputs is not None:
+                        if key in wanted:
+                            results[key] = pg if key not in results else F.add(results[key], pg)
+                    elif parent.grad_buffer is not None:
+                        F.accumulate_(parent.grad_buffer, pg)
+                    else:
+                        parent.grad = pg if parent.grad is None else F.add(parent.grad, pg)
+                else:
+                    if key in wanted:
+                        results[key] = pg if key not in results else F.add(results[key], pg)
+                    grads[key] = pg if key not in grads else F.add(grads[key], pg)
+            if not retain_graph:
+                node.backward = _released
+                node.inputs = ()
+    if inputs is not None:
+        return [results.get(id(v)) for v in inputs]
+    return None
+
+
+def _released(*_):
+    raise RuntimeError('this part of the graph was already back-propagated through and freed')

@@ -1,0 +1,298 @@
+"""GPU parity tests of the HIP operations (through the C ABI) against plain PyTorch-CPU fp32 references of
+the same ops -- the functions the reference itself calls (torch.nn.functional.conv2d etc.).
+Tolerance: 1e-3 relative to the tensor's magnitude (north_star), fp32 exact-MFMA results are typically 1e-6."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """CPU: the shared object loads and exports every function include/srgan_hip.h declares."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'srgan_hip.h')).read()
+    declared = set(re.findall(r'\b(srgan_[a-z0-9_]+)\s*\(', header))
+    declared.discard('srgan_conv_desc')
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_lib.LIBRARY)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} is declared in srgan_hip.h but not exported'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.library().srgan_version() == 100
+
+
+def test_product_fails_loudly_without_gpu_tensors():
+    """CPU: the product path has no CPU fallback."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd import functional as F, _lib
+    with pytest.raises(_lib.HipLibraryError):
+        F.leaf(torch.zeros(4))
+
+
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def F():
+    import srgan_amd  # noqa: F401
+    from srgan_amd import functional
+    assert torch.cuda.is_available()
+    return functional
+
+
+def dev(t):
+    return t.cuda()
+
+
+def close(actual, expected, rtol=1e-3, what=''):
+    actual = actual.cpu() if hasattr(actual, 'cpu') else actual
+    actual = actual.detach().double().numpy() if isinstance(actual, torch.Tensor) else np.asarray(actual, np.float64)
+    expected = expected.detach().double().numpy()
+    assert actual.shape == expected.shape, f'{what}: {actual.shape} vs {expected.shape}'
+    denom = max(np.abs(expected).max(), 1e-20)
+    err = np.abs(actual - expected).max() / denom
+    assert np.isfinite(actual).all(), f'{what}: non-finite values'
+    assert err <= rtol, f'{what}: max err / max|ref| = {err:.3e}'
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, S, stride, pad
+    (2, 3, 9, 8, 5, 3, 3, (1, 1), (1, 1)),
+    (2, 4, 7, 7, 6, 1, 1, (1, 1), (0, 0)),
+    (2, 3, 12, 10, 4, 4, 4, (2, 2), (1, 1)),
+    (1, 3, 15, 13, 4, 7, 7, (2, 2), (3, 3)),
+    (2, 2, 8, 8, 3, 2, 2, (2, 2), (0, 0)),
+    (3, 5, 4, 6, 7, 4, 6, (1, 1), (0, 0)),
+    (1, 2, 10, 10, 3, 3, 3, (3, 3), (1, 1)),
+    # DenseNet / DCGAN / VGG tile-boundary shapes (multi-tile, split-K, all MFMA tile configs)
+    (4, 256, 28, 28, 128, 1, 1, (1, 1), (0, 0)),
+    (4, 128, 28, 28, 32, 3, 3, (1, 1), (1, 1)),
+    (3, 200, 7, 7, 128, 1, 1, (1, 1), (0, 0)),
+    (2, 3, 64, 64, 64, 7, 7, (2, 2), (3, 3)),
+    (2, 64, 32, 32, 128, 4, 4, (2, 2), (1, 1)),
+    (2, 64, 20, 20, 64, 3, 3, (1, 1), (1, 1)),
+    (2, 48, 8, 8, 1, 8, 8, (8, 8), (0, 0)),          # map head in conv form (K = 1 -> direct kernel)
+    (2, 32, 16, 16, 20, 16, 16, (1, 1), (0, 0)),     # "linear" conv with a long reduction
+    (5, 70, 9, 9, 40, 3, 3, (1, 1), (1, 1)),         # ragged in every dimension
+]
+
+
+@gpu
+@pytest.mark.parametrize('force', [0, 1, 2])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_passes(F, case, force):
+    n, c, h, w_, k, r, s, stride, pad = case
+    if force == 1 and n * c * h * w_ * k * r * s > 3e8:
+        pytest.skip('direct kernel is only a cross-check for small shapes')
+    gen = torch.Generator().manual_seed(abs(hash(case)) % 1000)
+    x = torch.randn(n, c, h, w_, generator=gen)
+    w = torch.randn(k, c, r, s, generator=gen) / (c * r * s) ** 0.5
+    b = torch.randn(k, generator=gen)
+    y_ref = TF.conv2d(x, w, b, stride, pad)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    F.FORCE_KERNEL = force
+    try:
+        xv, wv, bv, gyv = (F.leaf(dev(t)) for t in (x, w, b, gy))
+        close(F.conv2d(xv, wv, bv, stride, pad), y_ref, what='fwd')
+        close(F.conv2d_backward_data(gyv, wv, x.shape, stride, pad), torch.nn.grad.conv2d_input(x.shape, w, gy, stride, pad),
+              what='bwd_data')
+        close(F.conv2d_backward_weight(xv, gyv, w.shape, stride, pad),
+              torch.nn.grad.conv2d_weight(x, w.shape, gy, stride, pad), what='bwd_weight')
+    finally:
+        F.FORCE_KERNEL = 0
+
+
+@gpu
+def test_conv_transpose(F):
+    gen = torch.Generator().manual_seed(3)
+    for (cin, cout, k, s, p, hin, batch) in [(6, 4, 4, 2, 1, 5, 2), (32, 48, 3, 1, 0, 1, 3), (40, 1, 4, 4, 0, 6, 2),
+                                             (64, 3, 4, 2, 1, 16, 2), (256, 64, 2, 1, 0, 1, 4)]:
+        z = torch.randn(batch, cin, hin, hin, generator=gen)
+        w = torch.randn(cin, cout, k, k, generator=gen) / cin ** 0.5
+        b = torch.randn(cout, generator=gen)
+        ref = TF.conv_transpose2d(z, w, b, stride=s, padding=p)
+        out = F.conv_transpose2d(F.leaf(dev(z)), F.leaf(dev(w)), F.leaf(dev(b)), s, p)
+        close(out, ref, what=f'convT {cin}->{cout} k{k}s{s}')
+
+
+@gpu
+@pytest.mark.parametrize('force', [0, 2])
+def test_linear_and_mm(F, force):
+    gen = torch.Generator().manual_seed(5)
+    F.FORCE_KERNEL = force
+    try:
+        for (bsz, fin, fout) in [(7, 11, 5), (256, 50, 10), (64, 300, 130), (2, 25088 // 8, 512), (130, 64, 1)]:
+            x, w, b = torch.randn(bsz, fin, generator=gen), torch.randn(fout, fin, generator=gen), torch.randn(fout, generator=gen)
+            xv, wv, bv = F.leaf(dev(x)), F.leaf(dev(w)), F.leaf(dev(b))
+            close(F.linear(xv, wv, bv), TF.linear(x, w, b), what=f'linear {bsz}x{fin}x{fout}')
+            gy = torch.randn(bsz, fout, generator=gen)
+            gv = F.leaf(dev(gy))
+            close(F.mm(gv, wv), gy @ w, what='g @ w')
+            close(F.mm(gv, xv, True, False), gy.t() @ x, what='g^T @ x')
+            close(F.mm(xv, gv, True, False), x.t() @ gy, what='x^T @ g')
+            close(F.mm(wv, xv, False, True), w @ x.t(), what='w @ x^T')
+    finally:
+        F.FORCE_KERNEL = 0
+
+
+@gpu
+def test_elementwise(F):
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(1031, generator=gen)
+    pos = x.abs() + 0.1
+    xv, pv = F.leaf(dev(x)), F.leaf(dev(pos))
+    cases = [(F.neg(xv), -x), (F.abs_(xv), x.abs()), (F.sign(xv), x.sign()), (F.sqrt(pv), pos.sqrt()), (F.exp(xv), x.exp()),
+             (F.log(pv), pos.log()), (F.log1p(pv), pos.log1p()), (F.square(xv), x * x), (F.tanh(xv), x.tanh()),
+             (F.relu(xv), x.relu()), (F.leaky_relu(xv, 0.05), TF.leaky_relu(x, 0.05)), (F.affine(xv, 2.5, -1.0), 2.5 * x - 1),
+             (F.pow_scalar(pv, 3.0), pos ** 3), (F.pow_scalar(pv, 1.5), pos ** 1.5), (F.sigmoid(xv), x.sigmoid()),
+             (F.softplus(xv), TF.softplus(x)), (F.one_minus_square(xv), 1 - x * x)]
+    for i, (actual, expected) in enumerate(cases):
+        close(actual, expected, rtol=1e-5, what=f'unary {i}')
+    y = torch.randn(1031, generator=gen)
+    y[5] = 0.0
+    yv = F.leaf(dev(y))
+    close(F.add(xv, yv), x + y, 1e-6)
+    close(F.sub(xv, yv), x - y, 1e-6)
+    close(F.mul(xv, yv), x * y, 1e-6)
+    close(F.div(xv, pv), x / pos, 1e-6)
+    safe = torch.where(y == 0, torch.zeros_like(x), x / y)
+    close(F.div_safe(xv, yv), safe, 1e-6)
+    close(F.mask_mul(xv, yv, 0.01), torch.where(y > 0, x, 0.01 * x), 1e-6)
+
+
+@gpu
+def test_channel_ops_and_frozen_batch_norm(F):
+    gen = torch.Generator().manual_seed(7)
+    for shape in [(3, 5, 6, 7), (2, 4, 40, 40), (4, 300, 1, 1), (2, 7, 3, 3)]:
+        x = torch.randn(shape, generator=gen)
+        c = shape[1]
+        mean, var = torch.randn(c, generator=gen), torch.rand(c, generator=gen) + 0.5
+        gamma, beta = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
+        ref = TF.batch_norm(x, mean, var, gamma, beta, training=False, eps=1e-5)
+        inv = (var + 1e-5).rsqrt()
+        out = F.chan_affine(F.leaf(dev(x)), F.leaf(dev(mean)), F.leaf(dev(inv)), F.leaf(dev(gamma)), F.leaf(dev(beta)))
+        close(out, ref, 1e-5, what=f'bn {shape}')
+        g = torch.randn(shape, generator=gen)
+        close(F.chan_reduce(F.leaf(dev(g))), g.sum(dim=(0, 2, 3)), 1e-5, 'chan sum')
+        expected = (g * (x - mean.view(1, -1, 1, 1))).sum(dim=(0, 2, 3)) * inv
+        close(F.chan_reduce(F.leaf(dev(g)), F.leaf(dev(x)), F.leaf(dev(mean)), F.leaf(dev(inv))), expected, 1e-4, 'gamma grad')
+    feats = torch.randn(16, 70000, generator=gen)
+    fv = F.leaf(dev(feats))
+    close(F.row_dot(fv, fv), (feats * feats).sum(1), 1e-5, 'row_dot')
+    close(F.row_norm(fv), feats.norm(dim=1), 1e-5, 'row_norm')
+    close(F.col_sum(fv), feats.sum(0), 1e-4, 'col_sum')
+    close(F.sum_all(fv), feats.sum().view(1), 1e-3, 'sum_all')
+    s = torch.randn(16, generator=gen)
+    close(F.row_scale(fv, F.leaf(dev(s))), feats * s.view(-1, 1), 1e-6, 'row_scale')
+    close(F.row_broadcast(F.leaf(dev(s)), (16, 33)), s.view(-1, 1).expand(16, 33), 1e-6, 'row_broadcast')
+
+
+@gpu
+def test_pooling_and_layout(F):
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 5, 13, 11, generator=gen)
+    xv = F.leaf(dev(x), requires_grad=True)
+    for (k, s, p) in [(3, 2, 1), (2, 2, 0)]:
+        close(F.max_pool2d(xv, k, s, p), TF.max_pool2d(x, k, s, p), 1e-6, f'maxpool k{k}')
+    xr = x.clone().requires_grad_()
+    ref = TF.max_pool2d(xr.relu(), 3, 2, 1)     # many ties at zero: arg-max choice must match torch
+    g = torch.randn(ref.shape, generator=gen)
+    ref.backward(g)
+    from srgan_amd.tape import backward
+    out = F.max_pool2d(F.relu(xv), 3, 2, 1)
+    backward(out, grad=F.leaf(dev(g)))
+    close(xv.grad, xr.grad, 1e-6, 'maxpool backward with ties')
+    for (k, s) in [(2, 2), (3, 1), (4, 4)]:
+        x2 = torch.randn(2, 3, 12, 12, generator=gen).requires_grad_()
+        ref = TF.avg_pool2d(x2, k, s)
+        g = torch.randn(ref.shape, generator=gen)
+        ref.backward(g)
+        x2v = F.leaf(dev(x2.detach()), requires_grad=True)
+        out = F.avg_pool2d(x2v, k, s)
+        close(out, ref, 1e-6, 'avgpool')
+        backward(out, grad=F.leaf(dev(g)))
+        close(x2v.grad, x2.grad, 1e-6, 'avgpool backward')
+    a, b = torch.randn(2, 3, 4, 4, generator=gen), torch.randn(2, 5, 4, 4, generator=gen)
+    cat = F.cat_channels([F.leaf(dev(a)), F.leaf(dev(b))])
+    close(cat, torch.cat([a, b], 1), 1e-7, 'cat')
+    close(F.slice_channels(cat, 2, 6), torch.cat([a, b], 1)[:, 2:6], 1e-7, 'slice')
+
+
+@gpu
+def test_gradient_penalty_double_backward_matches_torch(F):
+    """conv -> leaky -> conv(stride 2) -> frozen BN -> relu -> maxpool -> linear features; penalty on the input
+    gradient; parameter gradients of the penalty through the double backward."""
+    from srgan_amd.tape import backward
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 2, 10, 10, generator=gen)
+    w1 = torch.randn(6, 2, 3, 3, generator=gen) * 0.5
+    b1 = torch.randn(6, generator=gen) * 0.1
+    w2 = torch.randn(4, 6, 4, 4, generator=gen) * 0.3
+    gamma, beta = torch.rand(4, generator=gen) + 0.5, torch.randn(4, generator=gen) * 0.1
+    mean, var = torch.randn(4, generator=gen) * 0.1, torch.rand(4, generator=gen) + 0.5
+    wl = torch.randn(5, 36, generator=gen) * 0.5
+    params = [w1, b1, w2, gamma, beta, wl]
+    tp = [p.clone().requires_grad_() for p in params]
+    xt = x.clone().requires_grad_()
+    h = TF.leaky_relu(TF.conv2d(xt, tp[0], tp[1], 1, 1), 0.05)
+    h = TF.conv2d(h, tp[2], None, 2, 1)
+    h = TF.batch_norm(h, mean, var, tp[3], tp[4], training=False).relu()
+    h = TF.max_pool2d(h, 3, 2, 1)
+    feats = TF.linear(h.reshape(3, -1), tp[5])
+    f = feats.norm(dim=1)
+    (gx,) = torch.autograd.grad(f, xt, torch.ones_like(f), create_graph=True)
+    gn = gx.reshape(3, -1).norm(dim=1)
+    penalty = (torch.relu(gn - 0.1) ** 2).mean() * 10
+    penalty.backward()
+
+    pv = [F.leaf(dev(p), requires_grad=True) for p in params]
+    xv = F.leaf(dev(x), requires_grad=True)
+    hv = F.leaky_relu(F.conv2d(xv, pv[0], pv[1], 1, 1), 0.05)
+    hv = F.conv2d(hv, pv[2], None, 2, 1)
+    inv = F.leaf(dev((var + 1e-5).rsqrt()))
+    hv = F.relu(F.chan_affine(hv, F.leaf(dev(mean)), inv, pv[3], pv[4]))
+    hv = F.max_pool2d(hv, 3, 2, 1)
+    fv = F.row_norm(F.linear(F.flatten2d(hv), pv[5]))
+    close(fv, f, 1e-5, 'feature norm')
+    (gxv,) = backward(fv, grad=F.full_like(fv, 1.0), inputs=[xv], create_graph=True)
+    close(gxv, gx, 1e-4, 'input gradient')
+    gnv = F.row_norm(F.flatten2d(gxv))
+    pen = F.scale(F.mean_all(F.square(F.relu(F.add_scalar(gnv, -0.1)))), 10.0)
+    close(pen, penalty.view(1), 1e-4, 'penalty')
+    backward(pen)
+    for i, (v, t) in enumerate(zip(pv, tp)):
+        close(v.grad, t.grad, 1e-3, f'penalty grad of param {i}')
+
+
+@gpu
+def test_adam_matches_torch(F):
+    import srgan_amd  # noqa: F401
+    from srgan_amd import nn
+    from srgan_amd.optim import Adam
+    torch.manual_seed(0)
+    module = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    reference = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    reference.load_state_dict(module.state_dict())
+    arena = nn.flatten_parameters(module, torch.device('cuda', 0))
+    optimizer = Adam(arena, lr=1e-2, weight_decay=0.1)
+    reference_optimizer = torch.optim.Adam(reference.parameters(), lr=1e-2, weight_decay=0.1)
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(5):
+        for p, q in zip(module.parameters(), reference.parameters()):
+            g = torch.randn(q.shape, generator=gen)
+            q.grad = g.clone()
+            p.grad.copy_(g)
+        optimizer.step()
+        reference_optimizer.step()
+    for p, q in zip(module.parameters(), reference.parameters()):
+        close(p.data, q.data, 1e-6, 'adam parameter')
+    state = optimizer.state_dict()
+    assert set(state['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    close(state['state'][0]['exp_avg'], reference_optimizer.state_dict()['state'][0]['exp_avg'], 1e-6, 'exp_avg')

@@ -1,0 +1,306 @@
+"""GPU parity of whole training steps (HIP path through the C ABI) against the golden fixtures generated from
+the unmodified reference (tests/golden/make_goldens.py) and against the CPU oracle on the same seeded inputs.
+Tolerance 1e-3 relative (north_star); every case runs in both schedules (shared forwards / reference order)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, golden_state, golden_scalars, checksum, assert_close
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import srgan_amd
+    assert torch.cuda.is_available()
+    return srgan_amd
+
+
+def make_experiment(builders, settings_overrides, sgan_bins=None, crowd=False):
+    from srgan_amd.settings import Settings
+    from srgan_amd.srgan import Experiment
+    from srgan_amd.sgan import SganExperiment
+    from srgan_amd.utility import SummaryWriter, seed_all
+    base = SganExperiment if sgan_bins is not None else Experiment
+    if crowd:
+        from srgan_amd.crowd.srgan import CrowdExperiment
+        base = CrowdExperiment
+
+    class _Experiment(base):
+        def dataset_setup(self):
+            pass
+
+        def model_setup(self):
+            self.G, self.D, self.DNN = builders()
+
+        def validation_summaries(self, step):
+            pass
+
+    settings = Settings()
+    for key, value in settings_overrides.items():
+        setattr(settings, key, value)
+    experiment = _Experiment(settings)
+    if sgan_bins is not None:
+        experiment.bins = sgan_bins
+    seed_all(0)
+    experiment.model_setup()
+    experiment.dnn_summary_writer = SummaryWriter()
+    experiment.gan_summary_writer = SummaryWriter()
+    return experiment
+
+
+def finish_setup(experiment):
+    experiment.gpu_mode()
+    experiment.prepare_optimizers()
+    experiment.train_mode()
+
+
+def run_step(experiment, x, y, u, step, g):
+    experiment.injected_draws = {k: torch.from_numpy(g[f's{step}/{k}']) for k in ('z_d', 'z_g', 'alpha')}
+    experiment.dnn_training_step(x, y, step)
+    experiment.gan_training_step(x, y, u, step)
+    scalars = {tag: values[-1][1] for tag, values in experiment.gan_summary_writer.scalars.items()}
+    names = {'Generator/Loss': 'generator_loss', 'Discriminator/Labeled Loss': 'labeled_loss',
+             'Discriminator/Unlabeled Loss': 'unlabeled_loss', 'Discriminator/Fake Loss': 'fake_loss',
+             'Discriminator/Gradient Penalty': 'gradient_penalty', 'Discriminator/Gradient Norm': 'gradient_norm_mean',
+             'Feature Norm/Labeled': 'feature_norm_labeled', 'Feature Norm/Unlabeled': 'feature_norm_unlabeled'}
+    result = {names[tag]: value for tag, value in scalars.items()}
+    result['dnn_loss'] = experiment.dnn_summary_writer.scalars['Discriminator/Labeled Loss'][-1][1]
+    return result
+
+
+def check(result, expected, what):
+    for key, value in expected.items():
+        if key in result:
+            atol = 1e-6 if abs(value) < 1e-3 else 0.0
+            assert_close(result[key], value, rtol=RTOL, atol=atol, what=f'{what} {key}')
+
+
+def dev(array):
+    return torch.from_numpy(np.asarray(array)).cuda()
+
+
+@pytest.mark.parametrize('reference_schedule', [False, True])
+@pytest.mark.parametrize('name,steps', [('g3_coefficient_srgan', 3), ('g3b_coefficient_srgan_gp_active', 2)])
+def test_coefficient_srgan(pkg, name, steps, reference_schedule):
+    from srgan_amd.coefficient.models import MLP, Generator
+    g = load_golden(name)
+    experiment = make_experiment(lambda: (Generator(10), MLP(10), MLP(10)),
+                                 dict(batch_size=int(g['batch_size']), reference_schedule=reference_schedule))
+    for module, prefix in ((experiment.D, 'init/D'), (experiment.DNN, 'init/DNN'), (experiment.G, 'init/G')):
+        module.load_state_dict(golden_state(g, prefix))
+    finish_setup(experiment)
+    for step in range(steps):
+        x, y, u = (dev(g[f's{step}/{k}']) for k in ('x', 'y', 'u'))
+        result = run_step(experiment, x, y, u, step, g)
+        check(result, golden_scalars(g, step), f'{name} step {step}')
+        assert_close(experiment.gradient_norm.cpu().numpy(), g[f's{step}/gradient_norm'], rtol=RTOL, atol=1e-6,
+                     what='gradient_norm')
+        assert_close(experiment.labeled_features.cpu().numpy(), g[f's{step}/labeled_features'], rtol=RTOL, atol=1e-5,
+                     what='labeled_features')
+    for key, value in golden_state(g, 'final/D').items():
+        assert_close(experiment.D.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=2e-5,
+                     what=f'final D {key}')
+    for key, value in golden_state(g, 'final/G').items():
+        assert_close(experiment.G.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=2e-5,
+                     what=f'final G {key}')
+
+
+def test_coefficient_first_step_gradients(pkg):
+    from srgan_amd.coefficient.models import MLP, Generator
+    g = load_golden('g3b_coefficient_srgan_gp_active')
+    experiment = make_experiment(lambda: (Generator(10), MLP(10), MLP(10)), dict(batch_size=int(g['batch_size'])))
+    for module, prefix in ((experiment.D, 'init/D'), (experiment.DNN, 'init/DNN'), (experiment.G, 'init/G')):
+        module.load_state_dict(golden_state(g, prefix))
+    finish_setup(experiment)
+    experiment.d_optimizer.step = lambda: None      # keep the accumulated gradients for inspection
+    experiment.g_optimizer.step = lambda: None
+    x, y, u = (dev(g[f's0/{k}']) for k in ('x', 'y', 'u'))
+    run_step(experiment, x, y, u, 0, g)
+    for name, parameter in experiment.D.named_parameters():
+        expected = g[f's0/d_grad/{name}']
+        scale = np.abs(expected).max()
+        assert_close(parameter.grad.cpu().numpy(), expected, rtol=RTOL, atol=1e-4 * scale, what=f'D grad {name}')
+    for name, parameter in experiment.G.named_parameters():
+        expected = g[f's0/g_grad/{name}']
+        scale = np.abs(expected).max()
+        assert_close(parameter.grad.cpu().numpy(), expected, rtol=RTOL, atol=1e-4 * scale, what=f'G grad {name}')
+
+
+def test_coefficient_sgan(pkg):
+    from srgan_amd.coefficient.models import SganMLP, Generator
+    g = load_golden('g4_coefficient_sgan')
+    experiment = make_experiment(lambda: (Generator(), SganMLP(10), SganMLP(10)), dict(batch_size=int(g['batch_size'])),
+                                 sgan_bins=torch.linspace(-3, 3, 10))
+    for module, prefix in ((experiment.D, 'init/D'), (experiment.DNN, 'init/DNN'), (experiment.G, 'init/G')):
+        module.load_state_dict(golden_state(g, prefix))
+    finish_setup(experiment)
+    for step in range(2):
+        x, y, u = (dev(g[f's{step}/{k}']) for k in ('x', 'y', 'u'))
+        result = run_step(experiment, x, y, u, step, g)
+        check(result, golden_scalars(g, step), f'sgan step {step}')
+    for key, value in golden_state(g, 'final/D').items():
+        assert_close(experiment.D.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=2e-5, what=key)
+
+
+@pytest.mark.parametrize('reference_schedule', [False, True])
+def test_tiny_dcgan_with_active_gradient_penalty(pkg, reference_schedule):
+    from srgan_amd.age.models import Generator, Discriminator
+    g = load_golden('g5_tiny_dcgan')
+    experiment = make_experiment(lambda: (Generator(image_size=32, conv_dim=8), Discriminator(32, 8), Discriminator(32, 8)),
+                                 dict(batch_size=4, matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
+                                      gradient_penalty_multiplier=1e2, reference_schedule=reference_schedule))
+    for key, value in golden_state(g, 'init/G').items():    # constructors reproduce the reference's random stream
+        np.testing.assert_array_equal(experiment.G.state_dict()[key].numpy(), value.numpy())
+    for module, prefix in ((experiment.D, 'init/D'), (experiment.DNN, 'init/DNN')):
+        module.load_state_dict(golden_state(g, prefix))
+    finish_setup(experiment)
+    for step in range(2):
+        x, y, u = (dev(g[f's{step}/{k}']) for k in ('x', 'y', 'u'))
+        result = run_step(experiment, x, y, u, step, g)
+        check(result, golden_scalars(g, step), f'tiny dcgan step {step}')
+        assert_close(experiment.gradient_norm.cpu().numpy(), g[f's{step}/gradient_norm'], rtol=RTOL, what='gn')
+        assert_close(experiment.fake_features.cpu().numpy(), g[f's{step}/fake_features'], rtol=RTOL, atol=1e-4,
+                     what='fake features')
+    assert result['gradient_penalty'] > 1.0
+    for key, value in golden_state(g, 'final/D').items():
+        assert_close(experiment.D.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=3e-5, what=key)
+    for key, value in golden_state(g, 'final/G').items():
+        assert_close(experiment.G.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=3e-5, what=key)
+
+
+def test_layer_kats_with_double_backward(pkg):
+    """_DenseLayer / _DenseBlock / _Transition / MapModule / stem: forward, input gradient and the parameter
+    gradients of a gradient-penalty style double backward, against the reference's own layers (golden g6)."""
+    from collections import OrderedDict
+    from srgan_amd import functional as F, nn
+    from srgan_amd.crowd.models import _DenseLayer, _DenseBlock, _Transition, MapModule
+    from srgan_amd.tape import backward
+    g = load_golden('g6_layers')
+    stem = nn.Sequential(OrderedDict([('conv0', nn.Conv2d(3, 8, kernel_size=7, stride=2, padding=3, bias=False)),
+                                      ('norm0', nn.BatchNorm2d(8)), ('relu0', nn.ReLU(inplace=True)),
+                                      ('pool0', nn.MaxPool2d(kernel_size=3, stride=2, padding=1))]))
+    modules = {'dense_layer': _DenseLayer(16, 8, 4, 0), 'dense_block': _DenseBlock(3, 8, 2, 4, 0),
+               'transition': _Transition(32, 16), 'map_module': MapModule(16, 4, 32), 'stem': stem}
+    for prefix, module in modules.items():
+        module.load_state_dict(golden_state(g, f'{prefix}/state'))
+        nn.flatten_parameters(module, torch.device('cuda', 0))
+        x = F.leaf(dev(g[f'{prefix}/x']), requires_grad=True)
+        y = module(x)
+        ys = list(y) if isinstance(y, tuple) else [y]
+        scalar = None
+        for i, t in enumerate(ys):
+            assert_close(t.cpu().numpy(), g[f'{prefix}/y{i}'], rtol=RTOL, atol=1e-5, what=f'{prefix} y{i}')
+            term = F.sum_all(F.mul(t, F.leaf(dev(g[f'{prefix}/c{i}']))))
+            scalar = term if scalar is None else F.add(scalar, term)
+        (gx,) = backward(scalar, inputs=[x], create_graph=True)
+        assert_close(gx.cpu().numpy(), g[f'{prefix}/gx'], rtol=RTOL, atol=1e-5, what=f'{prefix} gx')
+        penalty = F.mean_all(F.square(F.row_norm(F.flatten2d(gx))))
+        assert_close(penalty.cpu().numpy().reshape(()), g[f'{prefix}/penalty'], rtol=RTOL, what=f'{prefix} penalty')
+        module._srgan_arena.zero_grad()
+        backward(penalty)
+        for name, parameter in module.named_parameters():
+            key = f'{prefix}/ggparam/{name}'
+            if key in g.files:
+                expected = g[key]
+                assert_close(parameter.grad.cpu().numpy(), expected, rtol=RTOL, atol=1e-4 * max(np.abs(expected).max(), 1e-8),
+                             what=f'{prefix} penalty grad {name}')
+
+
+def crowd_inputs(generator, batch, size):
+    x = torch.rand(batch, 3, size, size, generator=generator) * 2 - 1
+    u = torch.rand(batch, 3, size, size, generator=generator) * 2 - 1
+    heads = (torch.rand(batch, size, size, generator=generator) < 0.002).float()
+    knn_map = torch.rand(batch, size, size, generator=generator)
+    return x, (heads, knn_map), u
+
+
+@pytest.mark.parametrize('name,size,steps,reference_schedule', [
+    ('g7b_crowd64', 64, 2, False), ('g7b_crowd64', 64, 1, True), ('g7c_crowd64_gp_active', 64, 1, False),
+    ('g7c_crowd64_gp_active', 64, 1, True), ('g7_crowd224', 224, 1, False)])
+def test_crowd_steps(pkg, name, size, steps, reference_schedule):
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
+    g = load_golden(name)
+    batch = int(g['batch_size'])
+    experiment = make_experiment(
+        lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
+        dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
+             gradient_penalty_multiplier=1e2, map_multiplier=1e-3, reference_schedule=reference_schedule), crowd=True)
+    scale = float(g['d_scale'])
+    if scale != 1.0:
+        with torch.no_grad():
+            for m in experiment.D.modules():
+                if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                    m.weight.mul_(scale)
+    for module, prefix in ((experiment.D, 'init_ck/D'), (experiment.DNN, 'init_ck/DNN'), (experiment.G, 'init_ck/G')):
+        for pname, p in module.named_parameters():
+            assert_close(checksum(p), g[f'{prefix}/{pname}'], rtol=1e-9, atol=1e-12, what=f'{prefix} {pname}')
+    finish_setup(experiment)
+    generator = torch.Generator().manual_seed(int(g['input_seed']))
+    batches = [crowd_inputs(generator, batch, size) for _ in range(steps)]
+    from srgan_amd.tape import no_grad
+    from srgan_amd.srgan import as_var
+    with no_grad():
+        density, count, maps = experiment.D(as_var(batches[0][0]))
+    assert_close(count.cpu().numpy(), g['fwd/count'], rtol=RTOL, what='count')
+    assert_close(experiment.D.features.cpu().numpy(), g['fwd/features'], rtol=RTOL, atol=1e-5, what='features')
+    assert_close(checksum(maps.data)[:2], g['fwd/maps_ck'], rtol=RTOL, what='density-map checksums')
+    step_view = max(size // 8, 1)
+    assert_close(maps.cpu().numpy()[:, :, ::step_view, ::step_view], g['fwd/maps_sample'], rtol=RTOL, atol=1e-5,
+                 what='density-map samples')
+    assert float(density.data.abs().sum()) == float(g['fwd/density_abs_sum']) == 0.0
+    for step, (x, y, u) in enumerate(batches):
+        result = run_step(experiment, x.cuda(), tuple(t.cuda() for t in y), u.cuda(), step, g)
+        check(result, golden_scalars(g, step), f'{name} step {step}')
+        assert_close(experiment.gradient_norm.cpu().numpy(), g[f's{step}/gradient_norm'], rtol=RTOL, what='gn')
+    if 'gp_active' in name:
+        assert result['gradient_penalty'] > 10.0
+    if steps == int(np.sum([1 for k in g.files if k.endswith('/alpha')])):
+        # post-step weights: compare per-tensor checksums (abs-sum) of the final parameters
+        for prefix, module in (('final_ck/D', experiment.D), ('final_ck/G', experiment.G)):
+            for pname, p in module.named_parameters():
+                expected = g[f'{prefix}/{pname}']
+                assert_close(checksum(p)[1], expected[1], rtol=RTOL, what=f'{prefix} {pname} abs-sum')
+
+
+def test_age_dcgan128(pkg):
+    from srgan_amd.age.models import Generator, Discriminator
+    g = load_golden('g8_age_dcgan128')
+    experiment = make_experiment(lambda: (Generator(), Discriminator(), Discriminator()),
+                                 dict(batch_size=4, matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
+                                      gradient_penalty_multiplier=1e2))
+    for pname, p in experiment.D.named_parameters():
+        assert_close(checksum(p), g[f'init_ck/D/{pname}'], rtol=1e-9, atol=1e-12, what=pname)
+    finish_setup(experiment)
+    generator = torch.Generator().manual_seed(int(g['input_seed']))
+    for step in range(2):
+        x = torch.rand(4, 3, 128, 128, generator=generator) * 2 - 1
+        u = torch.rand(4, 3, 128, 128, generator=generator) * 2 - 1
+        y = torch.rand(4, generator=generator) * 85 + 10
+        result = run_step(experiment, x.cuda(), y.cuda(), u.cuda(), step, g)
+        check(result, golden_scalars(g, step), f'age step {step}')
+    for prefix, module in (('final_ck/D', experiment.D), ('final_ck/G', experiment.G)):
+        for pname, p in module.named_parameters():
+            assert_close(checksum(p)[1], g[f'{prefix}/{pname}'][1], rtol=RTOL, what=f'{prefix} {pname}')
+
+
+def test_vgg224(pkg):
+    from srgan_amd.age.models import Generator
+    from srgan_amd.age.vgg import vgg16
+    g = load_golden('g8b_vgg224')
+    experiment = make_experiment(lambda: (Generator(image_size=224), vgg16(num_classes=1), vgg16(num_classes=1)),
+                                 dict(batch_size=2, matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
+                                      gradient_penalty_multiplier=1e2))
+    for pname, p in experiment.D.named_parameters():
+        assert_close(checksum(p), g[f'init_ck/D/{pname}'], rtol=1e-9, atol=1e-12, what=pname)
+    finish_setup(experiment)
+    generator = torch.Generator().manual_seed(int(g['input_seed']))
+    x = torch.rand(2, 3, 224, 224, generator=generator) * 2 - 1
+    u = torch.rand(2, 3, 224, 224, generator=generator) * 2 - 1
+    y = torch.rand(2, generator=generator) * 85 + 10
+    result = run_step(experiment, x.cuda(), y.cuda(), u.cuda(), 0, g)
+    check(result, golden_scalars(g, 0), 'vgg step 0')
+    assert_close(experiment.labeled_features.cpu().numpy(), g['s0/labeled_features'], rtol=RTOL, atol=1e-4,
+                 what='vgg features')
