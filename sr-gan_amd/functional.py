@@ -251,7 +251,8 @@ def _dims_nchw(shape):
 
 def chan_affine(x, mean=None, scale_a=None, scale_b=None, shift=None, dims=None, out_shape=None):
     """y[n,c,i] = ((x or 1) - mean[c]) * scale_a[c] * scale_b[c] + shift[c]; ``dims`` = (N, C, HW) view of the
-    data (defaults to NCHW).  ``mean`` is treated as a constant."""
+    data (defaults to NCHW).  ``mean`` is treated as a constant.  NB a missing ``x`` is ONE, so a pure broadcast
+    of a vector passes it as ``scale_a`` (not as ``shift``)."""
     reference = x if x is not None else next(v for v in (scale_a, scale_b, shift) if v is not None)
     if dims is None:
         dims = _dims_nchw(x.shape)
@@ -345,8 +346,15 @@ def row_broadcast(s, shape):
     count = 1
     for extent in shape[1:]:
         count *= extent
-    return chan_affine(None, None, None, None, view(s, (rows,)) if s.shape != (rows,) else s,
+    return chan_affine(None, None, view(s, (rows,)) if s.shape != (rows,) else s, None, None,
                        dims=(1, rows, count), out_shape=tuple(shape))
+
+
+def col_broadcast(v, rows):
+    """out[b, f] = v[f] for b < rows."""
+    width = v.numel()
+    return chan_affine(None, None, view(v, (width,)) if v.shape != (width,) else v, None, None,
+                       dims=(rows, width, 1), out_shape=(rows, width))
 
 
 def row_norm(x):

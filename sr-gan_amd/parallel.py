@@ -1,0 +1,107 @@
+"""Data parallelism for the three-stream batch: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
+
+The reference is single-device.  The step shards naturally over examples, with ONE subtlety
+(SURVEY.md §8e): the feature-matching / contrasting losses apply a non-linear function to the *batch mean* of
+the discriminator features, so ranks must exchange feature sums in the forward pass (a few hundred bytes to a
+few hundred KB) -- averaging per-rank losses or gradients as a stock DDP wrapper would do is NOT the
+reference's arithmetic.  Everything is expressed as SUMs:
+
+* forward: all-reduce(sum) of per-rank feature sums, then divide by the global batch; its backward is the
+  identity on the local sum (every rank already holds dL/d(mean));
+* per-example means (labeled loss, gradient penalty) are local sums / global batch;
+* backward: all-reduce(sum) of each network's flat gradient arena, in large buckets (xGMI is point-to-point,
+  7 links x ~153 GB/s per GPU: few large messages, not one per tensor).
+
+The same object drives the CPU oracle over gloo in the world-size-2 tests (it only needs tensors).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+BUCKET_ELEMENTS = 32 * 1024 * 1024     # 128 MiB fp32 per all-reduce call
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """all-reduce(sum) with identity backward, for torch-autograd users (the oracle)."""
+
+    @staticmethod
+    def forward(ctx, tensor, group):
+        out = tensor.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
+class DataParallel:
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+
+    @classmethod
+    def from_environment(cls, backend=None):
+        """Initialise from RANK / WORLD_SIZE / MASTER_* (torchrun); ``nccl`` (= RCCL) when a GPU is present."""
+        if not dist.is_initialized():
+            if backend is None:
+                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            if backend == 'nccl':
+                torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            dist.init_process_group(backend=backend)
+        return cls()
+
+    # ---- batch bookkeeping -----------------------------------------------------------------------------
+    def global_batch(self, local_batch):
+        return local_batch * self.world_size
+
+    def local_batch(self, global_batch):
+        if global_batch % self.world_size:
+            raise ValueError(f'global batch {global_batch} is not divisible by {self.world_size} ranks')
+        return global_batch // self.world_size
+
+    def shard(self, tensor):
+        """This rank's contiguous slice of the leading (batch) dimension."""
+        local = self.local_batch(tensor.shape[0])
+        return tensor[self.rank * local:(self.rank + 1) * local]
+
+    # ---- collectives -----------------------------------------------------------------------------------
+    def all_reduce_sum_(self, tensor):
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+        return tensor
+
+    def all_reduce_sum_autograd(self, tensor):
+        return _AllReduceSum.apply(tensor, self.group)
+
+    def all_reduce_sum_float(self, value):
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        holder = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(holder, op=dist.ReduceOp.SUM, group=self.group)
+        return float(holder.item())
+
+    def all_reduce_sum_var(self, var):
+        """Tape version: forward all-reduce of a (small) var, identity backward."""
+        from .tape import Var, Node, grad_enabled
+        data = var.data.clone()
+        dist.all_reduce(data, op=dist.ReduceOp.SUM, group=self.group)
+        out = Var(data, requires_grad=grad_enabled() and var.requires_grad)
+        if out.requires_grad:
+            out.node = Node((var,), lambda g, needs: (g,), 'all_reduce_sum')
+        return out
+
+    def all_reduce_gradients(self, arena):
+        """Sum the flat gradient arena over ranks in 128 MiB buckets."""
+        grad = arena.grad
+        for start in range(0, grad.numel(), BUCKET_ELEMENTS):
+            dist.all_reduce(grad[start:start + BUCKET_ELEMENTS], op=dist.ReduceOp.SUM, group=self.group)
+
+    def broadcast_parameters(self, arena, source=0):
+        """Make every rank start from rank ``source``'s weights."""
+        dist.broadcast(arena.data, src=source, group=self.group)
+
+    def barrier(self):
+        dist.barrier(group=self.group)

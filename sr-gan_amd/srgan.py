@@ -479,7 +479,7 @@ class Experiment(ABC):
         if len(predicted_labels.shape) == 2 and predicted_labels.shape[1] == 1 and len(labels.shape) == 1:
             batch = predicted_labels.shape[0]
             rows = F.row_broadcast(F.view(predicted_labels, (batch,)), (batch, batch))
-            columns = F.chan_affine(None, None, None, None, labels, dims=(batch, batch, 1), out_shape=(batch, batch))
+            columns = F.col_broadcast(labels, batch)
             difference = F.sub(rows, columns)
             return F.scale(F.sum_all(F.pow_scalar(F.abs_(difference), order)),
                            1.0 / (batch * self._global_batch(batch)))

