@@ -1,0 +1,233 @@
+"""Headline benchmark: SRGAN training images/s on the crowd workload (BASELINE.json configs[2]/[3]).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one iteration of the reference's training loop (srgan.py:104-118): ``dnn_training_step`` +
+``gan_training_step`` (8 D forwards / 6 D backwards / GP double backward / G forward x2 + backward / 3 Adam
+updates in the reference's schedule) on a synthetic batch of 16 crowd images of 512x512 per GPU (weak scaling:
+global batch = 16 * N), inputs resident in HBM.  Prints ONE JSON line on rank 0.
+
+Extra legs (rank 0, N = 1 only):
+* ``roofline``: every contraction launch (the MFMA gather-GEMM kernel family = the dominant kernel) of one
+  extra step is bracketed with HIP events on its launch stream inside libsrgan_hip.so; achieved =
+  sum(logical 2*M*N*K) / sum(event durations), against the fp32 MFMA peak (157.3 TF/s,
+  MI355X_MICROARCH.md).  ``step_tflops`` is the end-to-end figure: BASELINE.md's algorithmic FLOPs per image x
+  images/s.
+* ``cpu_baseline``: the CPU oracle (PyTorch-CPU fp32 restatement of the reference step, kind "port") timed on
+  this box's host cores on a bounded sample (one full iteration at the same 512x512 shape, batch 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# algorithmic FLOPs per image of the reference's as-written schedule (conv + linear, 2*MAC)
+ALGORITHMIC_GFLOP_PER_IMAGE = {512: 1188.7 + 135.6, 224: 227.5 + 26.0}
+
+
+def parse():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=3)
+    parser.add_argument('--warmup', type=int, default=1)
+    parser.add_argument('--image-size', type=int, default=512)
+    parser.add_argument('--batch-per-gpu', type=int, default=16)
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-roofline', action='store_true')
+    parser.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    parser.add_argument('--shape-report', default=None, help='write the per-shape contraction timing table here')
+    parser.add_argument('--reference-schedule', action='store_true',
+                        help='replay the reference forward/backward order instead of sharing forwards')
+    return parser.parse_args()
+
+
+def build_experiment(args, dp):
+    import srgan_amd  # noqa: F401
+    from srgan_amd.settings import Settings
+    from srgan_amd.crowd.srgan import CrowdExperiment
+    from srgan_amd.utility import SummaryWriter, seed_all
+    settings = Settings()                                   # run.py:57-68 crowd hyper-parameters
+    settings.batch_size = args.batch_per_gpu * (dp.world_size if dp else 1)
+    settings.image_patch_size = settings.label_patch_size = args.image_size
+    settings.matching_loss_multiplier, settings.contrasting_loss_multiplier = 1e3, 1e2
+    settings.gradient_penalty_multiplier, settings.map_multiplier = 1e2, 1e-3
+    settings.learning_rate = 1e-4
+    settings.reference_schedule = args.reference_schedule
+    experiment = CrowdExperiment(settings)
+    experiment.dp = dp
+    seed_all(0)
+    experiment.dataset_setup()
+    experiment.model_setup()
+    experiment.gpu_mode()
+    experiment.prepare_optimizers()
+    experiment.train_mode()
+    experiment.dnn_summary_writer = SummaryWriter(summary_period=10 ** 9)    # no host syncs inside timed steps
+    experiment.gan_summary_writer = SummaryWriter(summary_period=10 ** 9)
+    if dp is not None and dp.world_size > 1:
+        for module in (experiment.D, experiment.DNN, experiment.G):
+            dp.broadcast_parameters(module._srgan_arena)
+    return experiment
+
+
+def one_step(experiment, labeled, unlabeled, step):
+    x, heads, knn = next(labeled)
+    u = next(unlabeled)[0]
+    experiment.dnn_training_step(x, (heads, knn), step + 1)      # step + 1 with a huge summary period: no host sync
+    experiment.gan_training_step(x, (heads, knn), u, step + 1)
+
+
+def usable_cores():
+    """Host cores this process may actually use: the CPU affinity mask capped by the cgroup CPU quota (the GPU
+    box exposes 256 logical CPUs under a 16-CPU quota; oversubscribing it stalls the oracle for hours)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(image_size, limit_seconds=420):
+    """Runs ``cpu_baseline_child`` in a child process under a hard time limit (it never touches the GPU)."""
+    import subprocess
+    command = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--image-size', str(image_size)]
+    try:
+        output = subprocess.run(command, capture_output=True, text=True, timeout=limit_seconds).stdout
+        return json.loads(output.strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, ValueError, IndexError) as error:
+        return {'value': None, 'unit': 'images/s', 'cores': usable_cores(), 'kind': 'port',
+                'sample': f'not measured: {type(error).__name__} (limit {limit_seconds} s)'}
+
+
+def cpu_baseline_child(image_size):
+    """The oracle's full iteration on the host cores, one timed step at batch 1 of the same image shape."""
+    from types import SimpleNamespace
+    from oracle import functional as OF, models as OM
+    from oracle.experiment import OracleExperiment
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    batch = 1
+    settings = SimpleNamespace(batch_size=batch, learning_rate=1e-4, weight_decay=0, labeled_loss_multiplier=1.0,
+                               matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
+                               srgan_loss_multiplier=1.0, gradient_penalty_multiplier=1e2, mean_offset=0,
+                               labeled_loss_order=2, generator_training_step_period=1, normalize_feature_norm=False,
+                               contrasting_distance_function=OF.abs_plus_one_sqrt_mean_neg,
+                               matching_distance_function=OF.abs_mean, map_multiplier=1e-3)
+    OF.seed_all(0)
+    G = OM.DCGANGenerator(image_size=image_size)
+    D, DNN = OM.KnnDenseNetCat(image_size=image_size), OM.KnnDenseNetCat(image_size=image_size)
+    oracle = OracleExperiment(settings, D, DNN, G,
+                              labeled_loss_function=lambda p, y, order: OF.crowd_labeled_loss(p, y, order, 1e-3))
+    generator = torch.Generator().manual_seed(0)
+    x = torch.rand(batch, 3, image_size, image_size, generator=generator) * 2 - 1
+    u = torch.rand(batch, 3, image_size, image_size, generator=generator) * 2 - 1
+    heads = (torch.rand(batch, image_size, image_size, generator=generator) < 0.002).float()
+    knn = torch.rand(batch, image_size, image_size, generator=generator)
+    start = time.perf_counter()
+    oracle.dnn_training_step(x, (heads, knn))
+    oracle.gan_training_step(x, (heads, knn), u, 0)
+    elapsed = time.perf_counter() - start
+    return {'value': batch / elapsed, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 full iteration (dnn_training_step + gan_training_step) of the PyTorch-CPU fp32 oracle, '
+                      f'crowd {image_size}x{image_size}, batch {batch}, {elapsed:.1f} s'}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline_child(args.image_size)))
+        return
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if args.gpus != 1:
+            raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dp = None
+    if world > 1:
+        import srgan_amd  # noqa: F401
+        from srgan_amd.parallel import DataParallel
+        dp = DataParallel.from_environment('nccl')
+    rank = dp.rank if dp else 0
+    experiment = build_experiment(args, dp)
+    labeled = experiment.infinite_iter(experiment.train_dataset_loader)
+    unlabeled = experiment.infinite_iter(experiment.unlabeled_dataset_loader)
+
+    def fence():
+        if dp is not None:
+            dp.barrier()
+        torch.cuda.synchronize()
+
+    for step in range(args.warmup):
+        one_step(experiment, labeled, unlabeled, step)
+    fence()
+    start = time.perf_counter()
+    for step in range(args.steps):
+        one_step(experiment, labeled, unlabeled, args.warmup + step)
+    fence()
+    elapsed = time.perf_counter() - start
+    if dp is not None:
+        elapsed = dp.all_reduce_max_float(elapsed)
+    global_batch = experiment.settings.batch_size
+    images_per_second = global_batch * args.steps / elapsed
+
+    result = {
+        'metric': 'SRGAN train images/sec (G+D step)', 'value': images_per_second, 'unit': 'images/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'crowd SRGAN (KnnDenseNetCat D/DNN + DCGenerator) {args.image_size}x{args.image_size}, '
+                               f'batch {args.batch_per_gpu}/GPU, dnn_training_step + gan_training_step per step',
+                   'global_batch': global_batch, 'image_size': args.image_size,
+                   'schedule': 'reference' if args.reference_schedule else 'shared-forwards',
+                   'parallelism': f'dp{world}', 'random_init_weights': True},
+    }
+    gflop = ALGORITHMIC_GFLOP_PER_IMAGE.get(args.image_size)
+    if gflop:
+        result['step_tflops'] = images_per_second * gflop / 1e3
+        result['step_frac_of_fp32_mfma_peak'] = result['step_tflops'] / (FP32_MFMA_PEAK_TFLOPS * world)
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        import ctypes
+        from srgan_amd import _lib
+        lib = _lib.library()
+        lib.srgan_profile_begin()
+        one_step(experiment, labeled, unlabeled, args.warmup + args.steps)
+        kernel_ms, flops, mfma_flops, launches = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(lib.srgan_profile_end(ctypes.byref(kernel_ms), ctypes.byref(flops), ctypes.byref(mfma_flops),
+                                         ctypes.byref(launches)), 'srgan_profile_end')
+        torch.cuda.synchronize()
+        if args.shape_report:
+            size = lib.srgan_profile_report(None, 0)
+            text = ctypes.create_string_buffer(size)
+            lib.srgan_profile_report(text, size)
+            with open(args.shape_report, 'w') as handle:
+                handle.write(text.value.decode())
+        achieved = flops.value / (kernel_ms.value * 1e-3) / 1e12 if kernel_ms.value > 0 else 0.0
+        result['roofline'] = {
+            'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+            'kernel': 'srgan::gg_mfma_kernel<*> (all conv / linear passes of one step)',
+            'launches': launches.value, 'kernel_ms_per_step': kernel_ms.value,
+            'logical_gflop_per_step': flops.value / 1e9, 'mfma_share_of_flops': mfma_flops.value / max(flops.value, 1.0),
+            'avg_launch_us': 1e3 * kernel_ms.value / max(launches.value, 1),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args.image_size)
+    if rank == 0:
+        print(json.dumps(result))
+    if dp is not None:
+        dp.barrier()
+
+
+if __name__ == '__main__':
+    main()

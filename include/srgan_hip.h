@@ -130,6 +130,16 @@ int srgan_crowd_map_l1_bwd(const float* maps, const float* target, const float* 
 int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int32_t step, void* stream);
 
+/* ---- measurement ---------------------------------------------------------------------------------------------
+ * Between begin and end every contraction launch (conv / gemm passes) is bracketed by a pair of HIP events on
+ * its launch stream; end() synchronises and returns the summed kernel time, the summed logical 2*M*N*K, the
+ * part of it executed by the MFMA kernel, and the launch count (bench.py's roofline leg). */
+int srgan_profile_begin(void);
+int srgan_profile_end(double* kernel_ms, double* flops, double* mfma_flops, int64_t* launches);
+/* Per-shape text report of the last profiled region ("M N K kind bm bn split akf bkf count ms" per line);
+ * returns the bytes needed (tuning aid). */
+int64_t srgan_profile_report(char* buffer, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

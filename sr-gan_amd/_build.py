@@ -45,5 +45,8 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as pool:
         objects = list(pool.map(compile_one, _sources()))
+    # The library NEEDs libamdhip64.so.7 -- the SONAME of the HIP runtime PyTorch-ROCm bundles.  _lib.library()
+    # imports torch first, so the loader binds us to that already-loaded runtime (one runtime per process: it
+    # owns the allocations and streams we are handed).
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objects + ['-o', LIBRARY])
     return LIBRARY

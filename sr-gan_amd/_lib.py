@@ -40,6 +40,10 @@ SIGNATURES = {
     'srgan_gp_interpolate': ([vp, vp, vp, vp, i32, i64, vp], ctypes.c_int),
     'srgan_crowd_map_l1_fwd': ([vp, vp, vp, i32, i32, i64, vp], ctypes.c_int),
     'srgan_crowd_map_l1_bwd': ([vp, vp, vp, vp, i32, i32, i64, vp], ctypes.c_int),
+    'srgan_profile_begin': ([], ctypes.c_int),
+    'srgan_profile_end': ([ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
+    'srgan_profile_report': ([ctypes.c_char_p, ctypes.c_int64], ctypes.c_int64),
     'srgan_adam_step': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp], ctypes.c_int),
 }
 
@@ -58,6 +62,7 @@ def library():
         if not os.path.exists(LIBRARY):
             raise HipLibraryError(f'{LIBRARY} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                                   '(there is no CPU fallback)')
+        import torch  # noqa: F401  -- first: loads PyTorch-ROCm's HIP runtime (SONAME libamdhip64.so.7) that we bind to
         lib = ctypes.CDLL(LIBRARY)
         for name, (argtypes, restype) in SIGNATURES.items():
             function = getattr(lib, name)      # AttributeError if the ABI lost a symbol

@@ -14,6 +14,8 @@
 #include "conv_plan.h"
 #include <stdarg.h>
 #include <string.h>
+#include <map>
+#include <string>
 
 namespace srgan {
 
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void gg_mfma_kernel(const GatherGemm p) {
   }
 }
 
-// Direct form for very skinny outputs (M <= 4: single-channel map heads, RGB generator output, count
+// Direct form for very skinny outputs (M <= 2: single-channel map heads, count
 // layers): one thread per C element, lanes along columns, A broadcast.  HBM/L2-bound, no matrix core.
 __global__ __launch_bounds__(256) void gg_direct_kernel(const GatherGemm p) {
   const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
@@ -209,7 +211,9 @@ struct GGConfig { int kind; int bm, bn; int tiles; };   // kind 0 direct, 1 mfma
 
 static GGConfig choose_config(const GatherGemm& p, int force) {
   GGConfig c;
-  if ((p.M <= 4 && force != 2) || force == 1) {
+  // M <= 2 (single-channel map heads, count layers): the direct form; from 3 rows up (RGB image gradients, generator
+  // output) the MFMA tile wins even at 3/32 row utilisation because the direct form is VALU/latency bound.
+  if ((p.M <= 2 && force != 2) || force == 1) {
     c.kind = 0; c.bm = 1; c.bn = 256;
     c.tiles = p.M * ((p.N + 255) / 256);
     return c;
@@ -255,7 +259,45 @@ bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
   return p.split_k > 1;
 }
 
+// ---- optional live timing of every contraction launch with HIP events on the launch stream -------------------
+// (bench.py: roofline.achieved = sum of logical 2*M*N*K over launches / sum of their event-timed durations)
+struct ProfileRecord { int32_t M, N, K, kind, bm, bn, split, akf, bkf; };
+struct ProfileState {
+  bool enabled = false;
+  std::vector<hipEvent_t> events;     // pairs: start, stop
+  std::vector<ProfileRecord> records; // one per pair
+  size_t used = 0;
+  double flops = 0.0;
+  double mfma_flops = 0.0;
+  int64_t launches = 0;
+};
+static ProfileState g_profile;
+
+static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStream_t stream);
+
 int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
+  if (!g_profile.enabled || p.M <= 0 || p.N <= 0) return gg_launch_unprofiled(p, c, stream);
+  if (g_profile.used + 2 > g_profile.events.size()) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t e;
+      SRGAN_HIP(hipEventCreate(&e));
+      g_profile.events.push_back(e);
+    }
+  }
+  hipEvent_t start = g_profile.events[g_profile.used], stop = g_profile.events[g_profile.used + 1];
+  SRGAN_HIP(hipEventRecord(start, stream));
+  const int status = gg_launch_unprofiled(p, c, stream);
+  SRGAN_HIP(hipEventRecord(stop, stream));
+  g_profile.used += 2;
+  g_profile.records.push_back(ProfileRecord{p.M, p.N, p.K, c.kind, c.bm, c.bn, p.split_k, p.a_kfast, p.b_kfast});
+  const double f = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  g_profile.flops += f;
+  if (c.kind == 1) g_profile.mfma_flops += f;
+  g_profile.launches += 1;
+  return status;
+}
+
+static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return SRGAN_OK;
   if (c.kind == 0) {
     dim3 grid((p.N + 255) / 256, p.M, p.split_k);
@@ -349,6 +391,63 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
   std::vector<GatherGemm> plans{plan_conv_bwd_weight(g, x, gy, gw)};
   return gg_run_group(plans, gw, (int64_t)g.K * g.C * g.R * g.S, accumulate, force_kernel, (hipStream_t)stream);
+}
+
+int srgan_profile_begin(void) {
+  g_profile.enabled = true;
+  g_profile.used = 0;
+  g_profile.records.clear();
+  g_profile.flops = 0.0;
+  g_profile.mfma_flops = 0.0;
+  g_profile.launches = 0;
+  return SRGAN_OK;
+}
+
+int srgan_profile_end(double* kernel_ms, double* flops, double* mfma_flops, int64_t* launches) {
+  g_profile.enabled = false;
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < g_profile.used; i += 2) {
+    SRGAN_HIP(hipEventSynchronize(g_profile.events[i + 1]));
+    float ms = 0.f;
+    SRGAN_HIP(hipEventElapsedTime(&ms, g_profile.events[i], g_profile.events[i + 1]));
+    total += ms;
+  }
+  if (kernel_ms) *kernel_ms = total;
+  if (flops) *flops = g_profile.flops;
+  if (mfma_flops) *mfma_flops = g_profile.mfma_flops;
+  if (launches) *launches = g_profile.launches;
+  return SRGAN_OK;
+}
+
+// Per-shape breakdown of the last profiled region as text lines "M N K kind bm bn split akf bkf count ms"
+// (tuning aid; call after srgan_profile_end).  Returns the number of bytes needed.
+int64_t srgan_profile_report(char* buffer, int64_t capacity) {
+  struct Key { int32_t v[9]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
+  struct Acc { int64_t count = 0; double ms = 0.0; };
+  std::map<Key, Acc> table;
+  for (size_t i = 0; i < g_profile.records.size(); ++i) {
+    const ProfileRecord& r = g_profile.records[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_profile.events[2 * i], g_profile.events[2 * i + 1]) != hipSuccess) continue;
+    Key k{{r.M, r.N, r.K, r.kind, r.bm, r.bn, r.split, r.akf, r.bkf}};
+    Acc& a = table[k];
+    a.count += 1;
+    a.ms += ms;
+  }
+  std::string out;
+  char line[160];
+  for (const auto& kv : table) {
+    const int32_t* v = kv.first.v;
+    snprintf(line, sizeof(line), "%d %d %d %d %d %d %d %d %d %lld %.4f\n", v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7],
+             v[8], (long long)kv.second.count, kv.second.ms);
+    out += line;
+  }
+  if (buffer && capacity > 0) {
+    const size_t n = out.size() < (size_t)capacity - 1 ? out.size() : (size_t)capacity - 1;
+    memcpy(buffer, out.data(), n);
+    buffer[n] = 0;
+  }
+  return (int64_t)out.size() + 1;
 }
 
 int srgan_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,

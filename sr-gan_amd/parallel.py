@@ -83,6 +83,12 @@ class DataParallel:
         dist.all_reduce(holder, op=dist.ReduceOp.SUM, group=self.group)
         return float(holder.item())
 
+    def all_reduce_max_float(self, value):
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        holder = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(holder, op=dist.ReduceOp.MAX, group=self.group)
+        return float(holder.item())
+
     def all_reduce_sum_var(self, var):
         """Tape version: forward all-reduce of a (small) var, identity backward."""
         from .tape import Var, Node, grad_enabled

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r'\b(srgan_[a-z0-9_]+)\s*\(', header))
     declared.discard('srgan_conv_desc')
     assert len(declared) >= 20
-    lib = ctypes.CDLL(_lib.LIBRARY)
+    lib = _lib.library()
     for name in sorted(declared):
         assert hasattr(lib, name), f'{name} is declared in srgan_hip.h but not exported'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)

@@ -1,0 +1,111 @@
+"""World-size-2 ``gloo`` test of the data-parallel algorithm (sr-gan_amd/parallel.py) on the CPU.
+
+The product's DataParallel context (feature-sum all-reduce in the forward pass, gradient-arena all-reduce,
+sharding helpers) is exercised with the CPU oracle as the compute engine (the HIP engine needs a GPU; the
+algorithm and the collectives are engine-independent).  Two ranks, each with half of the global batch, must
+reproduce the single-process step on the whole batch: losses, every gradient and the post-Adam weights."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import load_golden, golden_state, make_settings
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _build(g, dp, network):
+    from oracle import models as OM
+    from oracle.experiment import OracleExperiment
+    if network == 'mlp':
+        settings = make_settings(batch_size=int(g['batch_size']))
+        D, DNN, G = OM.CoefficientMLP(10), OM.CoefficientMLP(10), OM.CoefficientGenerator(10)
+    else:
+        settings = make_settings(batch_size=4, matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
+                                 gradient_penalty_multiplier=1e2)
+        D, DNN = OM.DCGANDiscriminator(32, 8), OM.DCGANDiscriminator(32, 8)
+        G = OM.DCGANGenerator(image_size=32, conv_dim=8)
+    for module, prefix in ((D, 'init/D'), (DNN, 'init/DNN'), (G, 'init/G')):
+        module.load_state_dict(golden_state(g, prefix))
+    return OracleExperiment(settings, D, DNN, G, dp=dp)
+
+
+def _run(experiment, g, shard):
+    from oracle.experiment import Draws
+    x, y, u = (shard(torch.from_numpy(g[f's0/{k}'])) for k in ('x', 'y', 'u'))
+    draws = Draws(*(shard(torch.from_numpy(g[f's0/{k}'])) for k in ('z_d', 'z_g', 'alpha')))
+    experiment.dnn_training_step(x, y)
+    result = experiment.gan_training_step(x, y, u, 0, draws)
+    tensors = {f'D/{k}': v.detach().clone() for k, v in experiment.D.state_dict().items()}
+    tensors.update({f'G/{k}': v.detach().clone() for k, v in experiment.G.state_dict().items()})
+    tensors.update({f'DNN/{k}': v.detach().clone() for k, v in experiment.DNN.state_dict().items()})
+    # per-rank D gradients captured before the all-reduce: their sum over ranks is the global gradient
+    tensors.update({f'Dgrad/{k}': v.detach().clone() for k, v in experiment.d_grads.items()})
+    return result, tensors
+
+
+def _worker(rank, world_size, port, golden_name, network, queue):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    torch.set_num_threads(2)
+    import srgan_amd  # noqa: F401
+    from srgan_amd.parallel import DataParallel
+    dp = DataParallel.from_environment('gloo')
+    g = load_golden(golden_name)
+    experiment = _build(g, dp, network)
+    result, tensors = _run(experiment, g, dp.shard)
+    # the oracle's batch means are already global (all-reduced in the forward pass); only the logged mean of the
+    # per-example gradient norms is local
+    result['gradient_norm_mean'] = dp.all_reduce_sum_float(result['gradient_norm_mean']) / world_size
+    queue.put((rank, result, {k: v.numpy() for k, v in tensors.items()}))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('golden_name,network', [('g3b_coefficient_srgan_gp_active', 'mlp'), ('g5_tiny_dcgan', 'dcgan')])
+def test_two_ranks_equal_one_rank_on_the_global_batch(golden_name, network):
+    g = load_golden(golden_name)
+    torch.set_num_threads(4)
+    reference_result, reference_tensors = _run(_build(g, None, network), g, lambda t: t)
+    context = mp.get_context('spawn')
+    queue = context.Queue()
+    port = _free_port()
+    workers = [context.Process(target=_worker, args=(rank, 2, port, golden_name, network, queue)) for rank in range(2)]
+    for worker in workers:
+        worker.start()
+    outputs = [queue.get(timeout=300) for _ in workers]
+    for worker in workers:
+        worker.join(timeout=60)
+        assert worker.exitcode == 0
+    for rank, result, tensors in outputs:
+        for key, value in reference_result.items():
+            assert abs(result[key] - value) <= 1e-4 * max(abs(value), 1e-6), (rank, key, result[key], value)
+        for key, value in reference_tensors.items():
+            scale = max(float(value.abs().max()), 1e-12)
+            actual = tensors[key]
+            if key.startswith('Dgrad/'):
+                actual = outputs[0][2][key] + outputs[1][2][key]
+            error = float(np.abs(actual - value.numpy()).max()) / scale
+            limit = 2e-3 if key.startswith(('D/', 'G/', 'DNN/')) and 'bias' in key else 1e-4
+            assert error <= limit, (rank, key, error)
+    # both ranks hold identical weights after the synchronised update
+    for key in outputs[0][2]:
+        if not key.startswith('Dgrad/'):
+            np.testing.assert_array_equal(outputs[0][2][key], outputs[1][2][key])
+
+
+def test_shard_and_batch_bookkeeping():
+    import srgan_amd  # noqa: F401
+    from srgan_amd.parallel import DataParallel
+    dp = DataParallel.__new__(DataParallel)
+    dp.group, dp.rank, dp.world_size = None, 1, 4
+    assert dp.global_batch(16) == 64 and dp.local_batch(128) == 32
+    assert dp.shard(torch.arange(8)).tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        dp.local_batch(30)
