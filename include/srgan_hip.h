@@ -87,6 +87,17 @@ int srgan_fill(float* y, int64_t n, float value, void* stream);
 int srgan_chan_affine(const float* x, const float* mean, const float* scale_a, const float* scale_b, const float* shift,
                       float* y, int32_t N, int32_t C, int64_t HW, void* stream);
 
+/* As srgan_chan_affine, then optionally y = max(y, 0) (relu != 0) and y = 0 where mask[n,c,i] <= 0 (mask may be
+ * NULL): frozen batch-norm + ReLU forward in one pass, and its input gradient g * [y > 0] * gamma / sigma
+ * (reference crowd/models.py:338-339,342-343,367-368,1073-1074,1149-1150). */
+int srgan_chan_affine_act(const float* x, const float* mean, const float* scale_a, const float* scale_b,
+                          const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C, int64_t HW,
+                          void* stream);
+/* Both parameter gradients of a frozen batch-norm (optionally followed by ReLU, mask = its output) in one pass into
+ * one [2, C] buffer: out[c] = inv_std[c] * sum g*[mask>0]*(x - mean[c]) (gamma), out[C + c] = sum g*[mask>0] (beta). */
+int srgan_bn_param_grads(const float* g, const float* x, const float* mask, const float* mean, const float* inv_std,
+                         float* g_gamma_beta, int32_t N, int32_t C, int64_t HW, void* stream);
+
 /* out[c] (=,+=) scale[c] * sum_{n,i} a[n,c,i] * ((b ? b[n,c,i] : 1) - mean[c])  (b, mean, scale optional).
  * Bias / batch-norm parameter gradients; with N = 1, C = batch it is the per-example dot product over C*H*W of
  * the gradient penalty (reference srgan.py:371,381); with HW = 1 the batch sum behind feature means

@@ -37,7 +37,9 @@ class _DenseLayer(nn.Sequential):
             raise NotImplementedError('drop_rate > 0 is never used on the hot path (crowd/models.py:1063)')
 
     def forward(self, x):
-        return F.cat_channels([x, super().forward(x)])
+        # BN + ReLU are one fused kernel each (same arithmetic as running norm1, relu1, ... in sequence)
+        bottleneck = self.conv1(self.norm1(x, relu=True))
+        return F.cat_channels([x, self.conv2(self.norm2(bottleneck, relu=True))])
 
 
 class _DenseBlock(nn.Sequential):
@@ -56,6 +58,9 @@ class _Transition(nn.Sequential):
         self.add_module('conv', nn.Conv2d(num_input_features, num_output_features, kernel_size=1, stride=1,
                                           bias=False))
         self.add_module('pool', nn.AvgPool2d(kernel_size=2, stride=2))
+
+    def forward(self, x):
+        return self.pool(self.conv(self.norm(x, relu=True)))
 
 
 class MapModule(nn.Module):
@@ -142,12 +147,13 @@ class KnnDenseNetCat(nn.Module):
 
     def forward(self, x):
         batch_size = x.shape[0]
-        out = self.conv_layer1(x)
+        stem = self.conv_layer1
+        out = stem.pool0(stem.norm0(stem.conv0(x), relu=True))
         t1_out = self.transition_layers.transition1(self.dense_blocks.denseblock1(out))
         t2_out = self.transition_layers.transition2(self.dense_blocks.denseblock2(t1_out))
         t3_out = self.transition_layers.transition3(self.dense_blocks.denseblock3(t2_out))
         db4_out = self.dense_blocks.denseblock4(t3_out)
-        n5_relu_out = F.relu(self.norm5(db4_out))
+        n5_relu_out = self.norm5(db4_out, relu=True)
         final_pool = F.avg_pool2d(n5_relu_out, kernel_size=self.final_pool_size, stride=1)
         final_count_features = F.leaky_relu(self.final_count_feature_layer(final_pool))
         final_count = self.count_layer(final_count_features)

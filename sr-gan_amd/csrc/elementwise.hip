@@ -107,11 +107,15 @@ __device__ __forceinline__ void chan_coefficients(const float* mean, const float
   b = (shift ? shift[c] : 0.f) - (mean ? mean[c] * a : 0.f);
 }
 
+// RELU: y = max(y, 0) (fused frozen-batch-norm + ReLU forward).  mask: y = 0 where mask <= 0 (fused backward of the
+// same pair: dL/dx = dL/dy * [y > 0] * scale).
+template <bool RELU>
 __global__ __launch_bounds__(256) void chan_affine_rows_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ scale_a,
                                                                const float* __restrict__ scale_b,
-                                                               const float* __restrict__ shift, float* __restrict__ y,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mask, float* __restrict__ y,
                                                                int C, int64_t HW, int segs, int64_t total_blocks) {
   for (int64_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
     const int64_t row = blk / segs;
@@ -121,22 +125,32 @@ __global__ __launch_bounds__(256) void chan_affine_rows_kernel(const float* __re
     chan_coefficients(mean, scale_a, scale_b, shift, c, a, b);
     const int64_t base = row * HW, beg = (int64_t)seg * AFF_SEG;
     const int64_t end = beg + AFF_SEG < HW ? beg + AFF_SEG : HW;
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) y[base + i] = (x ? x[base + i] : 1.f) * a + b;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+      float v = (x ? x[base + i] : 1.f) * a + b;
+      if (RELU) v = fmaxf(v, 0.f);
+      if (mask) v = mask[base + i] > 0.f ? v : 0.f;
+      y[base + i] = v;
+    }
   }
 }
 
+template <bool RELU>
 __global__ __launch_bounds__(256) void chan_affine_flat_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ scale_a,
                                                                const float* __restrict__ scale_b,
-                                                               const float* __restrict__ shift, float* __restrict__ y,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mask, float* __restrict__ y,
                                                                int C, int HW, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const int c = (int)((i / HW) % C);
     float a, b;
     chan_coefficients(mean, scale_a, scale_b, shift, c, a, b);
-    y[i] = (x ? x[i] : 1.f) * a + b;
+    float v = (x ? x[i] : 1.f) * a + b;
+    if (RELU) v = fmaxf(v, 0.f);
+    if (mask) v = mask[i] > 0.f ? v : 0.f;
+    y[i] = v;
   }
 }
 
@@ -229,22 +243,38 @@ int srgan_fill(float* y, int64_t n, float value, void* stream) {
   return launch_unary<U_AFFINE>(y, y, n, 0.f, value, (hipStream_t)stream);
 }
 
-int srgan_chan_affine(const float* x, const float* mean, const float* scale_a, const float* scale_b, const float* shift,
-                      float* y, int32_t N, int32_t C, int64_t HW, void* stream) {
-  SRGAN_REQUIRE(y && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_affine arguments");
+static int chan_affine_launch(const float* x, const float* mean, const float* scale_a, const float* scale_b,
+                              const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C,
+                              int64_t HW, hipStream_t s) {
   const int64_t n = (int64_t)N * C * HW;
-  hipStream_t s = (hipStream_t)stream;
   if (HW >= 256) {
     const int segs = (int)((HW + AFF_SEG - 1) / AFF_SEG);
     const int64_t blocks = (int64_t)N * C * segs;
     const unsigned grid = (unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16);
-    hipLaunchKernelGGL(chan_affine_rows_kernel, dim3(grid), dim3(256), 0, s, x, mean, scale_a, scale_b, shift, y, C, HW, segs,
-                       blocks);
+    if (relu) hipLaunchKernelGGL(chan_affine_rows_kernel<true>, dim3(grid), dim3(256), 0, s, x, mean, scale_a, scale_b,
+                                 shift, mask, y, C, HW, segs, blocks);
+    else hipLaunchKernelGGL(chan_affine_rows_kernel<false>, dim3(grid), dim3(256), 0, s, x, mean, scale_a, scale_b, shift,
+                            mask, y, C, HW, segs, blocks);
   } else {
-    hipLaunchKernelGGL(chan_affine_flat_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, mean, scale_a, scale_b, shift,
-                       y, C, (int)HW, n);
+    if (relu) hipLaunchKernelGGL(chan_affine_flat_kernel<true>, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, mean,
+                                 scale_a, scale_b, shift, mask, y, C, (int)HW, n);
+    else hipLaunchKernelGGL(chan_affine_flat_kernel<false>, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, mean, scale_a,
+                            scale_b, shift, mask, y, C, (int)HW, n);
   }
   return launch_status();
+}
+
+int srgan_chan_affine(const float* x, const float* mean, const float* scale_a, const float* scale_b, const float* shift,
+                      float* y, int32_t N, int32_t C, int64_t HW, void* stream) {
+  SRGAN_REQUIRE(y && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_affine arguments");
+  return chan_affine_launch(x, mean, scale_a, scale_b, shift, nullptr, 0, y, N, C, HW, (hipStream_t)stream);
+}
+
+int srgan_chan_affine_act(const float* x, const float* mean, const float* scale_a, const float* scale_b,
+                          const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C, int64_t HW,
+                          void* stream) {
+  SRGAN_REQUIRE(y && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_affine_act arguments");
+  return chan_affine_launch(x, mean, scale_a, scale_b, shift, mask, relu, y, N, C, HW, (hipStream_t)stream);
 }
 
 int srgan_copy_channels(const float* src, int32_t src_channels, int32_t src_first, float* dst, int32_t dst_channels,

@@ -22,13 +22,14 @@ namespace srgan {
 
 // Division of a non-negative 31-bit integer by a constant (round-up magic number form).
 struct FastDiv {
-  uint32_t d, mul, shr;
+  uint32_t d, mul, shr, add_mask;   // q = (umulhi(n, mul) + (n & add_mask)) >> shr  (branch-free, d == 1 included)
 };
 
 inline FastDiv make_fastdiv(uint32_t d) {
   FastDiv f;
   f.d = d ? d : 1u;
-  if (f.d == 1u) { f.mul = 0u; f.shr = 0u; return f; }
+  f.add_mask = 0u;
+  if (f.d == 1u) { f.mul = 0u; f.shr = 0u; f.add_mask = 0xFFFFFFFFu; return f; }
   uint32_t log2d = 0;
   while ((1ull << log2d) < f.d) ++log2d;           // ceil(log2 d)
   const uint32_t p = 31u + log2d;
@@ -46,7 +47,7 @@ GG_HD uint32_t fd_umulhi(uint32_t a, uint32_t b) {
 }
 
 GG_HD uint32_t fd_div(uint32_t n, const FastDiv& f) {
-  return f.d == 1u ? n : (fd_umulhi(n, f.mul) >> f.shr);
+  return (fd_umulhi(n, f.mul) + (n & f.add_mask)) >> f.shr;
 }
 
 // idx -> (c, a, b) with idx = (c * A + a) * B + b; then affine offset / coordinate maps.

@@ -14,6 +14,7 @@
 #include "conv_plan.h"
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include <map>
 #include <string>
 
@@ -32,11 +33,16 @@ const char* last_error() { return g_error; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GG_BK = 16;
+constexpr int GG_BK = 32;   // K-slice alignment of split-K chunks (the largest per-config BK)
+
+// BK is 16 for the 128x128 and 32x256 tiles (keeps VGPR + AGPR <= 256: two workgroups per CU so that one's staging
+// overlaps the other's MFMAs) and 32 for the smaller tiles (half the barriers per FLOP).
+template <int BM, int BN>
+struct TileBK { static constexpr int value = (BM * BN >= 128 * 128 || BN >= 256) ? 16 : 32; };
 
 template <int BM, int BN, int WGM, bool AKF, bool BKF>
-__global__ __launch_bounds__(256) void gg_mfma_kernel(const GatherGemm p) {
-  constexpr int BK = GG_BK;
+__global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
+  constexpr int BK = TileBK<BM, BN>::value;
   constexpr int WGN = 4 / WGM;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -76,41 +82,56 @@ __global__ __launch_bounds__(256) void gg_mfma_kernel(const GatherGemm p) {
   for (int e = 0; e < (BKF ? EB : 1); ++e) b_n[e] = decode(p.bn, n0 + b_nl[e]);
 
   float ra[EA], rb[EB];
+  // With m/n-fast staging every lane of a wavefront works on the same k (tile rows are >= 64 wide), so the k-side
+  // decode (two constant divisions + affine maps) is hoisted to the scalar unit via readfirstlane; the vector
+  // unit only adds the per-lane half and tests the halo.
+  constexpr bool A_UNIFORM_K = !AKF && BM >= 64;
+  constexpr bool B_UNIFORM_K = !BKF && BN >= 64;
+  // Loads are unconditional (the offset of an out-of-range element is clamped to 0, its value to 0.f afterwards):
+  // straight-line code lets the compiler keep all of a slice's loads in flight together.
   auto fetch = [&](int k0) {
     if (AKF) {
       const int k = k0 + a_kk[0];
       const Side sk = decode(p.ak, k);
-      const bool kok = sk.valid && k < kend;
+      const bool kok = sk.valid & (k < kend);
 #pragma unroll
-      for (int e = 0; e < EA; ++e) ra[e] = (kok && a_m[e].valid) ? p.A[a_m[e].off + sk.off] : 0.f;
+      for (int e = 0; e < EA; ++e) {
+        const bool ok = kok & a_m[e].valid;
+        const float v = p.A[ok ? a_m[e].off + sk.off : 0u];
+        ra[e] = ok ? v : 0.f;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < EA; ++e) {
-        const int k = k0 + a_kk[e];
+        const int k = k0 + (A_UNIFORM_K ? __builtin_amdgcn_readfirstlane(a_kk[e]) : a_kk[e]);
         const Side sk = decode(p.ak, k);
-        ra[e] = (sk.valid && k < kend && a_m[0].valid) ? p.A[a_m[0].off + sk.off] : 0.f;
+        const bool ok = sk.valid & (k < kend) & a_m[0].valid;
+        const float v = p.A[ok ? a_m[0].off + sk.off : 0u];
+        ra[e] = ok ? v : 0.f;
       }
     }
     if (BKF) {
       const int k = k0 + b_kk[0];
       const Side sk = decode(p.bk, k);
-      const bool kok = sk.valid && k < kend;
+      const bool kok = sk.valid & (k < kend);
 #pragma unroll
       for (int e = 0; e < EB; ++e) {
         const Side sn = b_n[e];
-        const bool ok = kok && sn.valid && (uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim &&
-                        (uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim;
-        rb[e] = ok ? p.B[sk.off + sn.off] : 0.f;
+        const bool ok = kok & sn.valid & ((uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim) &
+                        ((uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim);
+        const float v = p.B[ok ? sk.off + sn.off : 0u];
+        rb[e] = ok ? v : 0.f;
       }
     } else {
       const Side sn = b_n[0];
 #pragma unroll
       for (int e = 0; e < EB; ++e) {
-        const int k = k0 + b_kk[e];
+        const int k = k0 + (B_UNIFORM_K ? __builtin_amdgcn_readfirstlane(b_kk[e]) : b_kk[e]);
         const Side sk = decode(p.bk, k);
-        const bool ok = sk.valid && k < kend && sn.valid && (uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim &&
-                        (uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim;
-        rb[e] = ok ? p.B[sk.off + sn.off] : 0.f;
+        const bool ok = sk.valid & (k < kend) & sn.valid & ((uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim) &
+                        ((uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim);
+        const float v = p.B[ok ? sk.off + sn.off : 0u];
+        rb[e] = ok ? v : 0.f;
       }
     }
   };
@@ -219,20 +240,28 @@ static GGConfig choose_config(const GatherGemm& p, int force) {
     return c;
   }
   c.kind = 1;
-  c.bm = p.M > 64 ? 128 : (p.M > 32 ? 64 : 32);
-  const int big = c.bm == 32 ? 256 : 128, small = c.bm == 32 ? 128 : 64;
-  const int tm = (p.M + c.bm - 1) / c.bm;
-  const int tiles_big = tm * ((p.N + big - 1) / big);
-  c.bn = tiles_big >= 512 ? big : small;
-  c.tiles = tm * ((p.N + c.bn - 1) / c.bn);
+  // Largest tile that still yields >= target workgroups (4 per CU: staging of one hides under the MFMAs of the
+  // others); otherwise the smallest tile of the class, topped up by split-K in choose_split.
+  static const int target = getenv("SRGAN_TILE_TARGET") ? atoi(getenv("SRGAN_TILE_TARGET")) : 1024;
+  static const int candidates[3][3][2] = {{{128, 128}, {128, 64}, {64, 64}},     // M > 64
+                                          {{64, 128}, {64, 64}, {64, 64}},        // 32 < M <= 64
+                                          {{32, 256}, {32, 128}, {32, 128}}};     // M <= 32
+  const int cls = p.M > 64 ? 0 : (p.M > 32 ? 1 : 2);
+  for (int i = 0; i < 3; ++i) {
+    c.bm = candidates[cls][i][0];
+    c.bn = candidates[cls][i][1];
+    c.tiles = ((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+    if (c.tiles >= target) break;
+  }
   return c;
 }
 
 static void choose_split(GatherGemm& p, const GGConfig& c, bool allow_split) {
   p.split_k = 1;
   p.k_per_split = p.K > 0 ? ((p.K + GG_BK - 1) / GG_BK) * GG_BK : GG_BK;
-  if (!allow_split || p.K < 128 || c.tiles >= 256) return;
-  const int want = (512 + c.tiles - 1) / c.tiles;
+  static const int target = getenv("SRGAN_TILE_TARGET") ? atoi(getenv("SRGAN_TILE_TARGET")) : 1024;
+  if (!allow_split || p.K < 128 || c.tiles * 4 >= target * 3) return;
+  const int want = (target + c.tiles - 1) / c.tiles;
   const int max_split = p.K / 64;
   int split = want < max_split ? want : max_split;
   if (split <= 1) return;

@@ -277,6 +277,43 @@ def chan_affine(x, mean=None, scale_a=None, scale_b=None, shift=None, dims=None,
     return _out(data, (x, scale_a, scale_b, shift), backward, 'chan_affine')
 
 
+def batch_norm_eval(x, mean, inv_std, gamma, beta, relu=False):
+    """Frozen batch-norm (running statistics) optionally fused with the ReLU that follows it:
+    y = [relu]((x - mean) * inv_std * gamma + beta) in ONE pass.  Its backward is two fused passes (input gradient;
+    both parameter gradients) when only first-order gradients are needed, and is composed of differentiable
+    primitives when the backward itself is being recorded (gradient penalty)."""
+    n, c, hw = _dims_nchw(x.shape)
+    data = _empty(x.shape, x.data)
+    _call('srgan_chan_affine_act', _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma), _ptr(beta), None, 1 if relu else 0,
+          data.data_ptr(), n, c, hw, _stream())
+    out = _out(data, (x, gamma, beta), None, 'batch_norm_eval')
+    if out.node is None:
+        return out
+
+    def backward(g, needs):
+        if grad_enabled():
+            gm = mask_mul(g, out, 0.0) if relu else g
+            gx = chan_affine(gm, None, inv_std, gamma, None) if needs[0] else None
+            ggamma = chan_reduce(gm, x, mean, inv_std) if needs[1] else None
+            gbeta = chan_reduce(gm) if needs[2] else None
+            return gx, ggamma, gbeta
+        gx = ggamma = gbeta = None
+        mask = data.data_ptr() if relu else None
+        if needs[0]:
+            gx_data = _empty(x.shape, x.data)
+            _call('srgan_chan_affine_act', _ptr(g), None, _ptr(inv_std), _ptr(gamma), None, mask, 0, gx_data.data_ptr(),
+                  n, c, hw, _stream())
+            gx = Var(gx_data)
+        if needs[1] or needs[2]:
+            both = _empty((2, c), x.data)
+            _call('srgan_bn_param_grads', _ptr(g), _ptr(x), mask, _ptr(mean), _ptr(inv_std), both.data_ptr(), n, c, hw,
+                  _stream())
+            ggamma, gbeta = Var(both[0]), Var(both[1])
+        return gx, ggamma, gbeta
+    out.node.backward = backward
+    return out
+
+
 def chan_reduce(a, b=None, mean=None, scale=None, dims=None, like=None):
     """out[c] = scale[c] * sum_{n,i} a[n,c,i] * ((b or 1) - mean[c]) -> shape of ``like`` (default [C])."""
     if dims is None:

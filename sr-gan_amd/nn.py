@@ -56,9 +56,9 @@ class BatchNorm2d(nn.BatchNorm2d):
             self._inv_std_cache = cached
         return cached[1], cached[2]
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
         inv_std, mean = self._inverse_std()
-        return F.chan_affine(x, mean, inv_std, P(self.weight), P(self.bias))
+        return F.batch_norm_eval(x, mean, inv_std, P(self.weight), P(self.bias), relu=relu)
 
 
 class ReLU(nn.Module):
