@@ -98,6 +98,18 @@ int srgan_chan_affine_act(const float* x, const float* mean, const float* scale_
 int srgan_bn_param_grads(const float* g, const float* x, const float* mask, const float* mean, const float* inv_std,
                          float* g_gamma_beta, int32_t N, int32_t C, int64_t HW, void* stream);
 
+/* The same on channel-slice views: image n of x / mask / y starts at n * its batch stride (0 = dense), and
+ * accumulate != 0 adds into y.  Used by the concat-free dense block: batch-norm reads a slice of the block
+ * buffer; its input gradient is accumulated into a slice of the block's gradient buffer. */
+int srgan_chan_affine_act_strided(const float* x, const float* mean, const float* scale_a, const float* scale_b,
+                                  const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C,
+                                  int64_t HW, int64_t x_batch_stride, int64_t mask_batch_stride, int64_t y_batch_stride,
+                                  int accumulate, void* stream);
+/* srgan_bn_param_grads, ADDED (fp32 atomics) into separate gamma / beta gradient buffers; x may be a view. */
+int srgan_bn_param_grads_accumulate(const float* g, const float* x, const float* mask, const float* mean,
+                                    const float* inv_std, float* g_gamma, float* g_beta, int32_t N, int32_t C,
+                                    int64_t HW, int64_t x_batch_stride, void* stream);
+
 /* out[c] (=,+=) scale[c] * sum_{n,i} a[n,c,i] * ((b ? b[n,c,i] : 1) - mean[c])  (b, mean, scale optional).
  * Bias / batch-norm parameter gradients; with N = 1, C = batch it is the per-example dot product over C*H*W of
  * the gradient penalty (reference srgan.py:371,381); with HW = 1 the batch sum behind feature means

@@ -10,6 +10,7 @@ from torch import nn as torch_nn
 
 from .. import functional as F
 from .. import nn
+from .. import fused
 from ..age.models import Generator as _DCGANGenerator
 
 
@@ -48,6 +49,14 @@ class _DenseBlock(nn.Sequential):
         for i in range(num_layers):
             self.add_module('denselayer%d' % (i + 1),
                             _DenseLayer(num_input_features + i * growth_rate, growth_rate, bn_size, drop_rate))
+
+    def forward(self, x):
+        """First-order passes run the whole block as one concat-free node (fused.py); passes that will be
+        differentiated twice (gradient penalty) use the layer-by-layer primitive ops."""
+        from ..tape import higher_order_enabled
+        if higher_order_enabled() or not fused.ENABLED:
+            return super().forward(x)
+        return fused.dense_block(x, list(self.children()))
 
 
 class _Transition(nn.Sequential):

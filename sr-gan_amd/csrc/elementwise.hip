@@ -116,20 +116,25 @@ __global__ __launch_bounds__(256) void chan_affine_rows_kernel(const float* __re
                                                                const float* __restrict__ scale_b,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ mask, float* __restrict__ y,
-                                                               int C, int64_t HW, int segs, int64_t total_blocks) {
+                                                               int C, int64_t HW, int segs, int64_t total_blocks,
+                                                               int64_t x_bs, int64_t mask_bs, int64_t y_bs,
+                                                               int accumulate) {
+  // x / mask / y may be channel-slice views of wider buffers: image n starts at n * (its batch stride).
   for (int64_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
     const int64_t row = blk / segs;
     const int seg = (int)(blk - row * segs);
-    const int c = (int)(row % C);
+    const int64_t n = row / C;
+    const int c = (int)(row - n * C);
     float a, b;
     chan_coefficients(mean, scale_a, scale_b, shift, c, a, b);
-    const int64_t base = row * HW, beg = (int64_t)seg * AFF_SEG;
+    const int64_t xb = n * x_bs + (int64_t)c * HW, mb = n * mask_bs + (int64_t)c * HW, yb = n * y_bs + (int64_t)c * HW;
+    const int64_t beg = (int64_t)seg * AFF_SEG;
     const int64_t end = beg + AFF_SEG < HW ? beg + AFF_SEG : HW;
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-      float v = (x ? x[base + i] : 1.f) * a + b;
+      float v = (x ? x[xb + i] : 1.f) * a + b;
       if (RELU) v = fmaxf(v, 0.f);
-      if (mask) v = mask[base + i] > 0.f ? v : 0.f;
-      y[base + i] = v;
+      if (mask) v = mask[mb + i] > 0.f ? v : 0.f;
+      y[yb + i] = accumulate ? y[yb + i] + v : v;
     }
   }
 }
@@ -141,16 +146,19 @@ __global__ __launch_bounds__(256) void chan_affine_flat_kernel(const float* __re
                                                                const float* __restrict__ scale_b,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ mask, float* __restrict__ y,
-                                                               int C, int HW, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
+                                                               int C, int HW, int64_t n, int64_t x_bs, int64_t mask_bs,
+                                                               int64_t y_bs, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * 256, image = (int64_t)C * HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int c = (int)((i / HW) % C);
+    const int64_t img = i / image, within = i - img * image;
+    const int c = (int)(within / HW);
     float a, b;
     chan_coefficients(mean, scale_a, scale_b, shift, c, a, b);
-    float v = (x ? x[i] : 1.f) * a + b;
+    float v = (x ? x[img * x_bs + within] : 1.f) * a + b;
     if (RELU) v = fmaxf(v, 0.f);
-    if (mask) v = mask[i] > 0.f ? v : 0.f;
-    y[i] = v;
+    if (mask) v = mask[img * mask_bs + within] > 0.f ? v : 0.f;
+    float* dst = y + img * y_bs + within;
+    *dst = accumulate ? *dst + v : v;
   }
 }
 
@@ -245,21 +253,25 @@ int srgan_fill(float* y, int64_t n, float value, void* stream) {
 
 static int chan_affine_launch(const float* x, const float* mean, const float* scale_a, const float* scale_b,
                               const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C,
-                              int64_t HW, hipStream_t s) {
-  const int64_t n = (int64_t)N * C * HW;
+                              int64_t HW, hipStream_t s, int64_t x_bs = 0, int64_t mask_bs = 0, int64_t y_bs = 0,
+                              int accumulate = 0) {
+  const int64_t n = (int64_t)N * C * HW, dense = (int64_t)C * HW;
+  if (x_bs == 0) x_bs = dense;
+  if (mask_bs == 0) mask_bs = dense;
+  if (y_bs == 0) y_bs = dense;
   if (HW >= 256) {
     const int segs = (int)((HW + AFF_SEG - 1) / AFF_SEG);
     const int64_t blocks = (int64_t)N * C * segs;
     const unsigned grid = (unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16);
     if (relu) hipLaunchKernelGGL(chan_affine_rows_kernel<true>, dim3(grid), dim3(256), 0, s, x, mean, scale_a, scale_b,
-                                 shift, mask, y, C, HW, segs, blocks);
+                                 shift, mask, y, C, HW, segs, blocks, x_bs, mask_bs, y_bs, accumulate);
     else hipLaunchKernelGGL(chan_affine_rows_kernel<false>, dim3(grid), dim3(256), 0, s, x, mean, scale_a, scale_b, shift,
-                            mask, y, C, HW, segs, blocks);
+                            mask, y, C, HW, segs, blocks, x_bs, mask_bs, y_bs, accumulate);
   } else {
     if (relu) hipLaunchKernelGGL(chan_affine_flat_kernel<true>, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, mean,
-                                 scale_a, scale_b, shift, mask, y, C, (int)HW, n);
+                                 scale_a, scale_b, shift, mask, y, C, (int)HW, n, x_bs, mask_bs, y_bs, accumulate);
     else hipLaunchKernelGGL(chan_affine_flat_kernel<false>, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, mean, scale_a,
-                            scale_b, shift, mask, y, C, (int)HW, n);
+                            scale_b, shift, mask, y, C, (int)HW, n, x_bs, mask_bs, y_bs, accumulate);
   }
   return launch_status();
 }
@@ -275,6 +287,15 @@ int srgan_chan_affine_act(const float* x, const float* mean, const float* scale_
                           void* stream) {
   SRGAN_REQUIRE(y && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_affine_act arguments");
   return chan_affine_launch(x, mean, scale_a, scale_b, shift, mask, relu, y, N, C, HW, (hipStream_t)stream);
+}
+
+int srgan_chan_affine_act_strided(const float* x, const float* mean, const float* scale_a, const float* scale_b,
+                                  const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C,
+                                  int64_t HW, int64_t x_batch_stride, int64_t mask_batch_stride, int64_t y_batch_stride,
+                                  int accumulate, void* stream) {
+  SRGAN_REQUIRE(y && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_affine_act_strided arguments");
+  return chan_affine_launch(x, mean, scale_a, scale_b, shift, mask, relu, y, N, C, HW, (hipStream_t)stream,
+                            x_batch_stride, mask_batch_stride, y_batch_stride, accumulate);
 }
 
 int srgan_copy_channels(const float* src, int32_t src_channels, int32_t src_first, float* dst, int32_t dst_channels,

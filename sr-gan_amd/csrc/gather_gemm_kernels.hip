@@ -392,12 +392,19 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   SRGAN_REQUIRE(x && w && y, SRGAN_EINVAL, "srgan_conv2d_fwd pointers");
   SRGAN_REQUIRE(g.y_bs == (int64_t)g.K * g.OH * g.OW || true, SRGAN_EINVAL, "");
   std::vector<GatherGemm> plans{plan_conv_fwd(g, x, w, bias, y)};
-  // A strided-batch output view cannot be memset as one block: forbid K-splitting there.
+  // A strided-batch output view (a channel slice of a wider buffer) is zeroed with a 2-D memset when the launch
+  // combines K-slices with atomics.
   const bool dense_out = g.y_bs == (int64_t)g.K * g.OH * g.OW;
   if (!dense_out) {
-    GGConfig c = choose_config(plans[0], force_kernel);
-    choose_split(plans[0], c, false);
-    plans[0].mode = GG_STORE;
+    GGConfig c;
+    const bool atomic = gg_prepare(plans[0], force_kernel, &c);
+    if (atomic) {
+      SRGAN_HIP(hipMemset2DAsync(y, (size_t)g.y_bs * sizeof(float), 0, (size_t)g.K * g.OH * g.OW * sizeof(float),
+                                 (size_t)g.N, (hipStream_t)stream));
+      plans[0].mode = GG_ATOMIC;
+    } else {
+      plans[0].mode = GG_STORE;
+    }
     return gg_launch(plans[0], c, (hipStream_t)stream);
   }
   return gg_run_group(plans, y, (int64_t)g.N * g.y_bs, 0, force_kernel, (hipStream_t)stream);

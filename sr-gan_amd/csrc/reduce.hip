@@ -83,15 +83,18 @@ __global__ __launch_bounds__(256) void bn_param_grads_rows_kernel(const float* _
                                                                   const float* __restrict__ mask,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ inv_std,
-                                                                  float* __restrict__ out, int C, int64_t HW) {
+                                                                  float* __restrict__ out_gamma,
+                                                                  float* __restrict__ out_beta, int C, int64_t HW,
+                                                                  int64_t x_bs) {
   __shared__ float scratch[4];
   const int c = blockIdx.x, n = blockIdx.y;
-  const int64_t base = ((int64_t)n * C + c) * HW;
+  const int64_t base = ((int64_t)n * C + c) * HW;          // g and mask are dense
+  const int64_t xbase = (int64_t)n * x_bs + (int64_t)c * HW;  // x may be a channel-slice view
   const float mu = mean ? mean[c] : 0.f;
   float acc = 0.f, plain = 0.f;
-  if ((base & 3) == 0 && (HW & 3) == 0) {
+  if (((base | xbase) & 3) == 0 && (HW & 3) == 0) {
     const float4* g4 = reinterpret_cast<const float4*>(g + base);
-    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* x4 = reinterpret_cast<const float4*>(x + xbase);
     const float4* m4 = mask ? reinterpret_cast<const float4*>(mask + base) : nullptr;
     for (int64_t i = threadIdx.x; i < (HW >> 2); i += 256) {
       float4 gv = g4[i];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void bn_param_grads_rows_kernel(const float* _
     for (int64_t i = threadIdx.x; i < HW; i += 256) {
       float gv = g[base + i];
       if (mask) gv = mask[base + i] > 0.f ? gv : 0.f;
-      acc += gv * (x[base + i] - mu);
+      acc += gv * (x[xbase + i] - mu);
       plain += gv;
     }
   }
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256) void bn_param_grads_rows_kernel(const float* _
   __syncthreads();
   const float total_plain = block_sum_256(plain, scratch);
   if (threadIdx.x == 0) {
-    unsafeAtomicAdd(out + c, total * (inv_std ? inv_std[c] : 1.f));
-    unsafeAtomicAdd(out + C + c, total_plain);
+    unsafeAtomicAdd(out_gamma + c, total * (inv_std ? inv_std[c] : 1.f));
+    unsafeAtomicAdd(out_beta + c, total_plain);
   }
 }
 
@@ -233,8 +236,18 @@ int srgan_bn_param_grads(const float* g, const float* x, const float* mask, cons
     return launch_status();
   }
   SRGAN_HIP(hipMemsetAsync(g_gamma_beta, 0, (size_t)2 * C * sizeof(float), s));
-  hipLaunchKernelGGL(bn_param_grads_rows_kernel, dim3(C, N), dim3(256), 0, s, g, x, mask, mean, inv_std, g_gamma_beta, C,
-                     HW);
+  hipLaunchKernelGGL(bn_param_grads_rows_kernel, dim3(C, N), dim3(256), 0, s, g, x, mask, mean, inv_std, g_gamma_beta,
+                     g_gamma_beta + C, C, HW, (int64_t)C * HW);
+  return launch_status();
+}
+
+int srgan_bn_param_grads_accumulate(const float* g, const float* x, const float* mask, const float* mean,
+                                    const float* inv_std, float* g_gamma, float* g_beta, int32_t N, int32_t C,
+                                    int64_t HW, int64_t x_batch_stride, void* stream) {
+  SRGAN_REQUIRE(g && x && g_gamma && g_beta && N > 0 && C > 0 && HW > 0 && N <= 65535, SRGAN_EINVAL,
+                "srgan_bn_param_grads_accumulate arguments");
+  hipLaunchKernelGGL(bn_param_grads_rows_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mask, mean, inv_std,
+                     g_gamma, g_beta, C, HW, x_batch_stride ? x_batch_stride : (int64_t)C * HW);
   return launch_status();
 }
 

@@ -28,7 +28,7 @@ from . import functional as F
 from . import nn
 from .optim import Adam
 from .settings import Settings
-from .tape import Var, backward, no_grad
+from .tape import Var, backward, no_grad, higher_order
 from .utility import SummaryWriter, MixtureModel, current_device, make_directory_name_unique, seed_all
 
 
@@ -445,7 +445,8 @@ class Experiment(ABC):
 
     def interpolate_loss_calculation(self, interpolates):
         """Per-example feature norm of the interpolates (reference srgan.py:377-381)."""
-        _ = self.D(interpolates)
+        with higher_order():      # this forward is differentiated twice
+            _ = self.D(interpolates)
         self.interpolates_features = self.D.features
         return F.row_norm(F.flatten2d(self.interpolates_features))
 

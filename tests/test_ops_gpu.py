@@ -296,3 +296,46 @@ def test_adam_matches_torch(F):
     state = optimizer.state_dict()
     assert set(state['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
     close(state['state'][0]['exp_avg'], reference_optimizer.state_dict()['state'][0]['exp_avg'], 1e-6, 'exp_avg')
+
+
+@gpu
+def test_fused_dense_block_matches_primitive_path(F):
+    """The concat-free one-node dense block (fused.py) against the layer-by-layer primitive ops: forward,
+    input gradient and every parameter gradient, with trainable and with frozen parameters."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd import fused, nn
+    from srgan_amd.crowd.models import _DenseBlock
+    from srgan_amd.tape import backward
+    torch.manual_seed(3)
+    block = _DenseBlock(num_layers=3, num_input_features=8, bn_size=2, growth_rate=4)
+    gen = torch.Generator().manual_seed(4)
+    for m in block.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.weight.shape, generator=gen) + 0.5
+            m.bias.data = torch.randn(m.bias.shape, generator=gen) * 0.2
+            m.running_mean.data = torch.randn(m.running_mean.shape, generator=gen) * 0.2
+            m.running_var.data = torch.rand(m.running_var.shape, generator=gen) + 0.5
+    arena = nn.flatten_parameters(block, torch.device('cuda', 0))
+    x_host = torch.randn(3, 8, 9, 7, generator=gen)
+    cotangent = torch.randn(3, 20, 9, 7, generator=gen)
+    results = {}
+    for enabled in (False, True):
+        fused.ENABLED = enabled
+        try:
+            arena.zero_grad()
+            x = F.leaf(dev(x_host), requires_grad=True)
+            y = block(x)
+            backward(y, grad=F.leaf(dev(cotangent)))
+            results[enabled] = (y.cpu(), x.grad.cpu(), arena.grad.detach().cpu().clone())
+        finally:
+            fused.ENABLED = True
+    for i, what in enumerate(('output', 'input gradient', 'parameter gradients')):
+        close(results[True][i], results[False][i], 1e-4, what)
+    # frozen parameters (generator update): input gradient only, the arena stays untouched
+    arena.zero_grad()
+    with nn.frozen_parameters(block):
+        x = F.leaf(dev(x_host), requires_grad=True)
+        y = block(x)
+    backward(y, grad=F.leaf(dev(cotangent)))
+    close(x.grad, results[False][1], 1e-4, 'input gradient with frozen parameters')
+    assert float(arena.grad.abs().sum()) == 0.0
