@@ -1,0 +1,261 @@
+// conv3x3.hip -- 3x3 / stride 1 / pad 1 convolution with an LDS-resident input halo tile.
+//
+// The DenseNet growth convolutions (128 -> 32, reference crowd/models.py:344-345), their data gradients
+// (32 -> 128, same kernel with flipped taps) and every VGG convolution (age/vgg.py:78) are 3x3/s1/p1.  In the
+// generic gather-GEMM each B element is gathered once per tap with its own address decode; at 32 output channels
+// that gather, not the matrix pipe, is the bottleneck.  Here a workgroup stages, per chunk of CI_T input channels,
+//   * the input patch  [CI_T][TH + 2][TW + 2]  (each input element read from HBM/L2 ONCE for all 9 taps), and
+//   * the weight slice [CI_T * 9][BM]
+// into LDS with coalesced loads whose per-thread offsets are computed once per workgroup, and the inner loop is
+// nothing but ds_read_b32 at per-lane base + compile-time immediate offsets feeding v_mfma_f32_32x32x2_f32:
+// the two k-values of one MFMA are the SAME tap of two consecutive input channels, so the lane-half (k parity)
+// contributes a constant LDS offset.  MFMA rows = output channels, columns = 32 consecutive pixels of one image row
+// (lanes -> pixels: conflict-free LDS reads, 128-byte global stores).  The next chunk's global loads are issued
+// before the current chunk's 9 * CI_T / 2 * MI * NI MFMAs, so HBM latency hides under the matrix pipe.
+// Roofline: fp32 MFMA (157.3 TF/s); algorithmic work 2 * 9 * CI * CO FLOP per output pixel.
+#include "common.h"
+#include <stdlib.h>
+
+namespace srgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Conv3Params {
+  const float* in;      // [N, CI, H, W] (batch stride in_bs)
+  const float* w;       // element (o, i, kh, kw) at w[w_base + o*w_so + i*w_si + kh*w_skh + kw*w_skw]
+  float* out;           // [N, CO, H, W] (batch stride out_bs)
+  const float* bias;    // per output channel, optional
+  int32_t N, CI, CO, H, W;
+  int64_t in_bs, out_bs;
+  int32_t w_so, w_si, w_skh, w_skw, w_base;
+  int32_t tiles_x, tiles_y, tiles_m;
+  int32_t ci_per_split;
+  int32_t mode;         // 0 store, 1 accumulate, 2 atomic
+  int32_t debug;        // tuning experiments only (SRGAN_CONV3_DEBUG): 1 = no re-staging, 2 = no MFMA
+};
+
+template <int BM, int TH, int CI_T>
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
+  constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PHPW = PH * PW;
+  constexpr int MI = BM / 32, NI = TH / 4;        // each of the 4 waves owns NI image rows of 32 pixels
+  constexpr int LDW = BM + 1;
+  constexpr int PATCH = CI_T * PHPW, WTS = CI_T * 9 * BM;
+  constexpr int NP = (PATCH + 255) / 256, NW = (WTS + 255) / 256;
+  static_assert(CI_T % 2 == 0 && NI >= 1 && MI >= 1, "bad tile");
+  __shared__ float lds[PATCH + CI_T * 9 * LDW];
+  float* patch = lds;
+  float* wt = lds + PATCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  int block = blockIdx.x;
+  const int tm = block % p.tiles_m; block /= p.tiles_m;
+  const int tx = block % p.tiles_x; block /= p.tiles_x;
+  const int ty = block % p.tiles_y;
+  const int n = block / p.tiles_y;
+  const int m0 = tm * BM, y0 = ty * TH, x0 = tx * TW;
+  const int cbeg = (int)blockIdx.y * p.ci_per_split;
+  const int cend = min(p.CI, cbeg + p.ci_per_split);
+  const int HW = p.H * p.W;
+
+  // Per-thread staging offsets (relative to the chunk's first channel), computed once.
+  int poff[NP], woff[NW];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) {
+    const int flat = e * 256 + tid;
+    const int c = flat / PHPW, rem = flat - c * PHPW;
+    const int py = rem / PW, px = rem - py * PW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool ok = flat < PATCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    poff[e] = ok ? c * HW + y * p.W + x : -1;
+  }
+#pragma unroll
+  for (int e = 0; e < NW; ++e) {
+    const int flat = e * 256 + tid;
+    const int o = flat / (CI_T * 9), r = flat - o * (CI_T * 9);     // r = ci_local * 9 + tap : lanes walk r
+    const int ci = r / 9, tap = r - ci * 9;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const bool ok = flat < WTS && (m0 + o) < p.CO;
+    woff[e] = ok ? p.w_base + (m0 + o) * p.w_so + ci * p.w_si + kh * p.w_skh + kw * p.w_skw : -1;
+  }
+  const float* in_n = p.in + (int64_t)n * p.in_bs;
+
+  // Raw loads only in fetch(); validity is applied when the registers are written to LDS (any use of a loaded value
+  // before the MFMA loop would make the compiler wait for the loads there instead of overlapping them).
+  float rp[NP], rw[NW];
+  auto fetch = [&](int c0) {
+    const int room = cend - c0;                         // channels of this chunk that exist
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int flat = e * 256 + tid;
+      const bool ok = poff[e] >= 0 && flat / PHPW < room;
+      rp[e] = in_n[(int64_t)c0 * HW + (ok ? poff[e] : 0)];
+    }
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int flat = e * 256 + tid;
+      const int ci = (flat % (CI_T * 9)) / 9;
+      const bool ok = woff[e] >= 0 && ci < room;
+      rw[e] = p.w[ok ? woff[e] + c0 * p.w_si : 0];
+    }
+  };
+  auto stage = [&](int c0) {
+    const int room = cend - c0;
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int flat = e * 256 + tid;
+      const bool ok = poff[e] >= 0 && flat / PHPW < room;
+      if (flat < PATCH) patch[flat] = ok ? rp[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int flat = e * 256 + tid;
+      const int o = flat / (CI_T * 9), r = flat - o * (CI_T * 9);
+      const bool ok = woff[e] >= 0 && r / 9 < room;
+      if (flat < WTS) wt[r * LDW + o] = ok ? rw[e] : 0.f;
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // Per-lane LDS bases: the lane half selects the odd channel of a pair (constant offset), lanes 0..31 walk pixels
+  // (B) or output channels (A); everything else below is a compile-time immediate.
+  const float* a_base = wt + lhi * 9 * LDW + l31;
+  const float* b_base = patch + lhi * PHPW + (wave * NI) * PW + l31;
+
+  if (cbeg < cend) {
+    fetch(cbeg);
+    stage(cbeg);
+    __syncthreads();
+    for (int c0 = cbeg; c0 < cend; c0 += CI_T) {
+      const bool more = (c0 + CI_T < cend) && !(p.debug & 1);
+      if (more) fetch(c0 + CI_T);
+      // (the channel-pair loop is kept rolled: full unrolling makes the scheduler hoist hundreds of LDS reads and
+      // spill; the 9 taps x MI x NI MFMAs inside are plenty of straight-line work)
+#pragma unroll 1
+      for (int cp = 0; cp < ((p.debug & 2) ? 0 : CI_T / 2); ++cp) {
+        const float* a_cp = a_base + cp * (2 * 9 * LDW);
+        const float* b_cp = b_base + cp * (2 * PHPW);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int kh = tap / 3, kw = tap % 3;
+          float a[MI], b[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = a_cp[tap * LDW + mi * 32];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) b[ni] = b_cp[(ni + kh) * PW + kw];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (more) {
+        stage(c0 + CI_T);
+        __syncthreads();
+      }
+    }
+  }
+
+  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+  const int x = x0 + l31;
+  float* out_n = p.out + (int64_t)n * p.out_bs;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int y = y0 + wave * NI + ni;
+    if (y >= p.H || x >= p.W) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (o >= p.CO) continue;
+        float v = acc[mi][ni][r];
+        if (add_bias) v += p.bias[o];
+        float* dst = out_n + (int64_t)o * HW + y * p.W + x;
+        if (p.mode == 0) *dst = v;
+        else if (p.mode == 1) *dst += v;
+        else unsafeAtomicAdd(dst, v);
+      }
+    }
+  }
+}
+
+template <int BM, int CI_T>
+static void launch_conv3(const Conv3Params& p, int th, dim3 grid, hipStream_t stream) {
+  if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T>), grid, dim3(256), 0, stream, p);
+}
+
+// Declared in gather_gemm_kernels.hip: records a launch for the bench's live event timing.
+int profile_bracket_begin(hipStream_t stream);
+int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+
+bool conv3x3_enabled() {
+  static const bool disabled = getenv("SRGAN_NO_CONV3") != nullptr;
+  return !disabled;
+}
+
+// out = conv3x3(in, w) (+ bias), generic weight strides (forward and flipped-tap data gradient share the kernel).
+// The caller guarantees dense-or-strided NCHW, 3x3 / stride 1 / pad 1.  `accumulate` adds into out.
+int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
+                int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
+                int32_t W, int accumulate, hipStream_t stream) {
+  Conv3Params p;
+  p.in = in; p.w = w; p.out = out; p.bias = bias;
+  p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
+  p.in_bs = in_bs; p.out_bs = out_bs;
+  p.debug = getenv("SRGAN_CONV3_DEBUG") ? atoi(getenv("SRGAN_CONV3_DEBUG")) : 0;
+  p.w_so = w_so; p.w_si = w_si; p.w_skh = w_skh; p.w_skw = w_skw; p.w_base = w_base;
+  p.tiles_x = (W + 31) / 32;
+  // Tile choice: the widest output-channel tile (fewest re-reads of the input patch) and the 8-row pixel tile, as
+  // long as that still gives ~2 workgroups per CU; otherwise narrower / shorter tiles; input-channel splitting (fp32
+  // atomics into a pre-zeroed output) only as the last resort and never below two chunks per workgroup.
+  int bm = CO > 64 ? 128 : (CO > 32 ? 64 : 32);
+  int th = bm == 128 ? 4 : 8;            // 128 rows always use 4 pixel rows (64 accumulator registers per lane)
+  auto count = [&](int bm_, int th_) { return (int64_t)N * ((H + th_ - 1) / th_) * p.tiles_x * ((CO + bm_ - 1) / bm_); };
+  while (count(bm, th) < 512) {
+    if (th == 8) th = 4;
+    else if (bm > 32) { bm >>= 1; th = 4; }
+    else break;
+  }
+  const int ci_t = bm == 128 ? 4 : (bm == 64 ? 8 : 16);     // keeps the staged registers + accumulators <= 256
+  p.tiles_m = (CO + bm - 1) / bm;
+  p.tiles_y = (H + th - 1) / th;
+  const int64_t blocks = count(bm, th);
+  const int chunks = (CI + ci_t - 1) / ci_t;
+  int split = 1;
+  if (blocks < 384 && chunks >= 4) {
+    split = (int)((512 + blocks - 1) / blocks);
+    if (split > chunks / 2) split = chunks / 2;
+  }
+  const int chunks_per = (chunks + split - 1) / split;
+  p.ci_per_split = chunks_per * ci_t;
+  split = (chunks + chunks_per - 1) / chunks_per;
+  SRGAN_REQUIRE(blocks < (int64_t)1 << 31 && split <= 65535, SRGAN_ERANGE, "conv3x3 grid");
+  if (split > 1) {
+    if (!accumulate)
+      SRGAN_HIP(hipMemset2DAsync(out, (size_t)out_bs * sizeof(float), 0, (size_t)CO * H * W * sizeof(float), (size_t)N,
+                                 stream));
+    p.mode = 2;
+  } else {
+    p.mode = accumulate ? 1 : 0;
+  }
+  dim3 grid((unsigned)blocks, (unsigned)split, 1);
+  profile_bracket_begin(stream);
+  if (bm == 32) launch_conv3<32, 16>(p, th, grid, stream);
+  else if (bm == 64) launch_conv3<64, 8>(p, th, grid, stream);
+  else hipLaunchKernelGGL((conv3x3_lds_kernel<128, 4, 4>), grid, dim3(256), 0, stream, p);
+  const int status = launch_status();
+  profile_bracket_end(stream, CO, (int64_t)N * H * W, (int64_t)CI * 9, 2, bm, th * 32, split);
+  return status;
+}
+
+}  // namespace srgan

@@ -44,11 +44,22 @@ inline void choose_staging(GatherGemm& p) {
   p.b_kfast = innermost_run(p.bk) > innermost_run(p.bn) ? 1 : 0;
 }
 
+inline bool pointwise(const ConvGeom& g) {
+  return g.R == 1 && g.S == 1 && g.ph == 0 && g.pw == 0 && g.sh == 1 && g.sw == 1;
+}
+
+// A 1x1 / stride-1 / unpadded convolution never leaves the image: drop the halo test (enables 16-byte staging).
+inline void strip_halo(GatherGemm& p) {
+  p.hlim = 1; p.wlim = 1;
+  p.bk.h_a = p.bk.h0 = p.bk.w_b = p.bk.w0 = 0;
+  p.bn.h_a = p.bn.h0 = p.bn.w_b = p.bn.w0 = 0;
+}
+
 inline GatherGemm gg_blank() {
   GatherGemm p;
   p.A = nullptr; p.B = nullptr; p.C = nullptr; p.bias = nullptr; p.bias_cols = 0;
   p.hlim = 1; p.wlim = 1; p.M = p.N = p.K = 0; p.a_kfast = 1; p.b_kfast = 0;
-  p.mode = GG_STORE; p.split_k = 1; p.k_per_split = 0;
+  p.mode = GG_STORE; p.split_k = 1; p.k_per_split = 0; p.debug = 0;
   p.am = p.ak = p.bk = p.bn = p.cm = p.cn = dec_linear(0, 0);
   return p;
 }
@@ -79,6 +90,7 @@ inline GatherGemm plan_conv_fwd(const ConvGeom& g, const float* x, const float* 
   p.hlim = g.H; p.wlim = g.W;
   p.C = y; p.cm = dec_linear(g.K, OHW); p.cn = dec_3d(g.N, g.OH, g.OW, (int32_t)g.y_bs, g.OW, 1, 0, 0, 0, 0, 0);
   p.bias = bias;
+  if (pointwise(g)) strip_halo(p);
   choose_staging(p);
   return p;
 }
@@ -142,6 +154,7 @@ inline std::vector<GatherGemm> plan_conv_bwd_data(const ConvGeom& g, const float
       p.cn = dec_3d(g.N, nqh, nqw, (int32_t)g.x_bs, g.sh * g.W, g.sw,
                     (g.sh * qh0 + ch - g.ph) * g.W + (g.sw * qw0 + cw - g.pw), 0, 0, 0, 0);
       p.bias = bias;
+      if (pointwise(g)) strip_halo(p);
       choose_staging(p);
       plans.push_back(p);
     }
@@ -161,6 +174,7 @@ inline GatherGemm plan_conv_bwd_weight(const ConvGeom& g, const float* x, const 
   p.bn = dec_3d(g.C, g.R, g.S, g.H * g.W, g.W, 1, 0, 1, 0, 1, 0);
   p.hlim = g.H; p.wlim = g.W;
   p.C = gw; p.cm = dec_linear(g.K, CRS); p.cn = dec_linear(CRS, 1);
+  if (pointwise(g)) strip_halo(p);
   choose_staging(p);
   return p;
 }

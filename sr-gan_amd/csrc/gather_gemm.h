@@ -111,6 +111,7 @@ struct GatherGemm {
   int32_t a_kfast, b_kfast;                              // staging order: lanes along k (1) or along m/n (0)
   int32_t mode;                                          // StoreMode
   int32_t split_k, k_per_split;                          // filled by the launcher
+  int32_t debug;                                         // tuning experiments (SRGAN_GG_DEBUG): 1 no re-staging, 2 no MFMA
 };
 
 // Reference semantics of one output element (used by the CPU emulator and by the direct kernel).

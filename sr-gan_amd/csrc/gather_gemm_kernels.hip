@@ -37,19 +37,26 @@ constexpr int GG_BK = 32;   // K-slice alignment of split-K chunks (the largest 
 
 // BK is 16 for the 128x128 and 32x256 tiles (keeps VGPR + AGPR <= 256: two workgroups per CU so that one's staging
 // overlaps the other's MFMAs) and 32 for the smaller tiles (half the barriers per FLOP).
-template <int BM, int BN>
+// The 16-byte staged (VEC) variants need few registers, so they take K-slices of 32: twice the MFMA work per barrier
+// and per load round trip.
+template <int BM, int BN, bool VEC>
 struct TileBK { static constexpr int value = (BM * BN >= 128 * 128 || BN >= 256) ? 16 : 32; };
 
-template <int BM, int BN, int WGM, bool AKF, bool BKF>
+// VEC: both operands are staged with 16-byte loads along their contiguous direction (groups of 4 consecutive k or
+// m/n that share one address decode): the 1x1 convolutions and linear layers, i.e. plain GEMMs on NCHW data.
+// The host (vec_eligible) guarantees that every group is 16-byte aligned and entirely valid or entirely invalid.
+template <int BM, int BN, int WGM, bool AKF, bool BKF, bool VEC>
 __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
-  constexpr int BK = TileBK<BM, BN>::value;
+  constexpr int BK = TileBK<BM, BN, VEC>::value;
   constexpr int WGN = 4 / WGM;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MI = WM / 32, NI = WN / 32;
-  constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
-  constexpr int LDA = BM + 1, LDB = BN + 1;
-  static_assert(MI >= 1 && NI >= 1 && EA >= 1 && EB >= 1, "tile too small for 4 waves");
-  __shared__ float lds[BK * LDA + BK * LDB];
+  constexpr int G = VEC ? 4 : 1;                                  // elements per staged group
+  constexpr int AG = BM * BK / G, BG = BN * BK / G;               // groups per tile
+  constexpr int EA = (AG + 255) / 256, EB = (BG + 255) / 256;     // groups per thread
+  constexpr int LDA = BM + (VEC ? 4 : 1), LDB = BN + (VEC ? 4 : 1);
+  static_assert(MI >= 1 && NI >= 1, "tile too small for 4 waves");
+  __shared__ __attribute__((aligned(16))) float lds[BK * LDA + BK * LDB];
   float* As = lds;
   float* Bs = lds + BK * LDA;
 
@@ -59,20 +66,23 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
   const int kbeg = (int)blockIdx.y * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
 
-  // Per-thread staging coordinates.  With k-fast staging consecutive lanes walk k (the operand's contiguous
-  // direction), otherwise they walk m / n.
+  // Per-thread staging coordinates (first element of each group).  With k-fast staging consecutive lanes walk k
+  // (the operand's contiguous direction), otherwise they walk m / n.
   int a_kk[EA], a_ml[EA], b_kk[EB], b_nl[EB];
+  bool a_on[EA], b_on[EB];
 #pragma unroll
   for (int e = 0; e < EA; ++e) {
     const int flat = e * 256 + tid;
-    a_kk[e] = AKF ? flat % BK : flat / BM;
-    a_ml[e] = AKF ? flat / BK : flat % BM;
+    a_on[e] = (AG % 256 == 0) || flat < AG;
+    a_kk[e] = AKF ? (flat % (BK / G)) * G : flat / (BM / (AKF ? 1 : G));
+    a_ml[e] = AKF ? flat / (BK / G) : (flat % (BM / G)) * G;
   }
 #pragma unroll
   for (int e = 0; e < EB; ++e) {
     const int flat = e * 256 + tid;
-    b_kk[e] = BKF ? flat % BK : flat / BN;
-    b_nl[e] = BKF ? flat / BK : flat % BN;
+    b_on[e] = (BG % 256 == 0) || flat < BG;
+    b_kk[e] = BKF ? (flat % (BK / G)) * G : flat / (BN / (BKF ? 1 : G));
+    b_nl[e] = BKF ? flat / (BK / G) : (flat % (BN / G)) * G;
   }
   // Loop-invariant halves of the address computation.
   Side a_m[AKF ? EA : 1], b_n[BKF ? EB : 1];
@@ -81,65 +91,78 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
 #pragma unroll
   for (int e = 0; e < (BKF ? EB : 1); ++e) b_n[e] = decode(p.bn, n0 + b_nl[e]);
 
-  float ra[EA], rb[EB];
-  // With m/n-fast staging every lane of a wavefront works on the same k (tile rows are >= 64 wide), so the k-side
-  // decode (two constant divisions + affine maps) is hoisted to the scalar unit via readfirstlane; the vector
+  float ra[EA][G], rb[EB][G];
+  // With m/n-fast scalar staging every lane of a wavefront works on the same k (tile rows are >= 64 wide), so the
+  // k-side decode (two constant divisions + affine maps) is hoisted to the scalar unit via readfirstlane; the vector
   // unit only adds the per-lane half and tests the halo.
-  constexpr bool A_UNIFORM_K = !AKF && BM >= 64;
-  constexpr bool B_UNIFORM_K = !BKF && BN >= 64;
-  // Loads are unconditional (the offset of an out-of-range element is clamped to 0, its value to 0.f afterwards):
-  // straight-line code lets the compiler keep all of a slice's loads in flight together.
-  auto fetch = [&](int k0) {
-    if (AKF) {
-      const int k = k0 + a_kk[0];
-      const Side sk = decode(p.ak, k);
-      const bool kok = sk.valid & (k < kend);
-#pragma unroll
-      for (int e = 0; e < EA; ++e) {
-        const bool ok = kok & a_m[e].valid;
-        const float v = p.A[ok ? a_m[e].off + sk.off : 0u];
-        ra[e] = ok ? v : 0.f;
-      }
+  constexpr bool A_UNIFORM_K = !VEC && !AKF && BM >= 64;
+  constexpr bool B_UNIFORM_K = !VEC && !BKF && BN >= 64;
+  // Loads are unconditional (the offset of an out-of-range element is clamped to 0) and their results are NOT touched
+  // until stage(): the validity bits travel separately and the zeroing happens at the LDS write.  Any use of a loaded
+  // value inside fetch() makes the compiler wait for the whole slice before the MFMAs it is meant to overlap with.
+  uint32_t a_ok = 0u, b_ok = 0u;
+  auto load_group = [&](const float* base, uint32_t off, bool ok, float (&dst)[G]) {
+    if (VEC) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
+      dst[0] = v.x; dst[G > 1 ? 1 : 0] = v.y; dst[G > 2 ? 2 : 0] = v.z; dst[G > 3 ? 3 : 0] = v.w;
+      if (G == 1) dst[0] = v.x;
     } else {
-#pragma unroll
-      for (int e = 0; e < EA; ++e) {
-        const int k = k0 + (A_UNIFORM_K ? __builtin_amdgcn_readfirstlane(a_kk[e]) : a_kk[e]);
-        const Side sk = decode(p.ak, k);
-        const bool ok = sk.valid & (k < kend) & a_m[0].valid;
-        const float v = p.A[ok ? a_m[0].off + sk.off : 0u];
-        ra[e] = ok ? v : 0.f;
-      }
+      dst[0] = base[ok ? off : 0u];
     }
-    if (BKF) {
-      const int k = k0 + b_kk[0];
+  };
+  auto fetch = [&](int k0) {
+    a_ok = 0u; b_ok = 0u;
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      const int k = k0 + ((A_UNIFORM_K) ? __builtin_amdgcn_readfirstlane(a_kk[e]) : a_kk[e]);
+      const Side sk = decode(p.ak, k);
+      const Side sm = a_m[AKF ? e : 0];
+      const bool ok = a_on[e] & sk.valid & (k < kend) & sm.valid;
+      a_ok |= (ok ? 1u : 0u) << e;
+      load_group(p.A, sm.off + sk.off, ok, ra[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const int k = k0 + ((B_UNIFORM_K) ? __builtin_amdgcn_readfirstlane(b_kk[e]) : b_kk[e]);
       const Side sk = decode(p.bk, k);
-      const bool kok = sk.valid & (k < kend);
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const Side sn = b_n[e];
-        const bool ok = kok & sn.valid & ((uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim) &
-                        ((uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim);
-        const float v = p.B[ok ? sk.off + sn.off : 0u];
-        rb[e] = ok ? v : 0.f;
-      }
-    } else {
-      const Side sn = b_n[0];
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const int k = k0 + (B_UNIFORM_K ? __builtin_amdgcn_readfirstlane(b_kk[e]) : b_kk[e]);
-        const Side sk = decode(p.bk, k);
-        const bool ok = sk.valid & (k < kend) & sn.valid & ((uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim) &
-                        ((uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim);
-        const float v = p.B[ok ? sk.off + sn.off : 0u];
-        rb[e] = ok ? v : 0.f;
-      }
+      const Side sn = b_n[BKF ? e : 0];
+      bool ok = b_on[e] & sk.valid & (k < kend) & sn.valid;
+      if (!VEC) ok = ok & ((uint32_t)(sk.h + sn.h) < (uint32_t)p.hlim) & ((uint32_t)(sk.w + sn.w) < (uint32_t)p.wlim);
+      b_ok |= (ok ? 1u : 0u) << e;
+      load_group(p.B, sk.off + sn.off, ok, rb[e]);
     }
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int e = 0; e < EA; ++e) As[a_kk[e] * LDA + a_ml[e]] = ra[e];
+    for (int e = 0; e < EA; ++e) {
+      if (!a_on[e]) continue;
+      const bool ok = (a_ok >> e) & 1u;
+      float v[G];
 #pragma unroll
-    for (int e = 0; e < EB; ++e) Bs[b_kk[e] * LDB + b_nl[e]] = rb[e];
+      for (int i = 0; i < G; ++i) v[i] = ok ? ra[e][i] : 0.f;
+      if (VEC && !AKF) {
+        *reinterpret_cast<float4*>(&As[a_kk[e] * LDA + a_ml[e]]) = make_float4(v[0], v[G > 1 ? 1 : 0], v[G > 2 ? 2 : 0],
+                                                                                v[G > 3 ? 3 : 0]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < G; ++i) As[(a_kk[e] + (AKF ? i : 0)) * LDA + a_ml[e] + (AKF ? 0 : i)] = v[i];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      if (!b_on[e]) continue;
+      const bool ok = (b_ok >> e) & 1u;
+      float v[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) v[i] = ok ? rb[e][i] : 0.f;
+      if (VEC && !BKF) {
+        *reinterpret_cast<float4*>(&Bs[b_kk[e] * LDB + b_nl[e]]) = make_float4(v[0], v[G > 1 ? 1 : 0], v[G > 2 ? 2 : 0],
+                                                                                v[G > 3 ? 3 : 0]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < G; ++i) Bs[(b_kk[e] + (BKF ? i : 0)) * LDB + b_nl[e] + (BKF ? 0 : i)] = v[i];
+      }
+    }
   };
 
   f32x16 acc[MI][NI];
@@ -158,10 +181,10 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
     stage();
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      const bool more = k0 + BK < kend;
+      const bool more = (k0 + BK < kend) && !(p.debug & 1);
       if (more) fetch(k0 + BK);
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
+      for (int kk = 0; kk < ((p.debug & 2) ? 0 : BK); kk += 2) {
         float a[MI], b[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) a[mi] = As[(kk + lhi) * LDA + wm0 + mi * 32 + l31];
@@ -183,20 +206,23 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
 
   // Epilogue: C/D fragment of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+  Side sn[NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const Side sn = decode(p.cn, n0 + wn0 + ni * 32 + l31);
-    if (!sn.valid) continue;
+  for (int ni = 0; ni < NI; ++ni) sn[ni] = decode(p.cn, n0 + wn0 + ni * 32 + l31);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const Side sm = decode(p.cm, i);
-        if (!sm.valid) continue;
-        float v = acc[mi][ni][r];
-        if (add_bias) v += p.bias[p.bias_cols ? sn.c : sm.c];
-        float* dst = p.C + (uint32_t)(sm.off + sn.off);
+    for (int r = 0; r < 16; ++r) {
+      const int i = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const Side sm = decode(p.cm, i);
+      if (!sm.valid) continue;
+      const float row_bias = (add_bias && !p.bias_cols) ? p.bias[sm.c] : 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (!sn[ni].valid) continue;
+        float v = acc[mi][ni][r] + row_bias;
+        if (add_bias && p.bias_cols) v += p.bias[sn[ni].c];
+        float* dst = p.C + (uint32_t)(sm.off + sn[ni].off);
         if (p.mode == GG_STORE) *dst = v;
         else if (p.mode == GG_ACCUMULATE) *dst += v;
         else unsafeAtomicAdd(dst, v);
@@ -271,17 +297,48 @@ static void choose_split(GatherGemm& p, const GGConfig& c, bool allow_split) {
   p.split_k = (p.K + per - 1) / per;
 }
 
+template <int BM, int BN, int WGM, bool VEC>
+static void launch_mfma_v(const GatherGemm& p, dim3 grid, hipStream_t stream) {
+  if (p.a_kfast && p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, true, VEC>), grid, dim3(256), 0, stream, p);
+  else if (p.a_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, false, VEC>), grid, dim3(256), 0, stream, p);
+  else if (p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, true, VEC>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, false, VEC>), grid, dim3(256), 0, stream, p);
+}
+
+// Can a Dec3 be walked in aligned groups of 4 consecutive indices with unit element stride?
+static bool dec_vec_fast(const Dec3& d) {
+  const int32_t B = (int32_t)d.div_b.d, A = (int32_t)(d.div_ab.d / d.div_b.d);
+  if (d.limit % 4 || d.off0 % 4) return false;
+  if (B > 1) return d.off_b == 1 && B % 4 == 0 && d.off_a % 4 == 0 && d.off_c % 4 == 0;
+  if (A > 1) return d.off_a == 1 && A % 4 == 0 && d.off_c % 4 == 0;
+  return d.off_c == 1;
+}
+
+static bool dec_vec_slow(const Dec3& d) {
+  return d.off_c % 4 == 0 && d.off_a % 4 == 0 && d.off_b % 4 == 0 && d.off0 % 4 == 0;
+}
+
+// Both operands 16-byte stageable (1x1 convolutions / linear layers on contiguous data, no halo).
+static bool vec_eligible(const GatherGemm& p) {
+  static const bool disabled = getenv("SRGAN_NO_VEC") != nullptr;
+  if (disabled || p.hlim != 1 || p.wlim != 1) return false;
+  if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return false;
+  const bool a = p.a_kfast ? (dec_vec_fast(p.ak) && dec_vec_slow(p.am)) : (dec_vec_fast(p.am) && dec_vec_slow(p.ak));
+  const bool b = p.b_kfast ? (dec_vec_fast(p.bk) && dec_vec_slow(p.bn)) : (dec_vec_fast(p.bn) && dec_vec_slow(p.bk));
+  return a && b && p.K % 4 == 0;
+}
+
 template <int BM, int BN, int WGM>
 static void launch_mfma(const GatherGemm& p, dim3 grid, hipStream_t stream) {
-  if (p.a_kfast && p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, true>), grid, dim3(256), 0, stream, p);
-  else if (p.a_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, false>), grid, dim3(256), 0, stream, p);
-  else if (p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, true>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, false>), grid, dim3(256), 0, stream, p);
+  if (vec_eligible(p)) launch_mfma_v<BM, BN, WGM, true>(p, grid, stream);
+  else launch_mfma_v<BM, BN, WGM, false>(p, grid, stream);
 }
 
 // Plans one launch: fills split_k / k_per_split; returns whether the launch needs a zeroed (or live) C because
 // it combines K-slices with atomics.
 bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
+  static const int debug = getenv("SRGAN_GG_DEBUG") ? atoi(getenv("SRGAN_GG_DEBUG")) : 0;
+  p.debug = debug;
   GGConfig c = choose_config(p, force);
   choose_split(p, c, true);
   if (out) *out = c;
@@ -303,6 +360,52 @@ struct ProfileState {
 static ProfileState g_profile;
 
 static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStream_t stream);
+
+// Event bracket for contraction kernels that live in other translation units (conv3x3.hip).
+int profile_bracket_begin(hipStream_t stream) {
+  if (!g_profile.enabled) return SRGAN_OK;
+  if (g_profile.used + 2 > g_profile.events.size()) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t e;
+      SRGAN_HIP(hipEventCreate(&e));
+      g_profile.events.push_back(e);
+    }
+  }
+  SRGAN_HIP(hipEventRecord(g_profile.events[g_profile.used], stream));
+  return SRGAN_OK;
+}
+
+int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split) {
+  if (!g_profile.enabled) return SRGAN_OK;
+  SRGAN_HIP(hipEventRecord(g_profile.events[g_profile.used + 1], stream));
+  g_profile.used += 2;
+  g_profile.records.push_back(ProfileRecord{(int32_t)M, (int32_t)N, (int32_t)K, kind, bm, bn, split, 0, 0});
+  const double f = 2.0 * (double)M * (double)N * (double)K;
+  g_profile.flops += f;
+  g_profile.mfma_flops += f;
+  g_profile.launches += 1;
+  return SRGAN_OK;
+}
+
+bool conv3x3_enabled();
+int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
+                int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
+                int32_t W, int accumulate, hipStream_t stream);
+
+bool pointwise_enabled();
+int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
+                  int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream);
+
+// 1x1 / stride 1 / unpadded on images whose pixel count is a multiple of 32: the register-streamed pointwise kernel.
+static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
+  return force == 0 && pointwise_enabled() && pointwise(g) && (g.H * g.W) % 32 == 0 && out_channels >= 8;
+}
+
+// 3x3 / stride 1 / pad 1 with enough width to fill half of a 32-pixel MFMA column block: the LDS-halo kernel.
+static bool use_conv3x3(const ConvGeom& g, int out_channels, int force) {
+  return force == 0 && conv3x3_enabled() && g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+         g.W >= 16 && out_channels >= 8;
+}
 
 int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
   if (!g_profile.enabled || p.M <= 0 || p.N <= 0) return gg_launch_unprofiled(p, c, stream);
@@ -391,6 +494,11 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_fwd geometry");
   SRGAN_REQUIRE(x && w && y, SRGAN_EINVAL, "srgan_conv2d_fwd pointers");
   SRGAN_REQUIRE(g.y_bs == (int64_t)g.K * g.OH * g.OW || true, SRGAN_EINVAL, "");
+  if (use_pointwise(g, g.K, force_kernel))
+    return pointwise_run(x, g.x_bs, w, g.C, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream);
+  if (use_conv3x3(g, g.K, force_kernel))
+    return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, 0,
+                       (hipStream_t)stream);
   std::vector<GatherGemm> plans{plan_conv_fwd(g, x, w, bias, y)};
   // A strided-batch output view (a channel slice of a wider buffer) is zeroed with a 2-D memset when the launch
   // combines K-slices with atomics.
@@ -416,6 +524,12 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
   SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_data geometry");
   SRGAN_REQUIRE(gy && w && gx, SRGAN_EINVAL, "srgan_conv2d_bwd_data pointers");
   SRGAN_REQUIRE(g.x_bs == (int64_t)g.C * g.H * g.W, SRGAN_EUNSUPPORTED, "srgan_conv2d_bwd_data dense gx");
+  if (use_pointwise(g, g.C, force_kernel))   // the data gradient of a 1x1 convolution is the 1x1 convolution with W^T
+    return pointwise_run(gy, g.y_bs, w, 1, g.C, bias, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
+                         (hipStream_t)stream);
+  if (use_conv3x3(g, g.C, force_kernel))     // the data gradient is the same convolution with flipped taps
+    return conv3x3_run(gy, g.y_bs, w, 8, 9, g.C * 9, -3, -1, bias, gx, g.x_bs, g.N, g.K, g.C, g.H, g.W, accumulate,
+                       (hipStream_t)stream);
   std::vector<GatherGemm> plans = plan_conv_bwd_data(g, gy, w, bias, gx);
   return gg_run_group(plans, gx, (int64_t)g.N * g.x_bs, accumulate, force_kernel, (hipStream_t)stream);
 }

@@ -1,0 +1,225 @@
+// pointwise.hip -- 1x1 / stride 1 convolution: out[n, o, p] = sum_i w(o, i) * in[n, i, p]  (+ bias[o]).
+//
+// 63 % of the DenseNet-201 FLOPs are these (bottleneck and transition convolutions, reference
+// crowd/models.py:340-341,369-370) and their data gradients.  On NCHW data it is C[CO x P] = W[CO x CI] * X[CI x P]
+// with the pixel dimension P contiguous and at most a few hundred rows of W: the arithmetic intensity sits right at
+// the fp32-MFMA / HBM ridge (43 FLOP/B at CI = 256), so the activation stream has to overlap the matrix pipe
+// completely.  Design:
+//   * B operand (activations) NEVER touches LDS: the MFMA B fragment of v_mfma_f32_32x32x2_f32 is "32 consecutive
+//     pixels of channel k (lanes 0-31) and of channel k+1 (lanes 32-63)", i.e. two 128-byte rows -- exactly one
+//     coalesced global_load_dword per lane.  Every wave owns its own pixel columns for ALL output rows of the tile, so
+//     nothing is shared between waves.  A lane's address is base + k * HW: no index decode at all.
+//   * the whole next K-slice of B (16 k-pairs) is loaded into registers before the current slice's MFMAs issue: one
+//     full slice of matrix work (4096 cycles at 4 row blocks) hides the HBM latency.
+//   * A operand (weights, tiny and shared by every workgroup) is staged through a double-buffered LDS tile
+//     [32][BM + 1]: one barrier per K-slice.
+// Roofline: fp32 MFMA 157.3 TF/s, or HBM when CI is small; algorithmic bytes 4 * (CI + CO) per pixel.
+#include "common.h"
+#include <stdlib.h>
+
+namespace srgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PointwiseParams {
+  const float* in;      // [N, CI, HW], batch stride in_bs
+  const float* w;       // element (o, i) at w[o * w_so + i * w_si]
+  float* out;           // [N, CO, HW], batch stride out_bs
+  const float* bias;
+  int32_t N, CI, CO, HW;
+  int64_t in_bs, out_bs;
+  int32_t w_so, w_si;
+  int32_t tiles_m;
+  int32_t k_per_split;
+  int32_t mode;         // 0 store, 1 accumulate, 2 atomic
+};
+
+template <int MI>
+__global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams p) {
+  constexpr int BM = MI * 32, BK = 32, KP = BK / 2, LDA = BM + 1;
+  constexpr int EA = BM * BK / 256;
+  __shared__ float lds[2 * BK * LDA];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int tm = blockIdx.x % p.tiles_m;
+  const int64_t group = (int64_t)(blockIdx.x / p.tiles_m) * 4 + wave;     // this wave's 32-pixel column group
+  const int64_t pixel0 = group * 32;
+  const int64_t total = (int64_t)p.N * p.HW;
+  const bool live = pixel0 < total;                                     // whole groups only (HW % 32 == 0)
+  const int n = live ? (int)(pixel0 / p.HW) : 0;
+  const int pix = live ? (int)(pixel0 - (int64_t)n * p.HW) + l31 : l31;
+  const int m0 = tm * BM;
+  const int kbeg = (int)blockIdx.y * p.k_per_split;
+  const int kend = min(p.CI, kbeg + p.k_per_split);
+
+  const float* b_lane = p.in + (int64_t)n * p.in_bs + pix;
+
+  // A staging coordinates: lanes walk the weight's contiguous direction.
+  const bool k_contiguous = p.w_si == 1;
+  int a_k[EA], a_m[EA];
+#pragma unroll
+  for (int e = 0; e < EA; ++e) {
+    const int flat = e * 256 + tid;
+    a_k[e] = k_contiguous ? flat % BK : flat / BM;
+    a_m[e] = k_contiguous ? flat / BK : flat % BM;
+  }
+
+  float ra[EA];
+  float b0[KP], b1[KP];
+  auto fetch_a = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      const int k = k0 + a_k[e], m = m0 + a_m[e];
+      const bool ok = k < kend && m < p.CO;
+      ra[e] = p.w[ok ? m * p.w_so + k * p.w_si : 0];
+    }
+  };
+  auto stage_a = [&](int k0, float* As) {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      const bool ok = (k0 + a_k[e]) < kend && (m0 + a_m[e]) < p.CO;
+      As[a_k[e] * LDA + a_m[e]] = ok ? ra[e] : 0.f;
+    }
+  };
+  auto fetch_b = [&](int k0, float (&dst)[KP]) {
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      int k = k0 + 2 * q + lhi;
+      k = k < kend ? k : kend - 1;          // clamped: the matching A rows are zero
+      dst[q] = b_lane[(int64_t)k * p.HW];
+    }
+  };
+
+  f32x16 acc[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+  // One K-slice: prefetch the following slice (B into `bnxt`, A into registers), run this slice's MFMAs from `bcur`
+  // and LDS buffer `buffer`, then publish the prefetched A tile into the other LDS buffer.  The two B register sets
+  // are used ping-pong by the caller (explicitly unrolled by two) so that a slice's loads are in flight during the
+  // whole previous slice of matrix work; a register copy at the end of the loop gets folded away by the compiler
+  // and with it the prefetch distance.
+  auto slice = [&](int k0, const float (&bcur)[KP], float (&bnxt)[KP], int buffer) {
+    const bool more = k0 + BK < kend;
+    const float* As = lds + buffer * (BK * LDA) + lhi * LDA + l31;
+    // Per k-pair q: (1) the A fragments of pair q + 1 are read from LDS, (2) this pair's MI MFMAs issue, (3) ONE
+    // B load and (at most) one A load of the NEXT slice are issued.  Spreading the global loads between the MFMAs
+    // keeps the in-order wave from stalling on a full memory queue in front of its matrix work (issuing a slice's 32
+    // loads back to back serialises "memory time + MFMA time").
+    float a[2][MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[0][mi] = As[mi * 32];
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      if (q + 1 < KP) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[(q + 1) & 1][mi] = As[(2 * (q + 1)) * LDA + mi * 32];
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bcur[q], acc[mi], 0, 0, 0);
+      {   // unconditional (clamped) so that the slice stays one basic block; the last slice's loads are unused
+        int k = k0 + BK + 2 * q + lhi;
+        k = k < kend ? k : kend - 1;
+        bnxt[q] = b_lane[(int64_t)k * p.HW];
+        if (q < EA) {
+          const int ka = k0 + BK + a_k[q], m = m0 + a_m[q];
+          const bool ok = ka < kend && m < p.CO;
+          ra[q] = p.w[ok ? m * p.w_so + ka * p.w_si : 0];
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, MI, 0);                 // DS reads of the next pair
+      __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);                 // this pair's MFMAs
+      if (q < EA) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // next slice's global loads
+      else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    if (more) {
+      stage_a(k0 + BK, lds + (buffer ^ 1) * (BK * LDA));      // the other buffer: nobody reads it during this slice
+      __syncthreads();
+    }
+  };
+
+  if (kbeg < kend) {
+    fetch_a(kbeg);
+    fetch_b(kbeg, b0);
+    stage_a(kbeg, lds);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+      slice(k0, b0, b1, 0);
+      if (k0 + BK < kend) slice(k0 + BK, b1, b0, 1);
+    }
+  }
+
+  if (!live) return;
+  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+  float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (o >= p.CO) continue;
+      float v = acc[mi][r];
+      if (add_bias) v += p.bias[o];
+      float* dst = out_lane + (int64_t)o * p.HW;
+      if (p.mode == 0) *dst = v;
+      else if (p.mode == 1) *dst += v;
+      else unsafeAtomicAdd(dst, v);
+    }
+  }
+}
+
+int profile_bracket_begin(hipStream_t stream);
+int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+
+bool pointwise_enabled() {
+  static const bool disabled = getenv("SRGAN_NO_POINTWISE") != nullptr;
+  return !disabled;
+}
+
+int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
+                  int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream) {
+  PointwiseParams p;
+  p.in = in; p.w = w; p.out = out; p.bias = bias;
+  p.N = N; p.CI = CI; p.CO = CO; p.HW = HW;
+  p.in_bs = in_bs; p.out_bs = out_bs; p.w_so = w_so; p.w_si = w_si;
+  const int64_t groups = (int64_t)N * HW / 32;
+  const int64_t col_blocks = (groups + 3) / 4;
+  // Tallest row tile that still yields ~4 workgroups per CU; otherwise shorter tiles, then split over input channels.
+  static const int mi_cap = getenv("SRGAN_PW_MI") ? atoi(getenv("SRGAN_PW_MI")) : 4;
+  int mi = CO > 64 ? 4 : (CO > 32 ? 2 : 1);
+  if (mi > mi_cap) mi = mi_cap;
+  while (mi > 1 && col_blocks * ((CO + mi * 32 - 1) / (mi * 32)) < 1024) mi >>= 1;
+  p.tiles_m = (CO + mi * 32 - 1) / (mi * 32);
+  const int64_t blocks = col_blocks * p.tiles_m;
+  const int slices = (CI + 31) / 32;
+  int split = 1;
+  if (blocks < 768 && slices >= 4) {
+    split = (int)((1024 + blocks - 1) / blocks);
+    if (split > slices / 2) split = slices / 2;
+    if (split < 1) split = 1;
+  }
+  const int per = (slices + split - 1) / split;
+  p.k_per_split = per * 32;
+  split = (slices + per - 1) / per;
+  SRGAN_REQUIRE(blocks < ((int64_t)1 << 31) && split <= 65535, SRGAN_ERANGE, "pointwise grid");
+  if (split > 1) {
+    if (!accumulate)
+      SRGAN_HIP(hipMemset2DAsync(out, (size_t)out_bs * sizeof(float), 0, (size_t)CO * HW * sizeof(float), (size_t)N, stream));
+    p.mode = 2;
+  } else {
+    p.mode = accumulate ? 1 : 0;
+  }
+  dim3 grid((unsigned)blocks, (unsigned)split, 1);
+  profile_bracket_begin(stream);
+  if (mi == 4) hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, stream, p);
+  else if (mi == 2) hipLaunchKernelGGL(pointwise_kernel<2>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(pointwise_kernel<1>, grid, dim3(256), 0, stream, p);
+  const int status = launch_status();
+  profile_bracket_end(stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);
+  return status;
+}
+
+}  // namespace srgan

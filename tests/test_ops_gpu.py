@@ -81,6 +81,19 @@ CONV_CASES = [
     (2, 48, 8, 8, 1, 8, 8, (8, 8), (0, 0)),          # map head in conv form (K = 1 -> direct kernel)
     (2, 32, 16, 16, 20, 16, 16, (1, 1), (0, 0)),     # "linear" conv with a long reduction
     (5, 70, 9, 9, 40, 3, 3, (1, 1), (1, 1)),         # ragged in every dimension
+    # pointwise shapes eligible for 16-byte staging (all extents multiples of 4) and near-misses
+    (2, 64, 16, 16, 96, 1, 1, (1, 1), (0, 0)),
+    (2, 160, 32, 32, 128, 1, 1, (1, 1), (0, 0)),
+    (1, 36, 8, 12, 20, 1, 1, (1, 1), (0, 0)),
+    (2, 64, 16, 18, 32, 1, 1, (1, 1), (0, 0)),
+    (3, 896, 16, 16, 448, 1, 1, (1, 1), (0, 0)),
+    # 3x3 / s1 / p1 shapes for the LDS-halo kernel (force = 0): all three channel-tile widths, ragged tiles,
+    # fewer input channels than one chunk, split over input-channel chunks
+    (2, 128, 32, 32, 32, 3, 3, (1, 1), (1, 1)),
+    (1, 3, 40, 48, 64, 3, 3, (1, 1), (1, 1)),
+    (2, 32, 16, 64, 130, 3, 3, (1, 1), (1, 1)),
+    (2, 24, 33, 35, 16, 3, 3, (1, 1), (1, 1)),
+    (16, 128, 64, 64, 32, 3, 3, (1, 1), (1, 1)),
 ]
 
 
