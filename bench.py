@@ -84,6 +84,17 @@ def one_step(experiment, labeled, unlabeled, step):
     experiment.gan_training_step(x, (heads, knn), u, step + 1)
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per contraction launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, see the note in that file); None when the file is absent.  PMC collection needs
+    rocprofv3 around the process, so it cannot be measured from inside this script."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        return json.load(open(path))['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores():
     """Host cores this process may actually use: the CPU affinity mask capped by the cgroup CPU quota (the GPU
     box exposes 256 logical CPUs under a 16-CPU quota; oversubscribing it stalls the oracle for hours)."""
@@ -215,7 +226,7 @@ def main():
         achieved = flops.value / (kernel_ms.value * 1e-3) / 1e12 if kernel_ms.value > 0 else 0.0
         result['roofline'] = {
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic_per_launch(),
             'kernel': 'srgan::gg_mfma_kernel<*> (all conv / linear passes of one step)',
             'launches': launches.value, 'kernel_ms_per_step': kernel_ms.value,
             'logical_gflop_per_step': flops.value / 1e9, 'mfma_share_of_flops': mfma_flops.value / max(flops.value, 1.0),

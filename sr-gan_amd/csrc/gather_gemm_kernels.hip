@@ -315,7 +315,9 @@ static bool dec_vec_fast(const Dec3& d) {
 }
 
 static bool dec_vec_slow(const Dec3& d) {
-  return d.off_c % 4 == 0 && d.off_a % 4 == 0 && d.off_b % 4 == 0 && d.off0 % 4 == 0;
+  const int32_t B = (int32_t)d.div_b.d, A = (int32_t)(d.div_ab.d / d.div_b.d);
+  // strides of extent-1 components are never applied
+  return d.off_c % 4 == 0 && (A == 1 || d.off_a % 4 == 0) && (B == 1 || d.off_b % 4 == 0) && d.off0 % 4 == 0;
 }
 
 // Both operands 16-byte stageable (1x1 convolutions / linear layers on contiguous data, no halo).

@@ -34,9 +34,9 @@ struct PointwiseParams {
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
 };
 
-template <int MI>
+template <int MI, int BK>
 __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams p) {
-  constexpr int BM = MI * 32, BK = 32, KP = BK / 2, LDA = BM + 1;
+  constexpr int BM = MI * 32, KP = BK / 2, LDA = BM + 1;
   constexpr int EA = BM * BK / 256;
   __shared__ float lds[2 * BK * LDA];
 
@@ -194,15 +194,15 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   while (mi > 1 && col_blocks * ((CO + mi * 32 - 1) / (mi * 32)) < 1024) mi >>= 1;
   p.tiles_m = (CO + mi * 32 - 1) / (mi * 32);
   const int64_t blocks = col_blocks * p.tiles_m;
-  const int slices = (CI + 31) / 32;
+  const int slices = (CI + 63) / 64;
   int split = 1;
-  if (blocks < 768 && slices >= 4) {
+  if (blocks < 768 && slices >= 2) {
     split = (int)((1024 + blocks - 1) / blocks);
-    if (split > slices / 2) split = slices / 2;
+    if (split > slices) split = slices;
     if (split < 1) split = 1;
   }
   const int per = (slices + split - 1) / split;
-  p.k_per_split = per * 32;
+  p.k_per_split = per * 64;
   split = (slices + per - 1) / per;
   SRGAN_REQUIRE(blocks < ((int64_t)1 << 31) && split <= 65535, SRGAN_ERANGE, "pointwise grid");
   if (split > 1) {
@@ -214,9 +214,16 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);
   profile_bracket_begin(stream);
-  if (mi == 4) hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, stream, p);
-  else if (mi == 2) hipLaunchKernelGGL(pointwise_kernel<2>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(pointwise_kernel<1>, grid, dim3(256), 0, stream, p);
+  static const int bk = getenv("SRGAN_PW_BK") ? atoi(getenv("SRGAN_PW_BK")) : 32;
+  if (bk == 64) {
+    if (mi == 4) hipLaunchKernelGGL((pointwise_kernel<4, 64>), grid, dim3(256), 0, stream, p);
+    else if (mi == 2) hipLaunchKernelGGL((pointwise_kernel<2, 64>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((pointwise_kernel<1, 64>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (mi == 4) hipLaunchKernelGGL((pointwise_kernel<4, 32>), grid, dim3(256), 0, stream, p);
+    else if (mi == 2) hipLaunchKernelGGL((pointwise_kernel<2, 32>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((pointwise_kernel<1, 32>), grid, dim3(256), 0, stream, p);
+  }
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);
   return status;
