@@ -104,7 +104,7 @@ constexpr int AFF_SEG = 256 * 4 * 4;
 __device__ __forceinline__ void chan_coefficients(const float* mean, const float* scale_a, const float* scale_b,
                                                   const float* shift, int c, float& a, float& b) {
   a = (scale_a ? scale_a[c] : 1.f) * (scale_b ? scale_b[c] : 1.f);
-  b = (shift ? shift[c] : 0.f) - (mean ? mean[c] * a : 0.f);
+  b = __fsub_rn(shift ? shift[c] : 0.f, mean ? __fmul_rn(mean[c], a) : 0.f);   // bn_act_bwd recomputes exactly this
 }
 
 // RELU: y = max(y, 0) (fused frozen-batch-norm + ReLU forward).  mask: y = 0 where mask <= 0 (fused backward of the
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void chan_affine_rows_kernel(const float* __re
     const int64_t beg = (int64_t)seg * AFF_SEG;
     const int64_t end = beg + AFF_SEG < HW ? beg + AFF_SEG : HW;
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-      float v = (x ? x[xb + i] : 1.f) * a + b;
+      float v = fmaf(x ? x[xb + i] : 1.f, a, b);
       if (RELU) v = fmaxf(v, 0.f);
       if (mask) v = mask[mb + i] > 0.f ? v : 0.f;
       y[yb + i] = accumulate ? y[yb + i] + v : v;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void chan_affine_flat_kernel(const float* __re
     const int c = (int)(within / HW);
     float a, b;
     chan_coefficients(mean, scale_a, scale_b, shift, c, a, b);
-    float v = (x ? x[img * x_bs + within] : 1.f) * a + b;
+    float v = fmaf(x ? x[img * x_bs + within] : 1.f, a, b);
     if (RELU) v = fmaxf(v, 0.f);
     if (mask) v = mask[img * mask_bs + within] > 0.f ? v : 0.f;
     float* dst = y + img * y_bs + within;

@@ -124,6 +124,67 @@ __global__ __launch_bounds__(256) void bn_param_grads_rows_kernel(const float* _
   }
 }
 
+// Whole backward of a frozen batch-norm (+ReLU) in ONE pass over (g, x): the activation mask is recomputed from x
+// with the forward's own arithmetic (fma(x, a, b) > 0), the input gradient g*[y>0]*a is written (or accumulated
+// into a channel-slice view), and both parameter gradients leave as two fp32 atomics per workgroup.  One workgroup
+// per (channel, image) row.
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ inv_std,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ gx,
+                                                              float* __restrict__ out_gamma,
+                                                              float* __restrict__ out_beta, int C, int64_t HW,
+                                                              int64_t x_bs, int64_t gx_bs, int accumulate) {
+  __shared__ float scratch[4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  const int64_t base = ((int64_t)n * C + c) * HW;             // g is dense
+  const int64_t xbase = (int64_t)n * x_bs + (int64_t)c * HW;  // x / gx may be channel-slice views
+  const int64_t obase = (int64_t)n * gx_bs + (int64_t)c * HW;
+  const float mu = mean[c];
+  const float a = inv_std[c] * gamma[c];
+  const float b = __fsub_rn(beta[c], __fmul_rn(mu, a));       // = chan_coefficients() of the forward kernel
+  float acc = 0.f, plain = 0.f;
+  if (((base | xbase | obase) & 3) == 0 && (HW & 3) == 0) {
+    const float4* g4 = reinterpret_cast<const float4*>(g + base);
+    const float4* x4 = reinterpret_cast<const float4*>(x + xbase);
+    float4* o4 = gx ? reinterpret_cast<float4*>(gx + obase) : nullptr;
+    for (int64_t i = threadIdx.x; i < (HW >> 2); i += 256) {
+      float4 gv = g4[i];
+      const float4 xv = x4[i];
+      if (RELU) {
+        gv.x = fmaf(xv.x, a, b) > 0.f ? gv.x : 0.f; gv.y = fmaf(xv.y, a, b) > 0.f ? gv.y : 0.f;
+        gv.z = fmaf(xv.z, a, b) > 0.f ? gv.z : 0.f; gv.w = fmaf(xv.w, a, b) > 0.f ? gv.w : 0.f;
+      }
+      acc += gv.x * (xv.x - mu) + gv.y * (xv.y - mu) + gv.z * (xv.z - mu) + gv.w * (xv.w - mu);
+      plain += gv.x + gv.y + gv.z + gv.w;
+      if (o4) {
+        float4 o = make_float4(gv.x * a, gv.y * a, gv.z * a, gv.w * a);
+        if (accumulate) { const float4 old = o4[i]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        o4[i] = o;
+      }
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < HW; i += 256) {
+      float gv = g[base + i];
+      const float xv = x[xbase + i];
+      if (RELU) gv = fmaf(xv, a, b) > 0.f ? gv : 0.f;
+      acc += gv * (xv - mu);
+      plain += gv;
+      if (gx) gx[obase + i] = accumulate ? gx[obase + i] + gv * a : gv * a;
+    }
+  }
+  if (out_gamma == nullptr) return;
+  const float total = block_sum_256(acc, scratch);
+  __syncthreads();
+  const float total_plain = block_sum_256(plain, scratch);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(out_gamma + c, total * inv_std[c]);
+    unsafeAtomicAdd(out_beta + c, total_plain);
+  }
+}
+
 // HW == 1: a is [N, C]; lanes along c (coalesced), loop over the rows.
 __global__ __launch_bounds__(256) void chan_reduce_cols_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                const float* __restrict__ mean,
@@ -248,6 +309,22 @@ int srgan_bn_param_grads_accumulate(const float* g, const float* x, const float*
                 "srgan_bn_param_grads_accumulate arguments");
   hipLaunchKernelGGL(bn_param_grads_rows_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mask, mean, inv_std,
                      g_gamma, g_beta, C, HW, x_batch_stride ? x_batch_stride : (int64_t)C * HW);
+  return launch_status();
+}
+
+int srgan_bn_act_bwd(const float* g, const float* x, const float* mean, const float* inv_std, const float* gamma,
+                     const float* beta, int relu, float* gx, float* g_gamma, float* g_beta, int32_t N, int32_t C,
+                     int64_t HW, int64_t x_batch_stride, int64_t gx_batch_stride, int accumulate_gx, void* stream) {
+  SRGAN_REQUIRE(g && x && mean && inv_std && gamma && beta && N > 0 && C > 0 && HW > 0 && N <= 65535, SRGAN_EINVAL,
+                "srgan_bn_act_bwd arguments");
+  SRGAN_REQUIRE((g_gamma == nullptr) == (g_beta == nullptr) && (gx || g_gamma), SRGAN_EINVAL,
+                "srgan_bn_act_bwd outputs");
+  const int64_t dense = (int64_t)C * HW;
+  const int64_t x_bs = x_batch_stride ? x_batch_stride : dense, gx_bs = gx_batch_stride ? gx_batch_stride : dense;
+  if (relu) hipLaunchKernelGGL(bn_act_bwd_rows_kernel<true>, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mean,
+                               inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, x_bs, gx_bs, accumulate_gx);
+  else hipLaunchKernelGGL(bn_act_bwd_rows_kernel<false>, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mean,
+                          inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, x_bs, gx_bs, accumulate_gx);
   return launch_status();
 }
 

@@ -34,6 +34,12 @@ def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+def _zeros(shape, like):
+    data = _empty(shape, like)
+    _call('srgan_fill', data.data_ptr(), data.numel(), 0.0, _stream())
+    return data
+
+
 def _check_device(t):
     if not t.is_cuda:
         raise _lib.HipLibraryError('srgan_amd operations need device tensors (there is no CPU fallback)')
@@ -298,16 +304,15 @@ def batch_norm_eval(x, mean, inv_std, gamma, beta, relu=False):
             gbeta = chan_reduce(gm) if needs[2] else None
             return gx, ggamma, gbeta
         gx = ggamma = gbeta = None
-        mask = data.data_ptr() if relu else None
+        want_params = needs[1] or needs[2]
+        gx_data = _empty(x.shape, x.data) if needs[0] else None
+        both = _zeros((2, c), x.data) if want_params else None
+        _call('srgan_bn_act_bwd', _ptr(g), _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma), _ptr(beta),
+              1 if relu else 0, gx_data.data_ptr() if needs[0] else None, both[0].data_ptr() if want_params else None,
+              both[1].data_ptr() if want_params else None, n, c, hw, 0, 0, 0, _stream())
         if needs[0]:
-            gx_data = _empty(x.shape, x.data)
-            _call('srgan_chan_affine_act', _ptr(g), None, _ptr(inv_std), _ptr(gamma), None, mask, 0, gx_data.data_ptr(),
-                  n, c, hw, _stream())
             gx = Var(gx_data)
-        if needs[1] or needs[2]:
-            both = _empty((2, c), x.data)
-            _call('srgan_bn_param_grads', _ptr(g), _ptr(x), mask, _ptr(mean), _ptr(inv_std), both.data_ptr(), n, c, hw,
-                  _stream())
+        if want_params:
             ggamma, gbeta = Var(both[0]), Var(both[1])
         return gx, ggamma, gbeta
     out.node.backward = backward

@@ -92,13 +92,11 @@ def dense_block(x, layers):
             g_t2 = torch.empty_like(t2)
             F._call('srgan_conv2d_bwd_data', desc2, g_new, layer.conv2.weight.data_ptr(), None, g_t2.data_ptr(), 0, 0,
                     stream)
-            if train:
-                F._call('srgan_bn_param_grads_accumulate', g_t2.data_ptr(), b1.data_ptr(), t2.data_ptr(),
-                        mean2.data.data_ptr(), inv2.data.data_ptr(), layer.norm2.weight.grad.data_ptr(),
-                        layer.norm2.bias.grad.data_ptr(), n, width, hw, 0, stream)
             g_b1 = torch.empty_like(b1)
-            F._call('srgan_chan_affine_act', g_t2.data_ptr(), None, inv2.data.data_ptr(), layer.norm2.weight.data_ptr(),
-                    None, t2.data_ptr(), 0, g_b1.data_ptr(), n, width, hw, stream)
+            F._call('srgan_bn_act_bwd', g_t2.data_ptr(), b1.data_ptr(), mean2.data.data_ptr(), inv2.data.data_ptr(),
+                    layer.norm2.weight.data_ptr(), layer.norm2.bias.data_ptr(), 1, g_b1.data_ptr(),
+                    layer.norm2.weight.grad.data_ptr() if train else None,
+                    layer.norm2.bias.grad.data_ptr() if train else None, n, width, hw, 0, 0, 0, stream)
             desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
             if train:
                 F._call('srgan_conv2d_bwd_weight', desc1, t1.data_ptr(), g_b1.data_ptr(),
@@ -106,14 +104,12 @@ def dense_block(x, layers):
             g_t1 = torch.empty_like(t1)
             F._call('srgan_conv2d_bwd_data', desc1, g_b1.data_ptr(), layer.conv1.weight.data_ptr(), None, g_t1.data_ptr(),
                     0, 0, stream)
-            if train:
-                F._call('srgan_bn_param_grads_accumulate', g_t1.data_ptr(), buffer.data_ptr(), t1.data_ptr(),
-                        mean1.data.data_ptr(), inv1.data.data_ptr(), layer.norm1.weight.grad.data_ptr(),
-                        layer.norm1.bias.grad.data_ptr(), n, cin, hw, buffer_bs, stream)
-            # gradient w.r.t. the layer's (view) input, accumulated into the leading channels of the gradient buffer
-            F._call('srgan_chan_affine_act_strided', g_t1.data_ptr(), None, inv1.data.data_ptr(),
-                    layer.norm1.weight.data_ptr(), None, t1.data_ptr(), 0, gbuf.data_ptr(), n, cin, hw, 0, 0, buffer_bs, 1,
-                    stream)
+            # batch-norm 1 backward: parameter gradients, and the gradient w.r.t. the layer's (view) input
+            # accumulated into the leading channels of the gradient buffer, in one pass
+            F._call('srgan_bn_act_bwd', g_t1.data_ptr(), buffer.data_ptr(), mean1.data.data_ptr(), inv1.data.data_ptr(),
+                    layer.norm1.weight.data_ptr(), layer.norm1.bias.data_ptr(), 1, gbuf.data_ptr(),
+                    layer.norm1.weight.grad.data_ptr() if train else None,
+                    layer.norm1.bias.grad.data_ptr() if train else None, n, cin, hw, buffer_bs, buffer_bs, 1, stream)
             saved[index] = None
         gx = None
         if needs[0]:

@@ -208,6 +208,52 @@ def test_channel_ops_and_frozen_batch_norm(F):
 
 
 @gpu
+def test_fused_batch_norm_backward(F):
+    """srgan_bn_act_bwd: input gradient + both parameter gradients of frozen BN(+ReLU) in one pass, against torch
+    autograd; dense, odd (scalar-path) and channel-slice / accumulate forms."""
+    import ctypes
+    from srgan_amd import tape, _lib
+    gen = torch.Generator().manual_seed(17)
+    for shape in [(3, 5, 6, 7), (2, 4, 40, 40), (2, 6, 32, 48), (4, 9, 1, 1)]:
+        for relu in (False, True):
+            x = torch.randn(shape, generator=gen)
+            c = shape[1]
+            mean, var = torch.randn(c, generator=gen), torch.rand(c, generator=gen) + 0.5
+            gamma, beta = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
+            g = torch.randn(shape, generator=gen)
+            tx, tg, tb = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+            ref = TF.batch_norm(tx, mean, var, tg, tb, training=False, eps=1e-5)
+            ref = ref.relu() if relu else ref
+            ref.backward(g)
+            inv = (var + 1e-5).rsqrt()
+            xv, gv, bv = (F.leaf(dev(t), requires_grad=True) for t in (x, gamma, beta))
+            out = F.batch_norm_eval(xv, F.leaf(dev(mean)), F.leaf(dev(inv)), gv, bv, relu=relu)
+            close(out, ref.detach(), 1e-5, what=f'bn fwd {shape} relu={relu}')
+            tape.backward(out, F.leaf(dev(g)))
+            close(xv.grad, tx.grad, 1e-5, what=f'bn gx {shape} relu={relu}')
+            close(gv.grad, tg.grad, 1e-4, what=f'bn ggamma {shape} relu={relu}')
+            close(bv.grad, tb.grad, 1e-4, what=f'bn gbeta {shape} relu={relu}')
+    # channel-slice view of a wider buffer, gradient accumulated into a slice of a wider gradient buffer
+    n, c, total, h, w = 2, 5, 9, 16, 16
+    wide = torch.randn(n, total, h, w, generator=gen)
+    gwide = torch.randn(n, total, h, w, generator=gen)
+    g = torch.randn(n, c, h, w, generator=gen)
+    mean, var = torch.randn(c, generator=gen), torch.rand(c, generator=gen) + 0.5
+    gamma, beta = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
+    inv = (var + 1e-5).rsqrt()
+    tx = wide[:, :c].clone().requires_grad_()
+    TF.batch_norm(tx, mean, var, gamma, beta, training=False, eps=1e-5).relu().backward(g)
+    expected = gwide.clone()
+    expected[:, :c] += tx.grad
+    d = {k: dev(v) for k, v in dict(wide=wide, gwide=gwide, g=g, mean=mean, inv=inv, gamma=gamma, beta=beta).items()}
+    _lib.check(_lib.library().srgan_bn_act_bwd(d['g'].data_ptr(), d['wide'].data_ptr(), d['mean'].data_ptr(),
+                                               d['inv'].data_ptr(), d['gamma'].data_ptr(), d['beta'].data_ptr(), 1,
+                                               d['gwide'].data_ptr(), None, None, n, c, h * w, total * h * w,
+                                               total * h * w, 1, torch.cuda.current_stream().cuda_stream), 'bn_act_bwd')
+    close(d['gwide'], expected, 1e-5, what='bn_act_bwd strided accumulate')
+
+
+@gpu
 def test_pooling_and_layout(F):
     gen = torch.Generator().manual_seed(8)
     x = torch.randn(2, 5, 13, 11, generator=gen)
