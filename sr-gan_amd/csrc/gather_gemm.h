@@ -99,7 +99,7 @@ inline Dec3 dec_3d(int32_t count_c, int32_t A, int32_t B, int32_t off_c, int32_t
   return d;
 }
 
-enum StoreMode { GG_STORE = 0, GG_ACCUMULATE = 1, GG_ATOMIC = 2 };
+enum StoreMode { GG_STORE = 0, GG_ACCUMULATE = 1, GG_ATOMIC = 2, GG_PARTIAL = 3 };
 
 struct GatherGemm {
   const float* A; Dec3 am, ak;
@@ -112,6 +112,8 @@ struct GatherGemm {
   int32_t mode;                                          // StoreMode
   int32_t split_k, k_per_split;                          // filled by the launcher
   int32_t debug;                                         // tuning experiments (SRGAN_GG_DEBUG): 1 no re-staging, 2 no MFMA
+  float* partial;                                        // GG_PARTIAL: K-slice z stores to partial[(z*M + i)*N + j]
+  int32_t use_partial;                                   // launcher: combine K-slices through a workspace, not atomics
 };
 
 // Reference semantics of one output element (used by the CPU emulator and by the direct kernel).

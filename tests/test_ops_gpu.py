@@ -141,7 +141,8 @@ def test_linear_and_mm(F, force):
     gen = torch.Generator().manual_seed(5)
     F.FORCE_KERNEL = force
     try:
-        for (bsz, fin, fout) in [(7, 11, 5), (256, 50, 10), (64, 300, 130), (2, 25088 // 8, 512), (130, 64, 1)]:
+        for (bsz, fin, fout) in [(7, 11, 5), (256, 50, 10), (64, 300, 130), (2, 25088 // 8, 512), (130, 64, 1),
+                                 (16, 65536, 20)]:   # tiny output, long K: split-K through the partial-sum workspace
             x, w, b = torch.randn(bsz, fin, generator=gen), torch.randn(fout, fin, generator=gen), torch.randn(fout, generator=gen)
             xv, wv, bv = F.leaf(dev(x)), F.leaf(dev(w)), F.leaf(dev(b))
             close(F.linear(xv, wv, bv), TF.linear(x, w, b), what=f'linear {bsz}x{fin}x{fout}')
