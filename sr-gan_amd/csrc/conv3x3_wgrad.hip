@@ -1,0 +1,223 @@
+// conv3x3_wgrad.hip -- weight gradient of 3x3 / stride 1 / pad 1 convolutions (the DenseNet growth convolutions,
+// reference crowd/models.py:344-345; autograd's conv weight gradient behind loss.backward(), srgan.py:264,295,304).
+//
+//   gw[co, ci, kh, kw] += sum_{n,h,w} gy[n, co, h, w] * x[n, ci, h + kh - 1, w + kw - 1]
+//
+// As a gather-GEMM this is M = CO (32 for every growth convolution) x N = CI*9 x K = pixels, and the generic kernel
+// gathers every x element nine times (once per tap) for a single 32-row MFMA each: it ran at 27-47 TF/s.  Here one
+// workgroup stages a TH x 16 pixel tile of gy (32 output channels) and the matching (TH+2) x 18 halo patch of x
+// (32 input channels) in LDS ONCE and all nine taps read it.  MFMA roles (v_mfma_f32_32x32x2_f32): rows = co,
+// columns = ci, k = two horizontally adjacent pixels.  The workgroup is 3 waves, one per kernel row kh; a wave keeps
+// its three 32x32 tap accumulators (48 registers) across all the pixel tiles the workgroup walks and adds them to gw
+// with fp32 atomics once at the end.  The next tile is fetched into registers while the current one is in the MFMAs
+// (raw loads from clamped addresses; the validity mask is applied when the registers are written to LDS -- a use of
+// the loaded value before the MFMA loop would make the compiler wait for the loads there).
+#include "common.h"
+#include <stdlib.h>
+
+namespace srgan {
+
+using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+
+struct Wgrad3Params {
+  const float* x; const float* gy; float* gw;
+  int64_t x_bs, gy_bs;
+  int32_t N, CI, CO, H, W;
+  int32_t tiles_x, tiles_y, tiles;
+  int32_t debug;                  // tuning experiments (SRGAN_WGRAD3_DEBUG): 1 skip the atomic pass
+};
+
+constexpr int WG3_TW = 16;
+constexpr int WG3_CI = 32;      // input channels per workgroup (one MFMA column block)
+constexpr int WG3_CO = 32;
+constexpr int WG3_THREADS = 192;
+
+template <int TH>
+__global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgrad3Params p) {
+  constexpr int PW = WG3_TW + 2, PH = TH + 2;
+  constexpr int PATCH = PH * PW;            // halo patch of one channel
+  constexpr int PS = PATCH | 1;             // odd plane stride: the 32 lanes of an operand read hit 32 banks
+  constexpr int GT = TH * WG3_TW;           // gy tile of one channel
+  constexpr int GS = GT | 1;
+  static_assert(PH * 32 <= WG3_THREADS, "one (patch row, channel) pair per thread");
+  constexpr int OUT_ROW = WG3_CI * 9 + 1;   // epilogue transpose buffer: [co][ci*9 + tap], odd row stride
+  constexpr int SMEM = WG3_CI * PS + WG3_CO * GS > WG3_CO * OUT_ROW ? WG3_CI * PS + WG3_CO * GS : WG3_CO * OUT_ROW;
+  __shared__ float smem[SMEM];
+  float* xs = smem;
+  float* gs = smem + WG3_CI * PS;
+
+  const int tid = (int)threadIdx.x, lane = tid & 63, kh = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int ci0 = (int)blockIdx.y * WG3_CI, co0 = (int)blockIdx.z * WG3_CO;
+  const int HW = p.H * p.W;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* a_base = gs + l31 * GS + lhi;
+  const float* b_base = xs + l31 * PS + kh * PW + lhi;
+
+  // Staging ownership: thread -> (row, channel).  x: one patch row of one input channel = the 6 aligned float4 that
+  // cover columns [w0 - 4, w0 + 20) (18 of the 24 floats are the halo row); gy: one tile row of one output channel =
+  // 4 float4.  W % 4 == 0 (checked by the launcher) makes every float4 entirely inside or entirely outside the row.
+  const int srow = tid >> 5, sch = tid & 31;
+  const bool x_owner = srow < PH, g_owner = srow < TH;
+  const bool x_ch_ok = ci0 + sch < p.CI, g_ch_ok = co0 + sch < p.CO;
+  const uint32_t x_ch_off = (uint32_t)(min(ci0 + sch, p.CI - 1) * HW);
+  const uint32_t g_ch_off = (uint32_t)(min(co0 + sch, p.CO - 1) * HW);
+  float* xs_row = xs + sch * PS + srow * PW;
+  float* gs_row = gs + sch * GS + srow * WG3_TW;
+
+  float4 xv[6], gv[4];
+  uint32_t okbits = 0;
+
+  // Issues the loads of one tile (no use of the values here) and records which of them are real.
+  auto fetch = [&](int tile) {
+    const int tx = tile % p.tiles_x;
+    const int rest = tile / p.tiles_x;
+    const int ty = rest % p.tiles_y;
+    const int n = rest / p.tiles_y;
+    const int h0 = ty * TH, w0 = tx * WG3_TW;
+    const float* xn = p.x + (int64_t)n * p.x_bs;
+    const float* gn = p.gy + (int64_t)n * p.gy_bs;
+    okbits = 0;
+    if (x_owner) {
+      const int h = h0 + srow - 1;
+      const bool row_ok = x_ch_ok && (unsigned)h < (unsigned)p.H;
+      const uint32_t row_off = x_ch_off + (uint32_t)(min(max(h, 0), p.H - 1) * p.W);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int col = w0 - 4 + 4 * q;
+        const bool ok = row_ok && (unsigned)col < (unsigned)p.W;
+        okbits |= (ok ? 1u : 0u) << q;
+        xv[q] = *reinterpret_cast<const float4*>(xn + row_off + (uint32_t)min(max(col, 0), p.W - 4));
+      }
+    }
+    if (g_owner) {
+      const int h = h0 + srow;
+      const bool row_ok = g_ch_ok && h < p.H;
+      const uint32_t row_off = g_ch_off + (uint32_t)(min(h, p.H - 1) * p.W);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = w0 + 4 * q;
+        const bool ok = row_ok && col < p.W;
+        okbits |= (ok ? 1u : 0u) << (8 + q);
+        gv[q] = *reinterpret_cast<const float4*>(gn + row_off + (uint32_t)min(col, p.W - 4));
+      }
+    }
+  };
+
+  int tile = (int)blockIdx.x;
+  if (tile < p.tiles) fetch(tile);
+  for (; tile < p.tiles; tile += (int)gridDim.x) {
+    __syncthreads();                        // the previous tile's MFMA reads are done
+    if (x_owner) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const bool ok = (okbits >> q) & 1u;
+        const float v[4] = {ok ? xv[q].x : 0.f, ok ? xv[q].y : 0.f, ok ? xv[q].z : 0.f, ok ? xv[q].w : 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = 4 * q + j - 3;      // patch column of float j of quad q (patch column 0 = image column w0 - 1)
+          if (c >= 0 && c < PW) xs_row[c] = v[j];
+        }
+      }
+    }
+    if (g_owner) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = (okbits >> (8 + q)) & 1u;
+        gs_row[4 * q + 0] = ok ? gv[q].x : 0.f;
+        gs_row[4 * q + 1] = ok ? gv[q].y : 0.f;
+        gs_row[4 * q + 2] = ok ? gv[q].z : 0.f;
+        gs_row[4 * q + 3] = ok ? gv[q].w : 0.f;
+      }
+    }
+    __syncthreads();
+    const int next = tile + (int)gridDim.x;
+    if (next < p.tiles) fetch(next);
+
+#pragma unroll 1
+    for (int h = 0; h < TH; ++h) {          // rolled: bounds the LDS values the scheduler keeps in flight
+#pragma unroll
+      for (int w = 0; w < WG3_TW; w += 2) {
+        const float a = a_base[h * WG3_TW + w];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float b = b_base[h * PW + w + kw];
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kw], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- one atomic pass per workgroup.  C/D fragment: column = lane & 31 (ci), row = (r & 3) + 8 * (r >> 2) +
+  // 4 * (lane >> 5) (co).  In that layout a wave's lanes are 36 bytes apart in gw (one L2 atomic transaction per
+  // lane: measured 630 us per launch), so the 32 x 288 block is transposed through LDS and the atomics go out with
+  // lanes along the contiguous (ci, tap) run of each output-channel row.
+  if (p.debug & 1) return;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) smem[co * OUT_ROW + l31 * 9 + kh * 3 + kw] = acc[kw][r];
+  }
+  __syncthreads();
+  const int run = min(WG3_CI, p.CI - ci0) * 9;       // valid floats of each row
+  for (int idx = tid; idx < WG3_CO * WG3_CI * 9; idx += WG3_THREADS) {
+    const int co = idx / (WG3_CI * 9), within = idx - co * (WG3_CI * 9);
+    if (co0 + co < p.CO && within < run)
+      unsafeAtomicAdd(p.gw + ((int64_t)(co0 + co) * p.CI + ci0) * 9 + within, smem[co * OUT_ROW + within]);
+  }
+}
+
+int profile_bracket_begin(hipStream_t stream);
+int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+
+bool conv3x3_wgrad_enabled() {
+  static const bool disabled = getenv("SRGAN_NO_WGRAD3") != nullptr;
+  return !disabled;
+}
+
+// gw (=,+=) the weight gradient; x / gy may be channel-slice views (batch strides in elements).
+int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream) {
+  static const int th_override = getenv("SRGAN_WGRAD3_TH") ? atoi(getenv("SRGAN_WGRAD3_TH")) : 0;
+  Wgrad3Params p;
+  p.x = x; p.gy = gy; p.gw = gw; p.x_bs = x_bs; p.gy_bs = gy_bs;
+  p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
+  p.debug = getenv("SRGAN_WGRAD3_DEBUG") ? atoi(getenv("SRGAN_WGRAD3_DEBUG")) : 0;
+  const int ci_chunks = (CI + WG3_CI - 1) / WG3_CI, co_chunks = (CO + WG3_CO - 1) / WG3_CO;
+  int th = 4;                                  // 4-row tiles: fewer halo rows per pixel (2-row tiles never measured better)
+  if (th_override == 2 || th_override == 4) th = th_override;
+  p.tiles_x = (W + WG3_TW - 1) / WG3_TW;
+  p.tiles_y = (H + th - 1) / th;
+  const int64_t tiles = (int64_t)N * p.tiles_y * p.tiles_x;
+  SRGAN_REQUIRE(W % 4 == 0 && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0 && x_bs % 4 == 0 && gy_bs % 4 == 0, SRGAN_EINVAL,
+                "conv3x3 wgrad 16-byte rows");
+  SRGAN_REQUIRE(tiles < (int64_t)1 << 31 && ci_chunks <= 65535 && co_chunks <= 65535, SRGAN_ERANGE, "conv3x3 wgrad grid");
+  p.tiles = (int)tiles;
+  // Walkers: four resident 3-wave workgroups per CU (LDS-bound) over the whole grid, and at least `depth` tiles per
+  // walker so that the atomic pass (32 x 288 floats per workgroup) is amortised.
+  static const int resident = getenv("SRGAN_WGRAD3_WGS") ? atoi(getenv("SRGAN_WGRAD3_WGS")) : 1024;
+  static const int depth_override = getenv("SRGAN_WGRAD3_DEPTH") ? atoi(getenv("SRGAN_WGRAD3_DEPTH")) : 0;
+  // measured on 128 -> 32 channels, batch 16: 64x64 images best at 8 tiles per walker, 32x32 at 4, 16x16 at 1
+  const int depth = depth_override > 0 ? depth_override : (p.tiles >= 1024 ? 8 : (p.tiles >= 256 ? 4 : 1));
+  int walkers = resident / (ci_chunks * co_chunks);
+  if (walkers > (p.tiles + depth - 1) / depth) walkers = (p.tiles + depth - 1) / depth;
+  if (walkers < 1) walkers = 1;
+  if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)CO * CI * 9 * sizeof(float), stream));
+  dim3 grid((unsigned)walkers, (unsigned)ci_chunks, (unsigned)co_chunks);
+  profile_bracket_begin(stream);
+  if (th == 4) hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WG3_THREADS), 0, stream, p);
+  else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(WG3_THREADS), 0, stream, p);
+  const int status = launch_status();
+  profile_bracket_end(stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers);
+  return status;
+}
+
+}  // namespace srgan

@@ -42,6 +42,10 @@ inline int32_t innermost_run(const Dec3& d) {
 inline void choose_staging(GatherGemm& p) {
   p.a_kfast = innermost_run(p.ak) >= innermost_run(p.am) ? 1 : 0;
   p.b_kfast = innermost_run(p.bk) > innermost_run(p.bn) ? 1 : 0;
+  // A handful of rows / columns against a long K (weight gradients of the k = stride map-head convolutions): lanes
+  // along m / n would be almost all masked, lanes along k are all busy.
+  if (p.M > 0 && p.M <= 16 && p.K >= 64) p.a_kfast = 1;
+  if (p.N > 0 && p.N <= 16 && p.K >= 64) p.b_kfast = 1;
 }
 
 inline bool pointwise(const ConvGeom& g) {

@@ -387,7 +387,7 @@ bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
   choose_split(p, c, true);
   if (out) *out = c;
   static const bool no_partial = getenv("SRGAN_NO_PARTIAL") != nullptr;
-  p.use_partial = !no_partial && c.kind == 1 && p.split_k >= 32 && (int64_t)p.M * p.N <= 8192;
+  p.use_partial = !no_partial && c.kind == 1 && p.split_k >= 32 && (int64_t)p.M * p.N < 512;
   return p.split_k > 1 && !p.use_partial;
 }
 
@@ -451,6 +451,18 @@ static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
 static bool use_conv3x3(const ConvGeom& g, int out_channels, int force) {
   return force == 0 && conv3x3_enabled() && g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
          g.W >= 16 && out_channels >= 8;
+}
+
+bool conv3x3_wgrad_enabled();
+int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream);
+
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution with at least one wave's worth of input channels: the
+// LDS-patch kernel of conv3x3_wgrad.hip.
+static bool use_wgrad3x3(const ConvGeom& g, const float* x, const float* gy, int force) {
+  return force == 0 && conv3x3_wgrad_enabled() && g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 &&
+         g.pw == 1 && g.W >= 16 && g.W % 4 == 0 && g.C >= 32 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0 &&
+         (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
 }
 
 int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
@@ -597,6 +609,8 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   ConvGeom g;
   SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_weight geometry");
   SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
+  if (use_wgrad3x3(g, x, gy, force_kernel))
+    return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream);
   std::vector<GatherGemm> plans{plan_conv_bwd_weight(g, x, gy, gw)};
   return gg_run_group(plans, gw, (int64_t)g.K * g.C * g.R * g.S, accumulate, force_kernel, (hipStream_t)stream);
 }

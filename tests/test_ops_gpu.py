@@ -94,6 +94,7 @@ CONV_CASES = [
     (2, 32, 16, 64, 130, 3, 3, (1, 1), (1, 1)),
     (2, 24, 33, 35, 16, 3, 3, (1, 1), (1, 1)),
     (16, 128, 64, 64, 32, 3, 3, (1, 1), (1, 1)),
+    (3, 200, 20, 24, 40, 3, 3, (1, 1), (1, 1)),      # LDS-patch weight gradient: ragged channel chunks and tiles
 ]
 
 
