@@ -257,6 +257,74 @@ __global__ __launch_bounds__(256) void gg_direct_kernel(const GatherGemm p) {
   else unsafeAtomicAdd(dst, acc);
 }
 
+// A few output rows (M <= MR: RGB image gradients of the stem, the generator's 3-channel output layer) over a very
+// wide N: the MFMA tile would spend 29 of its 32 rows on padding (4.5 TF/s measured).  One thread per column keeps
+// MR accumulators.  Everything that depends only on k -- the decoded B-side offset / coordinates and the MR values
+// of A -- is tabulated in LDS once per 256-k chunk and read back as broadcasts, so each gathered B element costs one
+// vector load, two LDS broadcasts and ~12 VALU instructions, branch-free.
+template <int MR>
+__global__ __launch_bounds__(256) void gg_rows_kernel(const GatherGemm p) {
+  constexpr int KC = 256;
+  __shared__ int4 ktab[KC];                  // {B offset, h, w, -} of k
+  __shared__ float atab[KC * MR];            // A[i, k] for the MR rows
+  const int tid = (int)threadIdx.x;
+  const int j = (int)blockIdx.x * 256 + tid;
+  const bool col_ok = j < p.N;
+  const int jc = col_ok ? j : p.N - 1;
+  const Side bn = decode(p.bn, jc), cn = decode(p.cn, jc);
+  const int kbeg = (int)blockIdx.y * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const bool lane_ok = col_ok && bn.valid;
+  float acc[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) acc[i] = 0.f;
+
+  for (int k0 = kbeg; k0 < kend; k0 += KC) {
+    __syncthreads();
+    {
+      const int k = k0 + tid;
+      const bool k_ok = k < kend;
+      const Side bk = decode(p.bk, k_ok ? k : kbeg), ak = decode(p.ak, k_ok ? k : kbeg);
+      // an invalid k gets a row coordinate that fails every bounds test
+      ktab[tid] = make_int4((int)bk.off, (k_ok && bk.valid) ? bk.h : -0x40000000, bk.w, 0);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const Side am = decode(p.am, i < p.M ? i : 0);
+        const bool ok = k_ok && i < p.M && am.valid && ak.valid;
+        const float v = p.A[ok ? am.off + ak.off : 0u];
+        atab[tid * MR + i] = ok ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    const int kc = min(KC, kend - k0);
+#pragma unroll 8
+    for (int kk = 0; kk < kc; ++kk) {
+      const int4 t = ktab[kk];
+      // bitwise, not short-circuit: no divergent branches around the table reads
+      const bool ok = (int)lane_ok & (int)((uint32_t)(t.y + bn.h) < (uint32_t)p.hlim) &
+                      (int)((uint32_t)(t.z + bn.w) < (uint32_t)p.wlim);
+      const float v = p.B[ok ? (uint32_t)t.x + bn.off : 0u];
+      const float b = ok ? v : 0.f;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) acc[i] = fmaf(atab[kk * MR + i], b, acc[i]);
+    }
+  }
+  if (!col_ok || !cn.valid) return;
+  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    if (i >= p.M) break;
+    const Side cm = decode(p.cm, i);
+    if (!cm.valid) continue;
+    float v = acc[i];
+    if (add_bias) v += p.bias[p.bias_cols ? cn.c : cm.c];
+    float* dst = p.C + (uint32_t)(cm.off + cn.off);
+    if (p.mode == GG_STORE) *dst = v;
+    else if (p.mode == GG_ACCUMULATE) *dst += v;
+    else unsafeAtomicAdd(dst, v);
+  }
+}
+
 // Second stage of a split-K launch whose output is tiny (M*N of a few thousand): thousands of workgroups adding into
 // the same few cache lines serialise in L2 (measured: 310 us for a 20x16 output from 1024 K-slices), so the slices are
 // stored to a workspace and summed here -- 32 outputs x 8 slice-lanes per workgroup, no atomics, no pre-zeroing.
@@ -305,6 +373,12 @@ static GGConfig choose_config(const GatherGemm& p, int force) {
   if ((p.M <= 2 && force != 2) || force == 1) {
     c.kind = 0; c.bm = 1; c.bn = 256;
     c.tiles = p.M * ((p.N + 255) / 256);
+    return c;
+  }
+  static const bool no_rows = getenv("SRGAN_NO_ROWS") != nullptr;
+  if (force == 0 && !no_rows && p.M <= 8 && p.N >= 4096) {     // kind 5: the few-rows kernel
+    c.kind = 5; c.bm = p.M <= 4 ? 4 : 8; c.bn = 256;
+    c.tiles = (p.N + 255) / 256;
     return c;
   }
   c.kind = 1;
@@ -497,6 +571,11 @@ static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStrea
   }
   dim3 grid(c.tiles, p.split_k, 1);
   SRGAN_REQUIRE(p.split_k <= 65535, SRGAN_ERANGE, "split-k grid");
+  if (c.kind == 5) {
+    if (c.bm == 4) hipLaunchKernelGGL(gg_rows_kernel<4>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gg_rows_kernel<8>, grid, dim3(256), 0, stream, p);
+    return launch_status();
+  }
   if (p.use_partial && p.split_k > 1) {
     SRGAN_REQUIRE(p.mode == GG_STORE || p.mode == GG_ACCUMULATE, SRGAN_EINVAL, "partial-sum launch mode");
     const int64_t mn = (int64_t)p.M * p.N;

@@ -95,6 +95,8 @@ CONV_CASES = [
     (2, 24, 33, 35, 16, 3, 3, (1, 1), (1, 1)),
     (16, 128, 64, 64, 32, 3, 3, (1, 1), (1, 1)),
     (3, 200, 20, 24, 40, 3, 3, (1, 1), (1, 1)),      # LDS-patch weight gradient: ragged channel chunks and tiles
+    (4, 3, 96, 96, 16, 7, 7, (2, 2), (3, 3)),        # stem: the 3-row image gradient takes the few-rows kernel
+    (2, 5, 72, 72, 7, 3, 3, (1, 1), (1, 1)),         # 5 and 7 rows (MR = 8) in the few-rows kernel
 ]
 
 
@@ -127,7 +129,8 @@ def test_conv_passes(F, case, force):
 def test_conv_transpose(F):
     gen = torch.Generator().manual_seed(3)
     for (cin, cout, k, s, p, hin, batch) in [(6, 4, 4, 2, 1, 5, 2), (32, 48, 3, 1, 0, 1, 3), (40, 1, 4, 4, 0, 6, 2),
-                                             (64, 3, 4, 2, 1, 16, 2), (256, 64, 2, 1, 0, 1, 4)]:
+                                             (64, 3, 4, 2, 1, 16, 2), (256, 64, 2, 1, 0, 1, 4),
+                                             (64, 3, 4, 2, 1, 64, 2)]:    # generator output layer: few-rows kernel
         z = torch.randn(batch, cin, hin, hin, generator=gen)
         w = torch.randn(cin, cout, k, k, generator=gen) / cin ** 0.5
         b = torch.randn(cout, generator=gen)
