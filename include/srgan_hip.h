@@ -112,12 +112,14 @@ int srgan_bn_param_grads_accumulate(const float* g, const float* x, const float*
 
 /* Whole backward of frozen batch-norm (+ReLU when relu != 0) in one pass over (g, x): the activation mask is
  * recomputed from x (y = fma(x, a, b), a = inv_std*gamma, b = beta - mean*a, exactly the forward's arithmetic);
- * gx (=,+=) g*[y>0]*a (gx may be NULL; x / gx may be channel-slice views, batch stride 0 = dense); g_gamma[c] +=
- * inv_std[c] * sum g*[y>0]*(x - mean[c]) and g_beta[c] += sum g*[y>0] with fp32 atomics (both NULL = frozen
- * parameters).  Replaces the autograd backward of reference crowd/models.py:338-343 (norm+relu pairs). */
+ * gx (=,+=) g*[y>0]*a (gx may be NULL; g / x / gx may be channel-slice views, batch stride 0 = dense; unscaled != 0
+ * drops the factor a: gx = g*[y>0], the masked tangent used by the double backward of the gradient penalty);
+ * g_gamma[c] += inv_std[c] * sum g*[y>0]*(x - mean[c]) and g_beta[c] += sum g*[y>0] with fp32 atomics (both NULL =
+ * frozen parameters).  Replaces the autograd backward of reference crowd/models.py:338-343 (norm+relu pairs). */
 int srgan_bn_act_bwd(const float* g, const float* x, const float* mean, const float* inv_std, const float* gamma,
                      const float* beta, int relu, float* gx, float* g_gamma, float* g_beta, int32_t N, int32_t C,
-                     int64_t HW, int64_t x_batch_stride, int64_t gx_batch_stride, int accumulate_gx, void* stream);
+                     int64_t HW, int64_t g_batch_stride, int64_t x_batch_stride, int64_t gx_batch_stride,
+                     int accumulate_gx, int unscaled, void* stream);
 
 /* out[c] (=,+=) scale[c] * sum_{n,i} a[n,c,i] * ((b ? b[n,c,i] : 1) - mean[c])  (b, mean, scale optional).
  * Bias / batch-norm parameter gradients; with N = 1, C = batch it is the per-example dot product over C*H*W of

@@ -30,9 +30,9 @@ for (n, c, h, w) in shapes:
     r = [f'bnrelu_fwd {2*nbytes/ms/1e6:6.0f}']
     ms = timed(lambda: lib.srgan_chan_affine_act_strided(wide.data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, 1, y.data_ptr(), n, c, hw, total*hw, 0, 0, 0, stream))
     r.append(f'fwd_strided {2*nbytes/ms/1e6:6.0f}')
-    ms = timed(lambda: lib.srgan_bn_act_bwd(g.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, y.data_ptr(), gg.data_ptr(), gb.data_ptr(), n, c, hw, 0, 0, 0, stream))
+    ms = timed(lambda: lib.srgan_bn_act_bwd(g.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, y.data_ptr(), gg.data_ptr(), gb.data_ptr(), n, c, hw, 0, 0, 0, 0, 0, stream))
     r.append(f'bn_bwd {3*nbytes/ms/1e6:6.0f}')
-    ms = timed(lambda: lib.srgan_bn_act_bwd(g.data_ptr(), wide.data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, wide.data_ptr(), gg.data_ptr(), gb.data_ptr(), n, c, hw, total*hw, total*hw, 1, stream))
+    ms = timed(lambda: lib.srgan_bn_act_bwd(g.data_ptr(), wide.data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, wide.data_ptr(), gg.data_ptr(), gb.data_ptr(), n, c, hw, 0, total*hw, total*hw, 1, 0, stream))
     r.append(f'bn_bwd_acc {4*nbytes/ms/1e6:6.0f}')
     ms = timed(lambda: lib.srgan_ew_binary(0, x.data_ptr(), g.data_ptr(), y.data_ptr(), x.numel(), 0.0, stream))
     r.append(f'add {3*nbytes/ms/1e6:6.0f}')

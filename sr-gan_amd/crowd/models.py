@@ -51,10 +51,9 @@ class _DenseBlock(nn.Sequential):
                             _DenseLayer(num_input_features + i * growth_rate, growth_rate, bn_size, drop_rate))
 
     def forward(self, x):
-        """First-order passes run the whole block as one concat-free node (fused.py); passes that will be
-        differentiated twice (gradient penalty) use the layer-by-layer primitive ops."""
-        from ..tape import higher_order_enabled
-        if higher_order_enabled() or not fused.ENABLED:
+        """The whole block is one concat-free node (fused.py), first and second order (its recorded backward is
+        itself a node: the gradient penalty); ``fused.ENABLED = False`` selects the layer-by-layer primitive ops."""
+        if not fused.ENABLED:
             return super().forward(x)
         return fused.dense_block(x, list(self.children()))
 

@@ -136,15 +136,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
                                                               const float* __restrict__ beta, float* __restrict__ gx,
                                                               float* __restrict__ out_gamma,
                                                               float* __restrict__ out_beta, int C, int64_t HW,
-                                                              int64_t x_bs, int64_t gx_bs, int accumulate) {
+                                                              int64_t g_bs, int64_t x_bs, int64_t gx_bs, int accumulate,
+                                                              int unscaled) {
   __shared__ float scratch[4];
   const int c = blockIdx.x, n = blockIdx.y;
-  const int64_t base = ((int64_t)n * C + c) * HW;             // g is dense
-  const int64_t xbase = (int64_t)n * x_bs + (int64_t)c * HW;  // x / gx may be channel-slice views
+  const int64_t base = (int64_t)n * g_bs + (int64_t)c * HW;   // g / x / gx may be channel-slice views
+  const int64_t xbase = (int64_t)n * x_bs + (int64_t)c * HW;
   const int64_t obase = (int64_t)n * gx_bs + (int64_t)c * HW;
   const float mu = mean[c];
   const float a = inv_std[c] * gamma[c];
   const float b = __fsub_rn(beta[c], __fmul_rn(mu, a));       // = chan_coefficients() of the forward kernel
+  const float os = unscaled ? 1.f : a;                        // output scale
   float acc = 0.f, plain = 0.f;
   if (((base | xbase | obase) & 3) == 0 && (HW & 3) == 0) {
     const float4* g4 = reinterpret_cast<const float4*>(g + base);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
       acc += gv.x * (xv.x - mu) + gv.y * (xv.y - mu) + gv.z * (xv.z - mu) + gv.w * (xv.w - mu);
       plain += gv.x + gv.y + gv.z + gv.w;
       if (o4) {
-        float4 o = make_float4(gv.x * a, gv.y * a, gv.z * a, gv.w * a);
+        float4 o = make_float4(gv.x * os, gv.y * os, gv.z * os, gv.w * os);
         if (accumulate) { const float4 old = o4[i]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
         o4[i] = o;
       }
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
       if (RELU) gv = fmaf(xv, a, b) > 0.f ? gv : 0.f;
       acc += gv * (xv - mu);
       plain += gv;
-      if (gx) gx[obase + i] = accumulate ? gx[obase + i] + gv * a : gv * a;
+      if (gx) gx[obase + i] = accumulate ? gx[obase + i] + gv * os : gv * os;
     }
   }
   if (out_gamma == nullptr) return;
@@ -314,17 +316,19 @@ int srgan_bn_param_grads_accumulate(const float* g, const float* x, const float*
 
 int srgan_bn_act_bwd(const float* g, const float* x, const float* mean, const float* inv_std, const float* gamma,
                      const float* beta, int relu, float* gx, float* g_gamma, float* g_beta, int32_t N, int32_t C,
-                     int64_t HW, int64_t x_batch_stride, int64_t gx_batch_stride, int accumulate_gx, void* stream) {
+                     int64_t HW, int64_t g_batch_stride, int64_t x_batch_stride, int64_t gx_batch_stride,
+                     int accumulate_gx, int unscaled, void* stream) {
   SRGAN_REQUIRE(g && x && mean && inv_std && gamma && beta && N > 0 && C > 0 && HW > 0 && N <= 65535, SRGAN_EINVAL,
                 "srgan_bn_act_bwd arguments");
   SRGAN_REQUIRE((g_gamma == nullptr) == (g_beta == nullptr) && (gx || g_gamma), SRGAN_EINVAL,
                 "srgan_bn_act_bwd outputs");
   const int64_t dense = (int64_t)C * HW;
-  const int64_t x_bs = x_batch_stride ? x_batch_stride : dense, gx_bs = gx_batch_stride ? gx_batch_stride : dense;
+  const int64_t g_bs = g_batch_stride ? g_batch_stride : dense, x_bs = x_batch_stride ? x_batch_stride : dense;
+  const int64_t gx_bs = gx_batch_stride ? gx_batch_stride : dense;
   if (relu) hipLaunchKernelGGL(bn_act_bwd_rows_kernel<true>, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mean,
-                               inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, x_bs, gx_bs, accumulate_gx);
+                               inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, g_bs, x_bs, gx_bs, accumulate_gx, unscaled);
   else hipLaunchKernelGGL(bn_act_bwd_rows_kernel<false>, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mean,
-                          inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, x_bs, gx_bs, accumulate_gx);
+                          inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, g_bs, x_bs, gx_bs, accumulate_gx, unscaled);
   return launch_status();
 }
 

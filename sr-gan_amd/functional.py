@@ -309,7 +309,7 @@ def batch_norm_eval(x, mean, inv_std, gamma, beta, relu=False):
         both = _zeros((2, c), x.data) if want_params else None
         _call('srgan_bn_act_bwd', _ptr(g), _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma), _ptr(beta),
               1 if relu else 0, gx_data.data_ptr() if needs[0] else None, both[0].data_ptr() if want_params else None,
-              both[1].data_ptr() if want_params else None, n, c, hw, 0, 0, 0, _stream())
+              both[1].data_ptr() if want_params else None, n, c, hw, 0, 0, 0, 0, 0, _stream())
         if needs[0]:
             gx = Var(gx_data)
         if want_params:

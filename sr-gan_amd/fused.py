@@ -8,14 +8,26 @@ buffer of the same shape and walks the layers last-to-first: each layer reads it
 w.r.t. its (view) input is ACCUMULATED into the leading channels by the batch-norm backward kernel; weight and
 batch-norm parameter gradients are accumulated straight into the network's flat gradient arena.
 
-This node is first-order only.  When a forward is going to be differentiated twice (the gradient penalty's
-discriminator pass) the modules are run under ``tape.higher_order()`` and use the primitive ops instead.
+Second order (the gradient penalty, reference srgan.py:360-375: ``autograd.grad(..., create_graph=True)`` w.r.t.
+the block input, then ``.backward()`` of a function of that gradient).  With frozen batch-norm and ReLU the block is
+piecewise linear in its input, so its backward B(g) = J^T g is linear in g and depends on the parameters only
+through the weights and the batch-norm scales (the ReLU masks are piecewise constant).  The recorded backward
+therefore returns a node whose own backward is the *linearised forward* of the block: the adjoint of every
+intermediate of B is the corresponding tangent of F, so
+
+  dL/dg       = J v                     (one more concat-free forward pass with mask*scale in place of BN+ReLU)
+  dL/dW_conv  = wgrad(tangent at the conv input, first-backward gradient at the conv output)
+  dL/dgamma   = inv_std * sum_co W * wgrad(masked, unscaled tangent, ...)        (beta only moves the mask: 0)
+
+and no concatenation, slicing or mask tensors are materialised.  Only the input gradient may be requested from a
+recorded backward (exactly the penalty's use); parameter gradients of a recorded backward need the primitive path
+(``fused.ENABLED = False``).
 """
 import torch
 
 from . import _lib
 from . import functional as F
-from .tape import Var, Node, grad_enabled, higher_order_enabled
+from .tape import Var, Node, grad_enabled
 from .nn import parameter_var
 
 
@@ -31,6 +43,10 @@ def _desc(n, c, h, w, k, r, s, stride, pad, x_bs=0, y_bs=0):
     return _lib.ConvDesc(n, c, h, w, k, r, s, stride, stride, pad, pad, oh, ow, x_bs, y_bs)
 
 
+def _empty(shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
 def dense_block(x, layers):
     """``layers``: the block's ``_DenseLayer`` modules (norm1, conv1, norm2, conv2)."""
     n, c0, h, w = x.shape
@@ -39,84 +55,155 @@ def dense_block(x, layers):
     total = c0 + len(layers) * growth
     device = x.data.device
     stream = F._stream()
-    lib = _lib.library()
-    buffer = torch.empty((n, total, h, w), dtype=torch.float32, device=device)
+    buffer = _empty((n, total, h, w), device)
     buffer_bs = total * hw
     F._call('srgan_copy_channels', x.data.data_ptr(), c0, 0, buffer.data_ptr(), total, 0, c0, n, hw, 0, stream)
     saved = []
-    train = parameter_var(layers[0].conv1.weight).requires_grad and grad_enabled()
+    parameter_vars = [parameter_var(p) for layer in layers for p in layer.parameters()]
+    requires = grad_enabled() and (x.requires_grad or any(v.requires_grad for v in parameter_vars))
+    train = requires and any(v.requires_grad for v in parameter_vars)     # t1 / t2 are only read by weight gradients
     for index, layer in enumerate(layers):
         cin = c0 + index * growth
         inv1, mean1 = layer.norm1._inverse_std()
         inv2, mean2 = layer.norm2._inverse_std()
         width = layer.conv1.out_channels
-        t1 = torch.empty((n, cin, h, w), dtype=torch.float32, device=device)
+        t1 = _empty((n, cin, h, w), device)
         F._call('srgan_chan_affine_act_strided', buffer.data_ptr(), mean1.data.data_ptr(), inv1.data.data_ptr(),
                 layer.norm1.weight.data_ptr(), layer.norm1.bias.data_ptr(), None, 1, t1.data_ptr(), n, cin, hw,
                 buffer_bs, 0, 0, 0, stream)
-        b1 = torch.empty((n, width, h, w), dtype=torch.float32, device=device)
+        b1 = _empty((n, width, h, w), device)
         F._call('srgan_conv2d_fwd', _desc(n, cin, h, w, width, 1, 1, 1, 0), t1.data_ptr(), layer.conv1.weight.data_ptr(),
                 None, b1.data_ptr(), 0, stream)
-        t2 = torch.empty((n, width, h, w), dtype=torch.float32, device=device)
+        t2 = _empty((n, width, h, w), device)
         F._call('srgan_chan_affine_act', b1.data_ptr(), mean2.data.data_ptr(), inv2.data.data_ptr(),
                 layer.norm2.weight.data_ptr(), layer.norm2.bias.data_ptr(), None, 1, t2.data_ptr(), n, width, hw, stream)
         F._call('srgan_conv2d_fwd', _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs), t2.data_ptr(),
                 layer.conv2.weight.data_ptr(), None, _ptr(buffer, cin * hw), 0, stream)
-        saved.append((t1, b1, t2) if (grad_enabled()) else None)
+        if requires:
+            saved.append([t1 if train else None, b1, t2 if train else None])
 
-    parameter_vars = [parameter_var(p) for layer in layers for p in layer.parameters()]
-    requires = grad_enabled() and (x.requires_grad or train)
     out = Var(buffer, requires_grad=requires)
     if not requires:
         return out
 
+    def norm_pointers(norm):
+        inv, mean = norm._inverse_std()
+        return mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr()
+
     def backward(g, needs):
-        if grad_enabled():
-            raise RuntimeError('the fused dense block is first-order only: build forwards that will be differentiated '
-                               'twice under tape.higher_order()')
+        recorded = grad_enabled()
+        want_params = any(needs[1:])
+        if recorded and want_params:
+            raise NotImplementedError('a recorded (create_graph) backward of the fused dense block yields the input '
+                                      'gradient only; set srgan_amd.fused.ENABLED = False for parameter gradients of '
+                                      'a recorded backward')
         stream = F._stream()
-        gbuf = torch.empty_like(g.data)          # private copy: the incoming gradient may be shared
+        gbuf = _empty(g.shape, device)            # private copy: the incoming gradient may be shared
         F._call('srgan_ew_unary', F.U_COPY, g.data.data_ptr(), gbuf.data_ptr(), gbuf.numel(), 0.0, 0.0, stream)
+        kept = [None] * len(layers)               # per layer, for the double backward: (gradient at conv1's output, b1)
         for index in range(len(layers) - 1, -1, -1):
             layer = layers[index]
             t1, b1, t2 = saved[index]
             cin = c0 + index * growth
             width = layer.conv1.out_channels
-            inv1, mean1 = layer.norm1._inverse_std()
-            inv2, mean2 = layer.norm2._inverse_std()
+            mean1, inv1, gamma1, beta1 = norm_pointers(layer.norm1)
+            mean2, inv2, gamma2, beta2 = norm_pointers(layer.norm2)
             g_new = _ptr(gbuf, cin * hw)                                  # [N, growth, H, W] view, batch stride buffer_bs
             desc2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
-            if train:
+            if want_params:
                 F._call('srgan_conv2d_bwd_weight', desc2, t2.data_ptr(), g_new, layer.conv2.weight.grad.data_ptr(), 1, 0,
                         stream)
-            g_t2 = torch.empty_like(t2)
+            g_t2 = _empty(b1.shape, device)
             F._call('srgan_conv2d_bwd_data', desc2, g_new, layer.conv2.weight.data_ptr(), None, g_t2.data_ptr(), 0, 0,
                     stream)
-            g_b1 = torch.empty_like(b1)
-            F._call('srgan_bn_act_bwd', g_t2.data_ptr(), b1.data_ptr(), mean2.data.data_ptr(), inv2.data.data_ptr(),
-                    layer.norm2.weight.data_ptr(), layer.norm2.bias.data_ptr(), 1, g_b1.data_ptr(),
-                    layer.norm2.weight.grad.data_ptr() if train else None,
-                    layer.norm2.bias.grad.data_ptr() if train else None, n, width, hw, 0, 0, 0, stream)
+            g_b1 = _empty(b1.shape, device)
+            F._call('srgan_bn_act_bwd', g_t2.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1, g_b1.data_ptr(),
+                    layer.norm2.weight.grad.data_ptr() if want_params else None,
+                    layer.norm2.bias.grad.data_ptr() if want_params else None, n, width, hw, 0, 0, 0, 0, 0, stream)
             desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
-            if train:
+            if want_params:
                 F._call('srgan_conv2d_bwd_weight', desc1, t1.data_ptr(), g_b1.data_ptr(),
                         layer.conv1.weight.grad.data_ptr(), 1, 0, stream)
-            g_t1 = torch.empty_like(t1)
+            g_t1 = _empty((n, cin, h, w), device)
             F._call('srgan_conv2d_bwd_data', desc1, g_b1.data_ptr(), layer.conv1.weight.data_ptr(), None, g_t1.data_ptr(),
                     0, 0, stream)
             # batch-norm 1 backward: parameter gradients, and the gradient w.r.t. the layer's (view) input
             # accumulated into the leading channels of the gradient buffer, in one pass
-            F._call('srgan_bn_act_bwd', g_t1.data_ptr(), buffer.data_ptr(), mean1.data.data_ptr(), inv1.data.data_ptr(),
-                    layer.norm1.weight.data_ptr(), layer.norm1.bias.data_ptr(), 1, gbuf.data_ptr(),
-                    layer.norm1.weight.grad.data_ptr() if train else None,
-                    layer.norm1.bias.grad.data_ptr() if train else None, n, cin, hw, buffer_bs, buffer_bs, 1, stream)
-            saved[index] = None
+            F._call('srgan_bn_act_bwd', g_t1.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, gbuf.data_ptr(),
+                    layer.norm1.weight.grad.data_ptr() if want_params else None,
+                    layer.norm1.bias.grad.data_ptr() if want_params else None, n, cin, hw, 0, buffer_bs, buffer_bs, 1, 0,
+                    stream)
+            if recorded:
+                # The forward node itself may still be back-propagated later (the penalty also depends on the
+                # parameters through the forward activations), so nothing of `saved` is released here; the double
+                # backward holds its own references.
+                kept[index] = (g_b1, b1)
+            else:
+                saved[index] = None
         gx = None
         if needs[0]:
-            gx_data = torch.empty((n, c0, h, w), dtype=torch.float32, device=device)
+            gx_data = _empty((n, c0, h, w), device)
             F._call('srgan_copy_channels', gbuf.data_ptr(), total, 0, gx_data.data_ptr(), c0, 0, c0, n, hw, 0, stream)
             gx = Var(gx_data)
+            if recorded:
+                gx.requires_grad = True
+                gx.node = Node((g,) + tuple(parameter_vars), lambda v, needs2: double_backward(v, needs2, gbuf, kept),
+                               'dense_block_backward')
         return (gx,) + (None,) * len(parameter_vars)
+
+    def double_backward(v, needs2, gbuf, kept):
+        """Backward of the recorded backward: v = dL/d(input gradient).  Returns dL/dg (the linearised forward of the
+        block applied to v) and accumulates the weight / batch-norm-scale gradients into the gradient arena."""
+        if grad_enabled():
+            raise NotImplementedError('third-order differentiation of the fused dense block')
+        stream = F._stream()
+        want_params = any(needs2[1:])
+        vbuf = _empty((n, total, h, w), device)
+        F._call('srgan_copy_channels', v.data.data_ptr(), c0, 0, vbuf.data_ptr(), total, 0, c0, n, hw, 0, stream)
+        for index, layer in enumerate(layers):
+            g_b1, b1 = kept[index]
+            cin = c0 + index * growth
+            width = layer.conv1.out_channels
+            mean1, inv1, gamma1, beta1 = norm_pointers(layer.norm1)
+            mean2, inv2, gamma2, beta2 = norm_pointers(layer.norm2)
+            w1, w2 = layer.conv1.weight, layer.conv2.weight
+            desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
+            desc2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
+            # ---- batch-norm 1 + ReLU, linearised: masked (unscaled) tangent; the scale goes into the weights
+            u1 = _empty((n, cin, h, w), device)
+            F._call('srgan_bn_act_bwd', vbuf.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, u1.data_ptr(),
+                    None, None, n, cin, hw, buffer_bs, buffer_bs, 0, 0, 1, stream)
+            if want_params:
+                q1 = _empty(w1.shape, device)
+                F._call('srgan_conv2d_bwd_weight', desc1, u1.data_ptr(), g_b1.data_ptr(), q1.data_ptr(), 0, 0, stream)
+                # dL/dW1 += q1 * (inv_std * gamma)[ci];  dL/dgamma1 += inv_std * sum_co W1 * q1
+                F._call('srgan_chan_affine_act_strided', q1.data_ptr(), None, inv1, gamma1, None, None, 0,
+                        w1.grad.data_ptr(), width, cin, 1, 0, 0, 0, 1, stream)
+                F._call('srgan_chan_reduce', w1.data_ptr(), q1.data_ptr(), None, inv1, layer.norm1.weight.grad.data_ptr(),
+                        width, cin, 1, 1, stream)
+            w1s = _empty(w1.shape, device)
+            F._call('srgan_chan_affine_act', w1.data_ptr(), None, inv1, gamma1, None, None, 0, w1s.data_ptr(), width, cin, 1,
+                    stream)
+            b1_tangent = _empty(b1.shape, device)
+            F._call('srgan_conv2d_fwd', desc1, u1.data_ptr(), w1s.data_ptr(), None, b1_tangent.data_ptr(), 0, stream)
+            del u1
+            # ---- batch-norm 2 + ReLU, linearised
+            u2 = _empty(b1.shape, device)
+            F._call('srgan_bn_act_bwd', b1_tangent.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1, u2.data_ptr(),
+                    None, None, n, width, hw, 0, 0, 0, 0, 1, stream)
+            if want_params:
+                q2 = _empty(w2.shape, device)
+                F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), q2.data_ptr(), 0, 0, stream)
+                F._call('srgan_chan_affine_act_strided', q2.data_ptr(), None, inv2, gamma2, None, None, 0,
+                        w2.grad.data_ptr(), growth, width, 9, 0, 0, 0, 1, stream)
+                F._call('srgan_chan_reduce', w2.data_ptr(), q2.data_ptr(), None, inv2, layer.norm2.weight.grad.data_ptr(),
+                        growth, width, 9, 1, stream)
+            w2s = _empty(w2.shape, device)
+            F._call('srgan_chan_affine_act', w2.data_ptr(), None, inv2, gamma2, None, None, 0, w2s.data_ptr(), growth, width,
+                    9, stream)
+            F._call('srgan_conv2d_fwd', desc2, u2.data_ptr(), w2s.data_ptr(), None, _ptr(vbuf, cin * hw), 0, stream)
+            kept[index] = None
+        return (Var(vbuf) if needs2[0] else None,) + (None,) * len(parameter_vars)
 
     out.node = Node((x,) + tuple(parameter_vars), backward, 'dense_block')
     return out

@@ -253,8 +253,8 @@ def test_fused_batch_norm_backward(F):
     d = {k: dev(v) for k, v in dict(wide=wide, gwide=gwide, g=g, mean=mean, inv=inv, gamma=gamma, beta=beta).items()}
     _lib.check(_lib.library().srgan_bn_act_bwd(d['g'].data_ptr(), d['wide'].data_ptr(), d['mean'].data_ptr(),
                                                d['inv'].data_ptr(), d['gamma'].data_ptr(), d['beta'].data_ptr(), 1,
-                                               d['gwide'].data_ptr(), None, None, n, c, h * w, total * h * w,
-                                               total * h * w, 1, torch.cuda.current_stream().cuda_stream), 'bn_act_bwd')
+                                               d['gwide'].data_ptr(), None, None, n, c, h * w, 0, total * h * w,
+                                               total * h * w, 1, 0, torch.cuda.current_stream().cuda_stream), 'bn_act_bwd')
     close(d['gwide'], expected, 1e-5, what='bn_act_bwd strided accumulate')
 
 
@@ -403,3 +403,25 @@ def test_fused_dense_block_matches_primitive_path(F):
     backward(y, grad=F.leaf(dev(cotangent)))
     close(x.grad, results[False][1], 1e-4, 'input gradient with frozen parameters')
     assert float(arena.grad.abs().sum()) == 0.0
+    # second order (gradient penalty): recorded input gradient, then the parameter gradients of a function of it --
+    # the fused node's linearised-forward double backward against the primitive ops (two channel widths so that the
+    # block's downstream gradient itself depends on a parameter-carrying recorded op)
+    head = F.leaf(dev(torch.randn(20, generator=gen)), requires_grad=True)
+    second = {}
+    for enabled in (False, True):
+        fused.ENABLED = enabled
+        try:
+            arena.zero_grad()
+            head.grad = None
+            x = F.leaf(dev(x_host), requires_grad=True)
+            y = block(x)
+            scalar = F.sum_all(F.mul(F.chan_affine(y, None, head, None, None), F.leaf(dev(cotangent))))
+            (gx,) = backward(scalar, inputs=[x], create_graph=True)
+            penalty = F.mean_all(F.square(F.add_scalar(F.row_norm(F.flatten2d(gx)), -1.0)))
+            backward(penalty)
+            second[enabled] = (gx.cpu(), penalty.cpu(), arena.grad.detach().cpu().clone(), head.grad.cpu())
+        finally:
+            fused.ENABLED = True
+    for i, what in enumerate(('recorded input gradient', 'penalty', 'penalty parameter gradients', 'penalty head gradient')):
+        close(second[True][i], second[False][i], 1e-4, 'second order: ' + what)
+    assert float(second[True][2].abs().max()) > 0.0
