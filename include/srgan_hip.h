@@ -59,6 +59,20 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
 int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const float* gy, float* gw, int accumulate,
                             int force_kernel, void* stream);
 
+/* Convolutions whose input is relu(batch_norm_eval(x)) evaluated ON THE FLY inside the kernel (the DenseNet
+ * norm -> relu -> conv triples, reference crowd/models.py:338-345): the normalised tensor is never written to HBM.
+ * Zero padding applies to the activated tensor, as in the reference sequence.  Supported geometries: 1x1 / stride 1 /
+ * unpadded on images of a multiple of 32 pixels, and 3x3 / stride 1 / pad 1 with W >= 16 (weight gradient: W % 4 ==
+ * 0, C >= 32; forward: C <= 512); srgan_conv2d_bnrelu_supported(desc, pass) (pass 0 forward, 2 weight gradient)
+ * returns 1 when the fused form exists, otherwise the caller materialises the activation (srgan_chan_affine_act)
+ * and uses the plain entry points.  Results are identical to that two-step form up to summation order. */
+typedef struct srgan_bn_relu { const float* mean; const float* inv_std; const float* gamma; const float* beta; } srgan_bn_relu;
+int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass);
+int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
+                            const float* bias, float* y, void* stream);
+int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,
+                                   float* gw, int accumulate, void* stream);
+
 /* ---- strided GEMM  C[i*sci + j*scj] (=,+=) sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] + bias ----------------
  * C must be a dense M x N matrix (row- or column-major).  bias is indexed by row i, or by column j when
  * bias_on_columns != 0.  Replaces torch.nn.Linear forward/backward at reference coefficient/models.py:17-27,

@@ -15,6 +15,11 @@ class ConvDesc(ctypes.Structure):
                                          'OH', 'OW')] + [('x_batch_stride', i64), ('y_batch_stride', i64)]
 
 
+class BnRelu(ctypes.Structure):
+    """Mirror of ``srgan_bn_relu``: frozen batch-norm statistics and parameters of a fused norm -> relu -> conv."""
+    _fields_ = [(name, vp) for name in ('mean', 'inv_std', 'gamma', 'beta')]
+
+
 SIGNATURES = {
     'srgan_version': ([], ctypes.c_int),
     'srgan_last_error': ([], ctypes.c_char_p),
@@ -22,6 +27,10 @@ SIGNATURES = {
     'srgan_conv2d_bwd_data': ([ctypes.POINTER(ConvDesc), vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp],
                               ctypes.c_int),
     'srgan_conv2d_bwd_weight': ([ctypes.POINTER(ConvDesc), vp, vp, vp, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_conv2d_bnrelu_supported': ([ctypes.POINTER(ConvDesc), ctypes.c_int], ctypes.c_int),
+    'srgan_conv2d_fwd_bnrelu': ([ctypes.POINTER(ConvDesc), vp, ctypes.POINTER(BnRelu), vp, vp, vp, vp], ctypes.c_int),
+    'srgan_conv2d_bwd_weight_bnrelu': ([ctypes.POINTER(ConvDesc), vp, ctypes.POINTER(BnRelu), vp, vp, ctypes.c_int, vp],
+                                       ctypes.c_int),
     'srgan_gemm_f32': ([i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i32, ctypes.c_int, ctypes.c_int,
                         vp], ctypes.c_int),
     'srgan_ew_unary': ([ctypes.c_int, vp, vp, i64, f32, f32, vp], ctypes.c_int),

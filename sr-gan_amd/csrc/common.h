@@ -37,6 +37,14 @@ inline int launch_status() {
   return SRGAN_OK;
 }
 
+// y = fma(x, a, b) is frozen batch-norm: a = inv_std * gamma, b = beta - mean * a.  Every kernel that evaluates the
+// normalisation (forward, fused prologues, the mask recomputed in the backward) goes through this one function so
+// that the sign of y -- the ReLU mask -- is bit-identical everywhere.
+__device__ __forceinline__ void bn_coefficients(float mean, float inv_std, float gamma, float beta, float& a, float& b) {
+  a = __fmul_rn(inv_std, gamma);
+  b = __fsub_rn(beta, __fmul_rn(mean, a));
+}
+
 // Grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs x 8, never more than the work.
 inline unsigned stream_grid(int64_t work_items, int per_block) {
   int64_t blocks = (work_items + per_block - 1) / per_block;

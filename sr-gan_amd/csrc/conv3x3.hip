@@ -32,9 +32,16 @@ struct Conv3Params {
   int32_t ci_per_split;
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
   int32_t debug;        // tuning experiments only (SRGAN_CONV3_DEBUG): 1 = no re-staging, 2 = no MFMA
+  // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
+  const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
 
-template <int BM, int TH, int CI_T>
+constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range whose (a, b) fit the LDS table
+
+// PRO = frozen batch-norm + ReLU fused into the patch staging (reference crowd/models.py:342-345: norm2, relu2,
+// conv2): the (a, b) of the workgroup's input channels sit in a small LDS table and every patch element goes through
+// max(fma(x, a, b), 0) when it is written to LDS; padding stays exactly 0 (the reference pads the activated tensor).
+template <int BM, int TH, int CI_T, bool PRO>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
   constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PHPW = PH * PW;
   constexpr int MI = BM / 32, NI = TH / 4;        // each of the 4 waves owns NI image rows of 32 pixels
@@ -43,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
   constexpr int NP = (PATCH + 255) / 256, NW = (WTS + 255) / 256;
   static_assert(CI_T % 2 == 0 && NI >= 1 && MI >= 1, "bad tile");
   __shared__ float lds[PATCH + CI_T * 9 * LDW];
+  __shared__ float2 coef[PRO ? CONV3_PRO_MAX_CI : 1];
   float* patch = lds;
   float* wt = lds + PATCH;
 
@@ -104,7 +112,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     for (int e = 0; e < NP; ++e) {
       const int flat = e * 256 + tid;
       const bool ok = poff[e] >= 0 && flat / PHPW < room;
-      if (flat < PATCH) patch[flat] = ok ? rp[e] : 0.f;
+      float v = rp[e];
+      if (PRO) {
+        const float2 cf = coef[min(c0 - cbeg + flat / PHPW, CONV3_PRO_MAX_CI - 1)];
+        v = fmaxf(fmaf(v, cf.x, cf.y), 0.f);
+      }
+      if (flat < PATCH) patch[flat] = ok ? v : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < NW; ++e) {
@@ -130,6 +143,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
 
   if (cbeg < cend) {
     fetch(cbeg);
+    if (PRO) {
+      for (int c = tid; c < cend - cbeg; c += 256) {
+        float a, b;
+        bn_coefficients(p.bn_mean[cbeg + c], p.bn_inv[cbeg + c], p.bn_gamma[cbeg + c], p.bn_beta[cbeg + c], a, b);
+        coef[c] = make_float2(a, b);
+      }
+      __syncthreads();
+    }
     stage(cbeg);
     __syncthreads();
     for (int c0 = cbeg; c0 < cend; c0 += CI_T) {
@@ -190,8 +211,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
 
 template <int BM, int CI_T>
 static void launch_conv3(const Conv3Params& p, int th, dim3 grid, hipStream_t stream) {
-  if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T>), grid, dim3(256), 0, stream, p);
+  if (p.bn_mean) {
+    if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, true>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, false>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, false>), grid, dim3(256), 0, stream, p);
+  }
 }
 
 // Declared in gather_gemm_kernels.hip: records a launch for the bench's live event timing.
@@ -207,9 +233,12 @@ bool conv3x3_enabled() {
 // The caller guarantees dense-or-strided NCHW, 3x3 / stride 1 / pad 1.  `accumulate` adds into out.
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
-                int32_t W, int accumulate, hipStream_t stream) {
+                int32_t W, int accumulate, hipStream_t stream, const float* const* bn) {
   Conv3Params p;
   p.in = in; p.w = w; p.out = out; p.bias = bias;
+  p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
+  p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
+  SRGAN_REQUIRE(bn == nullptr || CI <= CONV3_PRO_MAX_CI, SRGAN_EUNSUPPORTED, "conv3x3 fused batch-norm channel count");
   p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
   p.in_bs = in_bs; p.out_bs = out_bs;
   p.debug = getenv("SRGAN_CONV3_DEBUG") ? atoi(getenv("SRGAN_CONV3_DEBUG")) : 0;
@@ -252,7 +281,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   profile_bracket_begin(stream);
   if (bm == 32) launch_conv3<32, 16>(p, th, grid, stream);
   else if (bm == 64) launch_conv3<64, 8>(p, th, grid, stream);
-  else hipLaunchKernelGGL((conv3x3_lds_kernel<128, 4, 4>), grid, dim3(256), 0, stream, p);
+  else launch_conv3<128, 4>(p, 4, grid, stream);
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * H * W, (int64_t)CI * 9, 2, bm, th * 32, split);
   return status;

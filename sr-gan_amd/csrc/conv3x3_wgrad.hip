@@ -25,6 +25,8 @@ struct Wgrad3Params {
   int32_t N, CI, CO, H, W;
   int32_t tiles_x, tiles_y, tiles;
   int32_t debug;                  // tuning experiments (SRGAN_WGRAD3_DEBUG): 1 skip the atomic pass
+  // x is relu(batch_norm_eval(x)) computed on the fly (per input channel) when bn_mean != NULL
+  const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
 
 constexpr int WG3_TW = 16;
@@ -68,6 +70,12 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
   const bool x_ch_ok = ci0 + sch < p.CI, g_ch_ok = co0 + sch < p.CO;
   const uint32_t x_ch_off = (uint32_t)(min(ci0 + sch, p.CI - 1) * HW);
   const uint32_t g_ch_off = (uint32_t)(min(co0 + sch, p.CO - 1) * HW);
+  float pro_a = 1.f, pro_b = 0.f;            // fused batch-norm + ReLU of this thread's input channel
+  const bool pro = p.bn_mean != nullptr;
+  if (pro) {
+    const int c = min(ci0 + sch, p.CI - 1);
+    bn_coefficients(p.bn_mean[c], p.bn_inv[c], p.bn_gamma[c], p.bn_beta[c], pro_a, pro_b);
+  }
   float* xs_row = xs + sch * PS + srow * PW;
   float* gs_row = gs + sch * GS + srow * WG3_TW;
 
@@ -118,7 +126,12 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const bool ok = (okbits >> q) & 1u;
-        const float v[4] = {ok ? xv[q].x : 0.f, ok ? xv[q].y : 0.f, ok ? xv[q].z : 0.f, ok ? xv[q].w : 0.f};
+        float v[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (pro) v[j] = fmaxf(fmaf(v[j], pro_a, pro_b), 0.f);
+          v[j] = ok ? v[j] : 0.f;            // padding is applied to the activated tensor
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int c = 4 * q + j - 3;      // patch column of float j of quad q (patch column 0 = image column w0 - 1)
@@ -185,12 +198,14 @@ bool conv3x3_wgrad_enabled() {
 
 // gw (=,+=) the weight gradient; x / gy may be channel-slice views (batch strides in elements).
 int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream) {
+                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn) {
   static const int th_override = getenv("SRGAN_WGRAD3_TH") ? atoi(getenv("SRGAN_WGRAD3_TH")) : 0;
   Wgrad3Params p;
   p.x = x; p.gy = gy; p.gw = gw; p.x_bs = x_bs; p.gy_bs = gy_bs;
   p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
   p.debug = getenv("SRGAN_WGRAD3_DEBUG") ? atoi(getenv("SRGAN_WGRAD3_DEBUG")) : 0;
+  p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
+  p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
   const int ci_chunks = (CI + WG3_CI - 1) / WG3_CI, co_chunks = (CO + WG3_CO - 1) / WG3_CO;
   int th = 4;                                  // 4-row tiles: fewer halo rows per pixel (2-row tiles never measured better)
   if (th_override == 2 || th_override == 4) th = th_override;

@@ -389,6 +389,14 @@ static GGConfig choose_config(const GatherGemm& p, int force) {
                                           {{64, 128}, {64, 64}, {64, 64}},        // 32 < M <= 64
                                           {{32, 256}, {32, 128}, {32, 128}}};     // M <= 32
   const int cls = p.M > 64 ? 0 : (p.M > 32 ? 1 : 2);
+  // Long-K problems (weight gradients: K = pixels) get their parallelism from split-K anyway, so they take the
+  // largest tile: at 64 x 64 the operand stream (16 FLOP/B) is HBM-bound at ~80 TF/s.
+  static const bool big_tiles = getenv("SRGAN_NO_BIG_TILES") == nullptr;
+  if (big_tiles && p.K >= 131072 && p.M >= 96 && p.N >= 96) {
+    c.bm = 128; c.bn = 128;
+    c.tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    return c;
+  }
   for (int i = 0; i < 3; ++i) {
     c.bm = candidates[cls][i][0];
     c.bn = candidates[cls][i][1];
@@ -510,11 +518,12 @@ int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int
 bool conv3x3_enabled();
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
-                int32_t W, int accumulate, hipStream_t stream);
+                int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
 
 bool pointwise_enabled();
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
-                  int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream);
+                  int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream,
+                  const float* const* bn = nullptr);
 
 // 1x1 / stride 1 / unpadded on images whose pixel count is a multiple of 32: the register-streamed pointwise kernel.
 static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
@@ -529,14 +538,31 @@ static bool use_conv3x3(const ConvGeom& g, int out_channels, int force) {
 
 bool conv3x3_wgrad_enabled();
 int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream);
+                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
 
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution with at least one wave's worth of input channels: the
 // LDS-patch kernel of conv3x3_wgrad.hip.
+static bool wgrad3x3_geometry(const ConvGeom& g) {
+  return g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.W >= 16 && g.W % 4 == 0 &&
+         g.C >= 32 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0;
+}
+
 static bool use_wgrad3x3(const ConvGeom& g, const float* x, const float* gy, int force) {
-  return force == 0 && conv3x3_wgrad_enabled() && g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 &&
-         g.pw == 1 && g.W >= 16 && g.W % 4 == 0 && g.C >= 32 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0 &&
-         (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
+  return force == 0 && conv3x3_wgrad_enabled() && wgrad3x3_geometry(g) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
+}
+
+bool pointwise_wgrad_enabled();
+int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+                        int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
+
+static bool pointwise_wgrad_geometry(const ConvGeom& g) {
+  return pointwise(g) && (g.H * g.W) % 32 == 0 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0 && g.C >= 16 && g.K >= 16;
+}
+
+// Weight gradient of a 1x1 / stride 1 convolution on whole 32-pixel chunks with 16-byte aligned rows: the
+// register-streamed kernel of pointwise_wgrad.hip.
+static bool use_pointwise_wgrad(const ConvGeom& g, const float* x, const float* gy, int force) {
+  return force == 0 && pointwise_wgrad_enabled() && pointwise_wgrad_geometry(g) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
 }
 
 int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
@@ -688,10 +714,61 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   ConvGeom g;
   SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_weight geometry");
   SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
+  if (use_pointwise_wgrad(g, x, gy, force_kernel))
+    return pointwise_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, accumulate, (hipStream_t)stream);
   if (use_wgrad3x3(g, x, gy, force_kernel))
     return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream);
   std::vector<GatherGemm> plans{plan_conv_bwd_weight(g, x, gy, gw)};
   return gg_run_group(plans, gw, (int64_t)g.K * g.C * g.R * g.S, accumulate, force_kernel, (hipStream_t)stream);
+}
+
+// ---- convolutions whose input is relu(batch_norm_eval(x)) evaluated on the fly (DenseNet norm -> relu -> conv)
+struct srgan_bn_relu { const float* mean; const float* inv_std; const float* gamma; const float* beta; };
+
+static bool bn_ok(const srgan_bn_relu* bn) { return bn && bn->mean && bn->inv_std && bn->gamma && bn->beta; }
+
+int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
+  ConvGeom g;
+  if (!to_geom(desc, g)) return 0;
+  if (pass == 0) {
+    if (pointwise(g)) return use_pointwise(g, g.K, 0) ? 1 : 0;
+    return (use_conv3x3(g, g.K, 0) && g.C <= 512) ? 1 : 0;
+  }
+  if (pass == 2) {
+    if (pointwise(g)) return pointwise_wgrad_geometry(g) ? 1 : 0;
+    return (conv3x3_wgrad_enabled() && wgrad3x3_geometry(g)) ? 1 : 0;
+  }
+  return 0;
+}
+
+int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
+                            const float* bias, float* y, void* stream) {
+  ConvGeom g;
+  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu geometry");
+  SRGAN_REQUIRE(x && w && y && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu pointers");
+  SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 0), SRGAN_EUNSUPPORTED, "srgan_conv2d_fwd_bnrelu geometry support");
+  const float* const coefficients[4] = {bn->mean, bn->inv_std, bn->gamma, bn->beta};
+  if (pointwise(g))
+    return pointwise_run(x, g.x_bs, w, g.C, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream,
+                         coefficients);
+  return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, 0, (hipStream_t)stream,
+                     coefficients);
+}
+
+int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,
+                                   float* gw, int accumulate, void* stream) {
+  ConvGeom g;
+  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_weight_bnrelu geometry");
+  SRGAN_REQUIRE(x && gy && gw && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_bwd_weight_bnrelu pointers");
+  SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 2), SRGAN_EUNSUPPORTED,
+                "srgan_conv2d_bwd_weight_bnrelu geometry support");
+  SRGAN_REQUIRE((((uintptr_t)x | (uintptr_t)gy) & 15) == 0, SRGAN_EINVAL, "srgan_conv2d_bwd_weight_bnrelu alignment");
+  const float* const coefficients[4] = {bn->mean, bn->inv_std, bn->gamma, bn->beta};
+  if (pointwise(g))
+    return pointwise_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, accumulate, (hipStream_t)stream,
+                               coefficients);
+  return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream,
+                           coefficients);
 }
 
 int srgan_profile_begin(void) {

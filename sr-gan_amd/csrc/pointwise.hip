@@ -32,13 +32,19 @@ struct PointwiseParams {
   int32_t tiles_m;
   int32_t k_per_split;
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
+  // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
+  const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
 
-template <int MI, int BK>
+// PRO = frozen batch-norm + ReLU fused into the B-operand stream (reference crowd/models.py:338-341: norm1, relu1,
+// conv1): the per-channel (a, b) of the slice are staged in LDS next to the weight tile and every activation goes
+// through max(fma(x, a, b), 0) in registers on its way into the MFMA -- the normalised tensor never exists in HBM.
+template <int MI, int BK, bool PRO>
 __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams p) {
   constexpr int BM = MI * 32, KP = BK / 2, LDA = BM + 1;
   constexpr int EA = BM * BK / 256;
   __shared__ float lds[2 * BK * LDA];
+  __shared__ float2 coef[2][PRO ? BK : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int tm = blockIdx.x % p.tiles_m;
@@ -66,6 +72,14 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
 
   float ra[EA];
   float b0[KP], b1[KP];
+  float rc[4];                                 // PRO: raw batch-norm parameters of channel k0 + (tid % BK)
+  auto fetch_c = [&](int k0) {
+    if (PRO) {
+      int k = k0 + (tid & (BK - 1));
+      k = k < kend ? k : kend - 1;
+      rc[0] = p.bn_mean[k]; rc[1] = p.bn_inv[k]; rc[2] = p.bn_gamma[k]; rc[3] = p.bn_beta[k];
+    }
+  };
   auto fetch_a = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
@@ -73,12 +87,19 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
       const bool ok = k < kend && m < p.CO;
       ra[e] = p.w[ok ? m * p.w_so + k * p.w_si : 0];
     }
+    fetch_c(k0);
   };
-  auto stage_a = [&](int k0, float* As) {
+  auto stage_a = [&](int k0, float* As, int buffer) {
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
       const bool ok = (k0 + a_k[e]) < kend && (m0 + a_m[e]) < p.CO;
       As[a_k[e] * LDA + a_m[e]] = ok ? ra[e] : 0.f;
+    }
+    if (PRO && tid < BK) {
+      float a, b;
+      bn_coefficients(rc[0], rc[1], rc[2], rc[3], a, b);
+      const bool ok = k0 + tid < kend;                       // beyond the split: (0, 0) -> the activation is 0
+      coef[buffer][tid] = make_float2(ok ? a : 0.f, ok ? b : 0.f);
     }
   };
   auto fetch_b = [&](int k0, float (&dst)[KP]) {
@@ -109,17 +130,22 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
     // keeps the in-order wave from stalling on a full memory queue in front of its matrix work (issuing a slice's 32
     // loads back to back serialises "memory time + MFMA time").
     float a[2][MI];
+    float2 cf[2];
+    const float2* cs = &coef[PRO ? buffer : 0][PRO ? lhi : 0];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) a[0][mi] = As[mi * 32];
+    if (PRO) cf[0] = cs[0];
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
       if (q + 1 < KP) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) a[(q + 1) & 1][mi] = As[(2 * (q + 1)) * LDA + mi * 32];
+        if (PRO) cf[(q + 1) & 1] = cs[2 * (q + 1)];
       }
+      const float bq = PRO ? fmaxf(fmaf(bcur[q], cf[q & 1].x, cf[q & 1].y), 0.f) : bcur[q];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bcur[q], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq, acc[mi], 0, 0, 0);
       {   // unconditional (clamped) so that the slice stays one basic block; the last slice's loads are unused
         int k = k0 + BK + 2 * q + lhi;
         k = k < kend ? k : kend - 1;
@@ -129,14 +155,16 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
           const bool ok = ka < kend && m < p.CO;
           ra[q] = p.w[ok ? m * p.w_so + ka * p.w_si : 0];
         }
+        if (q == KP - 1) fetch_c(k0 + BK);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, MI, 0);                 // DS reads of the next pair
+      __builtin_amdgcn_sched_group_barrier(0x100, PRO ? MI + 1 : MI, 0);  // DS reads of the next pair
+      if (PRO) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         // this pair's fma + max
       __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);                 // this pair's MFMAs
       if (q < EA) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // next slice's global loads
       else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     if (more) {
-      stage_a(k0 + BK, lds + (buffer ^ 1) * (BK * LDA));      // the other buffer: nobody reads it during this slice
+      stage_a(k0 + BK, lds + (buffer ^ 1) * (BK * LDA), buffer ^ 1);   // the other buffer: nobody reads it during this slice
       __syncthreads();
     }
   };
@@ -144,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   if (kbeg < kend) {
     fetch_a(kbeg);
     fetch_b(kbeg, b0);
-    stage_a(kbeg, lds);
+    stage_a(kbeg, lds, 0);
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
       slice(k0, b0, b1, 0);
@@ -179,10 +207,20 @@ bool pointwise_enabled() {
   return !disabled;
 }
 
+template <int MI, int BK>
+static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t stream) {
+  if (p.bn_mean) hipLaunchKernelGGL((pointwise_kernel<MI, BK, true>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((pointwise_kernel<MI, BK, false>), grid, dim3(256), 0, stream, p);
+}
+
+// bn (4 pointers: mean, inv_std, gamma, beta; NULL = none): the input is relu(batch_norm_eval(in)) on the fly.
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
-                  int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream) {
+                  int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream,
+                  const float* const* bn) {
   PointwiseParams p;
   p.in = in; p.w = w; p.out = out; p.bias = bias;
+  p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
+  p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
   p.N = N; p.CI = CI; p.CO = CO; p.HW = HW;
   p.in_bs = in_bs; p.out_bs = out_bs; p.w_so = w_so; p.w_si = w_si;
   const int64_t groups = (int64_t)N * HW / 32;
@@ -216,13 +254,13 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   profile_bracket_begin(stream);
   static const int bk = getenv("SRGAN_PW_BK") ? atoi(getenv("SRGAN_PW_BK")) : 32;
   if (bk == 64) {
-    if (mi == 4) hipLaunchKernelGGL((pointwise_kernel<4, 64>), grid, dim3(256), 0, stream, p);
-    else if (mi == 2) hipLaunchKernelGGL((pointwise_kernel<2, 64>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((pointwise_kernel<1, 64>), grid, dim3(256), 0, stream, p);
+    if (mi == 4) launch_pointwise<4, 64>(p, grid, stream);
+    else if (mi == 2) launch_pointwise<2, 64>(p, grid, stream);
+    else launch_pointwise<1, 64>(p, grid, stream);
   } else {
-    if (mi == 4) hipLaunchKernelGGL((pointwise_kernel<4, 32>), grid, dim3(256), 0, stream, p);
-    else if (mi == 2) hipLaunchKernelGGL((pointwise_kernel<2, 32>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((pointwise_kernel<1, 32>), grid, dim3(256), 0, stream, p);
+    if (mi == 4) launch_pointwise<4, 32>(p, grid, stream);
+    else if (mi == 2) launch_pointwise<2, 32>(p, grid, stream);
+    else launch_pointwise<1, 32>(p, grid, stream);
   }
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);

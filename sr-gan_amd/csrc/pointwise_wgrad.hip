@@ -1,0 +1,214 @@
+// pointwise_wgrad.hip -- weight gradient of 1x1 / stride 1 convolutions (the DenseNet bottleneck and transition
+// convolutions, reference crowd/models.py:340-341,369-370; autograd's conv weight gradient behind loss.backward(),
+// srgan.py:264,295,304):
+//
+//   gw[co, ci] += sum_{n, p} gy[n, co, p] * x[n, ci, p]
+//
+// Both operands are rows of pixels and the reduction runs ALONG the rows, so neither needs LDS: with
+// v_mfma_f32_32x32x2_f32 (A[i][k]: lane = i + 32*k, B[k][j]: lane = j + 32*k) lane (i, half) simply owns 16 consecutive
+// pixels of row i -- half 0 the first 16 of a 32-pixel chunk, half 1 the last 16 -- as four 16-byte loads, and the
+// 16 MFMA steps of the chunk walk those registers (the order of a sum does not matter as long as A and B agree on
+// it).  Every 128-byte line is fetched by exactly one load instruction and used completely.  Each WAVE is an
+// independent worker over its own range of pixel chunks for the workgroup's 64 x 64 output tile; the next chunk is
+// in flight while the current one is in the matrix pipe (explicit ping-pong register sets).  The four waves' tiles
+// are summed through LDS and leave as one coalesced fp32-atomic pass per workgroup.
+// The generic gather-GEMM staged both operands through LDS with a transpose and reached 55 TF/s on these shapes.
+#include "common.h"
+#include <stdlib.h>
+
+namespace srgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PwWgradParams {
+  const float* x; const float* gy; float* gw;
+  int64_t x_bs, gy_bs;
+  int32_t N, CI, CO, HW;
+  int32_t tiles_n;               // ci tiles
+  int32_t chunks, chunks_per_worker, chunks_per_image;
+  int32_t mode;                  // 1 accumulate (single K-slice per tile), 2 atomic
+  // x is relu(batch_norm_eval(x)) computed on the fly (per input channel) when bn_mean != NULL
+  const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
+};
+
+constexpr int PWG_MI = 2, PWG_NI = 2;      // 64 x 64 output tile per workgroup
+
+template <bool PRO>
+__global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradParams p) {
+  constexpr int MI = PWG_MI, NI = PWG_NI, ROWS = MI * 32, COLS = NI * 32, LDR = COLS + 1;
+  __shared__ float red[2 * ROWS * LDR];
+
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int tm = (int)blockIdx.x / p.tiles_n, tn = (int)blockIdx.x - tm * p.tiles_n;
+  const int co0 = tm * ROWS, ci0 = tn * COLS;
+  const int worker = (int)blockIdx.y * 4 + wave;
+  const int cbeg = worker * p.chunks_per_worker;
+  const int cend = min(p.chunks, cbeg + p.chunks_per_worker);
+
+  uint32_t a_row[MI], b_row[NI];            // element offset of this lane's 16-pixel run inside an image
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) a_row[mi] = (uint32_t)min(co0 + mi * 32 + l31, p.CO - 1) * (uint32_t)p.HW + 16u * lhi;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) b_row[ni] = (uint32_t)min(ci0 + ni * 32 + l31, p.CI - 1) * (uint32_t)p.HW + 16u * lhi;
+
+  float pro_a[NI], pro_b[NI];               // PRO: batch-norm + ReLU of this lane's input-channel rows
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    pro_a[ni] = 1.f; pro_b[ni] = 0.f;
+    if (PRO) {
+      const int c = min(ci0 + ni * 32 + l31, p.CI - 1);
+      bn_coefficients(p.bn_mean[c], p.bn_inv[c], p.bn_gamma[c], p.bn_beta[c], pro_a[ni], pro_b[ni]);
+    }
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  float4 a0[MI][4], b0[NI][4], a1[MI][4], b1[NI][4];
+  auto fetch = [&](int chunk, float4 (&a)[MI][4], float4 (&b)[NI][4]) {
+    chunk = min(chunk, p.chunks - 1);                      // clamped: a worker's surplus fetch is never used
+    const int n = chunk / p.chunks_per_image;
+    const uint32_t pix = (uint32_t)(chunk - n * p.chunks_per_image) * 32u;
+    const float* ga = p.gy + (int64_t)n * p.gy_bs + pix;
+    const float* xb = p.x + (int64_t)n * p.x_bs + pix;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[mi][q] = *reinterpret_cast<const float4*>(ga + a_row[mi] + 4 * q);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[ni][q] = *reinterpret_cast<const float4*>(xb + b_row[ni] + 4 * q);
+  };
+  auto compute = [&](const float4 (&a)[MI][4], const float4 (&b)[NI][4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float av[MI], bv[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[mi] = e == 0 ? a[mi][q].x : (e == 1 ? a[mi][q].y : (e == 2 ? a[mi][q].z : a[mi][q].w));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bv[ni] = e == 0 ? b[ni][q].x : (e == 1 ? b[ni][q].y : (e == 2 ? b[ni][q].z : b[ni][q].w));
+          if (PRO) bv[ni] = fmaxf(fmaf(bv[ni], pro_a[ni], pro_b[ni]), 0.f);     // at use time: the loads stay in flight
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  if (cbeg < cend) {
+    fetch(cbeg, a0, b0);
+    for (int c = cbeg; c < cend; c += 2) {
+      fetch(c + 1, a1, b1);
+      compute(a0, b0);
+      if (c + 1 < cend) {
+        fetch(c + 2, a0, b0);
+        compute(a1, b1);
+      }
+    }
+  }
+
+  // ---- sum the four waves' tiles through LDS, then one coalesced pass out.  C/D fragment: column = lane & 31, row =
+  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Two LDS tiles: waves 2, 3 deposit, waves 0, 1 add them to their
+  // registers and deposit the pair sums, all 256 threads add the two tiles.
+  float* mine = red + (wave & 1) * (ROWS * LDR);
+  auto at = [&](int mi, int ni, int r) { return (mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDR + ni * 32 + l31; };
+  if (wave >= 2) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[at(mi, ni, r)] = acc[mi][ni][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += mine[at(mi, ni, r)];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[at(mi, ni, r)] = acc[mi][ni][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < ROWS * COLS / 256; ++e) {
+    const int idx = tid + 256 * e;
+    const int row = idx / COLS, col = idx - row * COLS;
+    const float v = red[row * LDR + col] + red[ROWS * LDR + row * LDR + col];
+    if (co0 + row < p.CO && ci0 + col < p.CI) {
+      float* dst = p.gw + (int64_t)(co0 + row) * p.CI + ci0 + col;
+      if (p.mode == 2) unsafeAtomicAdd(dst, v);
+      else *dst += v;
+    }
+  }
+}
+
+int profile_bracket_begin(hipStream_t stream);
+int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+
+// The un-fused weight gradient stays on the generic gather-GEMM by default (measured equal: both are bound by the
+// operand stream at 64 x 64 tiles); this kernel serves the fused batch-norm form, where the generic one cannot.
+bool pointwise_wgrad_enabled() {
+  static const bool enabled = getenv("SRGAN_PW_WGRAD") != nullptr;
+  return enabled;
+}
+
+// gw (=,+=) the weight gradient of a 1x1 convolution; x / gy may be channel-slice views (batch strides in
+// elements).  Requires HW % 32 == 0 and 16-byte aligned rows (checked by the caller).
+int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+                        int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn) {
+  PwWgradParams p;
+  p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
+  p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
+  p.x = x; p.gy = gy; p.gw = gw; p.x_bs = x_bs; p.gy_bs = gy_bs;
+  p.N = N; p.CI = CI; p.CO = CO; p.HW = HW;
+  const int tiles_m = (CO + PWG_MI * 32 - 1) / (PWG_MI * 32);
+  p.tiles_n = (CI + PWG_NI * 32 - 1) / (PWG_NI * 32);
+  const int tiles = tiles_m * p.tiles_n;
+  p.chunks_per_image = HW / 32;
+  const int64_t chunks = (int64_t)N * p.chunks_per_image;
+  SRGAN_REQUIRE(chunks < ((int64_t)1 << 30) && tiles < (1 << 30), SRGAN_ERANGE, "pointwise wgrad grid");
+  p.chunks = (int)chunks;
+  // Three resident workgroups per CU (166 registers per lane): 768 workgroups = 3072 wave workers over the whole grid, but at least 8 chunks per worker so the LDS reduction + atomic pass is amortised.
+  static const int resident = getenv("SRGAN_PWG_WGS") ? atoi(getenv("SRGAN_PWG_WGS")) : 768;
+  static const int min_chunks = getenv("SRGAN_PWG_DEPTH") ? atoi(getenv("SRGAN_PWG_DEPTH")) : 8;
+  int split = (resident + tiles - 1) / tiles;
+  const int max_split = (int)((chunks + 4 * min_chunks - 1) / (4 * min_chunks));
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  p.chunks_per_worker = (int)((chunks + 4 * split - 1) / (4 * split));
+  split = (int)((chunks + 4 * (int64_t)p.chunks_per_worker - 1) / (4 * (int64_t)p.chunks_per_worker));
+  SRGAN_REQUIRE(split <= 65535, SRGAN_ERANGE, "pointwise wgrad split");
+  p.mode = split > 1 ? 2 : 1;
+  if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)CO * CI * sizeof(float), stream));
+  dim3 grid((unsigned)tiles, (unsigned)split, 1);
+  profile_bracket_begin(stream);
+  if (bn) hipLaunchKernelGGL(pointwise_wgrad_kernel<true>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(pointwise_wgrad_kernel<false>, grid, dim3(256), 0, stream, p);
+  const int status = launch_status();
+  profile_bracket_end(stream, CO, CI, (int64_t)N * HW, 6, PWG_MI * 32, PWG_NI * 32, split);
+  return status;
+}
+
+}  // namespace srgan

@@ -187,19 +187,27 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
   }
 }
 
-// HW == 1: a is [N, C]; lanes along c (coalesced), loop over the rows.
+// HW == 1: a is [N, C]; 32 columns x 8 row-lanes per workgroup (lanes along c: coalesced 128-byte rows), the rows
+// strided over the 8 row-lanes and combined through LDS -- a single thread per column would walk N dependent loads.
 __global__ __launch_bounds__(256) void chan_reduce_cols_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ scale,
                                                                float* __restrict__ out, int N, int C, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float mu = mean ? mean[c] : 0.f;
+  __shared__ float scratch[8][33];
+  const int col = (int)threadIdx.x & 31, rl = (int)threadIdx.x >> 5;
+  const int c = (int)blockIdx.x * 32 + col;
+  const float mu = (mean && c < C) ? mean[c] : 0.f;
   float acc = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const int64_t i = (int64_t)n * C + c;
-    acc += a[i] * ((b ? b[i] : 1.f) - mu);
-  }
+  if (c < C)
+    for (int n = rl; n < N; n += 8) {
+      const int64_t i = (int64_t)n * C + c;
+      acc += a[i] * ((b ? b[i] : 1.f) - mu);
+    }
+  scratch[rl][col] = acc;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+#pragma unroll
+  for (int r = 1; r < 8; ++r) acc += scratch[r][col];
   acc *= scale ? scale[c] : 1.f;
   out[c] = accumulate ? out[c] + acc : acc;
 }
@@ -271,7 +279,7 @@ int srgan_chan_reduce(const float* a, const float* b, const float* mean, const f
   SRGAN_REQUIRE(a && out && N > 0 && C > 0 && HW > 0, SRGAN_EINVAL, "srgan_chan_reduce arguments");
   hipStream_t s = (hipStream_t)stream;
   if (HW == 1) {
-    hipLaunchKernelGGL(chan_reduce_cols_kernel, dim3((C + 255) / 256), dim3(256), 0, s, a, b, mean, scale, out, N, C,
+    hipLaunchKernelGGL(chan_reduce_cols_kernel, dim3((C + 31) / 32), dim3(256), 0, s, a, b, mean, scale, out, N, C,
                        accumulate);
     return launch_status();
   }

@@ -32,6 +32,7 @@ from .nn import parameter_var
 
 
 ENABLED = True      # tests flip this to compare the fused block with the primitive path
+PROLOGUE = True     # batch-norm + ReLU evaluated inside the convolution kernels (tests flip this too)
 
 
 def _ptr(tensor, offset_elements=0):
@@ -62,16 +63,35 @@ def dense_block(x, layers):
     parameter_vars = [parameter_var(p) for layer in layers for p in layer.parameters()]
     requires = grad_enabled() and (x.requires_grad or any(v.requires_grad for v in parameter_vars))
     train = requires and any(v.requires_grad for v in parameter_vars)     # t1 / t2 are only read by weight gradients
+    width = layers[0].conv1.out_channels
+    lib = _lib.library()
+    # norm -> relu -> conv with the normalisation evaluated inside the convolution kernels (no t1 / t2 tensors at
+    # all) when the block's geometry has the fused forms; otherwise the activations are materialised.
+    probe1 = _desc(n, c0, h, w, width, 1, 1, 1, 0, buffer_bs, 0)
+    probe2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
+    prologue = PROLOGUE and all(lib.srgan_conv2d_bnrelu_supported(d, kind) for d in (probe1, probe2) for kind in (0, 2))
+
+    def bn_struct(norm):
+        inv, mean = norm._inverse_std()
+        return _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
+
     for index, layer in enumerate(layers):
         cin = c0 + index * growth
+        b1 = _empty((n, width, h, w), device)
+        if prologue:
+            F._call('srgan_conv2d_fwd_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), buffer.data_ptr(),
+                    bn_struct(layer.norm1), layer.conv1.weight.data_ptr(), None, b1.data_ptr(), stream)
+            F._call('srgan_conv2d_fwd_bnrelu', _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs), b1.data_ptr(),
+                    bn_struct(layer.norm2), layer.conv2.weight.data_ptr(), None, _ptr(buffer, cin * hw), stream)
+            if requires:
+                saved.append([None, b1, None])
+            continue
         inv1, mean1 = layer.norm1._inverse_std()
         inv2, mean2 = layer.norm2._inverse_std()
-        width = layer.conv1.out_channels
         t1 = _empty((n, cin, h, w), device)
         F._call('srgan_chan_affine_act_strided', buffer.data_ptr(), mean1.data.data_ptr(), inv1.data.data_ptr(),
                 layer.norm1.weight.data_ptr(), layer.norm1.bias.data_ptr(), None, 1, t1.data_ptr(), n, cin, hw,
                 buffer_bs, 0, 0, 0, stream)
-        b1 = _empty((n, width, h, w), device)
         F._call('srgan_conv2d_fwd', _desc(n, cin, h, w, width, 1, 1, 1, 0), t1.data_ptr(), layer.conv1.weight.data_ptr(),
                 None, b1.data_ptr(), 0, stream)
         t2 = _empty((n, width, h, w), device)
@@ -110,7 +130,10 @@ def dense_block(x, layers):
             mean2, inv2, gamma2, beta2 = norm_pointers(layer.norm2)
             g_new = _ptr(gbuf, cin * hw)                                  # [N, growth, H, W] view, batch stride buffer_bs
             desc2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
-            if want_params:
+            if want_params and prologue:
+                F._call('srgan_conv2d_bwd_weight_bnrelu', desc2, b1.data_ptr(), bn_struct(layer.norm2), g_new,
+                        layer.conv2.weight.grad.data_ptr(), 1, stream)
+            elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc2, t2.data_ptr(), g_new, layer.conv2.weight.grad.data_ptr(), 1, 0,
                         stream)
             g_t2 = _empty(b1.shape, device)
@@ -121,7 +144,11 @@ def dense_block(x, layers):
                     layer.norm2.weight.grad.data_ptr() if want_params else None,
                     layer.norm2.bias.grad.data_ptr() if want_params else None, n, width, hw, 0, 0, 0, 0, 0, stream)
             desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
-            if want_params:
+            if want_params and prologue:
+                F._call('srgan_conv2d_bwd_weight_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0),
+                        buffer.data_ptr(), bn_struct(layer.norm1), g_b1.data_ptr(), layer.conv1.weight.grad.data_ptr(), 1,
+                        stream)
+            elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc1, t1.data_ptr(), g_b1.data_ptr(),
                         layer.conv1.weight.grad.data_ptr(), 1, 0, stream)
             g_t1 = _empty((n, cin, h, w), device)

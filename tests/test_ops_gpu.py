@@ -363,6 +363,48 @@ def test_adam_matches_torch(F):
 
 
 @gpu
+def test_fused_batch_norm_convolutions(F):
+    """srgan_conv2d_fwd_bnrelu / srgan_conv2d_bwd_weight_bnrelu (normalisation evaluated inside the convolution
+    kernels) against the two-step form relu(bn(x)) -> conv of torch, 1x1 and 3x3, dense and channel-slice inputs."""
+    from srgan_amd import _lib
+    lib = _lib.library()
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(23)
+    for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 32, 32, 16, 16, 8, 3),
+                                      (2, 128, 128, 32, 32, 32, 3), (1, 70, 96, 20, 24, 40, 3)]:
+        pad = r // 2
+        wide = torch.randn(n, total, h, w, generator=gen)
+        x = wide[:, :c]
+        mean, var = torch.randn(c, generator=gen) * 0.3, torch.rand(c, generator=gen) + 0.5
+        gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.3
+        weight = torch.randn(k, c, r, r, generator=gen) / (c * r * r) ** 0.5
+        act = TF.batch_norm(x, mean, var, gamma, beta, training=False, eps=1e-5).relu()
+        y_ref = TF.conv2d(act, weight, None, 1, pad)
+        gy = torch.randn(y_ref.shape, generator=gen)
+        gw_ref = torch.nn.grad.conv2d_weight(act, weight.shape, gy, 1, pad)
+        d = {name: dev(t) for name, t in dict(wide=wide, mean=mean, inv=(var + 1e-5).rsqrt(), gamma=gamma, beta=beta,
+                                              weight=weight, gy=gy).items()}
+        desc = _lib.ConvDesc(n, c, h, w, k, r, r, 1, 1, pad, pad, h, w, total * h * w, 0)
+        bn = _lib.BnRelu(d['mean'].data_ptr(), d['inv'].data_ptr(), d['gamma'].data_ptr(), d['beta'].data_ptr())
+        for kind in (0, 2):
+            assert lib.srgan_conv2d_bnrelu_supported(desc, kind) == 1, (n, c, h, w, k, r, kind)
+        y = torch.empty(y_ref.shape, device='cuda')
+        _lib.check(lib.srgan_conv2d_fwd_bnrelu(desc, d['wide'].data_ptr(), bn, d['weight'].data_ptr(), None, y.data_ptr(),
+                                               stream), 'fwd_bnrelu')
+        close(y, y_ref, what=f'fused bn conv forward {c}->{k} k{r}')
+        gw = torch.full(weight.shape, 0.5, device='cuda')
+        _lib.check(lib.srgan_conv2d_bwd_weight_bnrelu(desc, d['wide'].data_ptr(), bn, d['gy'].data_ptr(), gw.data_ptr(), 1,
+                                                      stream), 'bwd_weight_bnrelu')
+        close(gw, gw_ref + 0.5, what=f'fused bn conv weight gradient {c}->{k} k{r} (accumulate)')
+        _lib.check(lib.srgan_conv2d_bwd_weight_bnrelu(desc, d['wide'].data_ptr(), bn, d['gy'].data_ptr(), gw.data_ptr(), 0,
+                                                      stream), 'bwd_weight_bnrelu')
+        close(gw, gw_ref, what=f'fused bn conv weight gradient {c}->{k} k{r}')
+    # geometries without a fused form are reported, not guessed
+    odd = _lib.ConvDesc(2, 32, 9, 7, 16, 1, 1, 1, 1, 0, 0, 9, 7, 0, 0)
+    assert lib.srgan_conv2d_bnrelu_supported(odd, 0) == 0 and lib.srgan_conv2d_bnrelu_supported(odd, 2) == 0
+
+
+@gpu
 def test_fused_dense_block_matches_primitive_path(F):
     """The concat-free one-node dense block (fused.py) against the layer-by-layer primitive ops: forward,
     input gradient and every parameter gradient, with trainable and with frozen parameters."""
@@ -425,3 +467,47 @@ def test_fused_dense_block_matches_primitive_path(F):
     for i, what in enumerate(('recorded input gradient', 'penalty', 'penalty parameter gradients', 'penalty head gradient')):
         close(second[True][i], second[False][i], 1e-4, 'second order: ' + what)
     assert float(second[True][2].abs().max()) > 0.0
+
+
+@gpu
+def test_fused_dense_block_with_in_kernel_batch_norm(F):
+    """A block geometry that takes the in-kernel batch-norm path (fused.PROLOGUE) against the materialised one:
+    forward, first-order gradients with trainable parameters, and the gradient-penalty second order."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd import fused, nn
+    from srgan_amd.crowd.models import _DenseBlock
+    from srgan_amd.tape import backward
+    torch.manual_seed(5)
+    block = _DenseBlock(num_layers=3, num_input_features=32, bn_size=4, growth_rate=8)
+    gen = torch.Generator().manual_seed(6)
+    for m in block.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.weight.shape, generator=gen) + 0.5
+            m.bias.data = torch.randn(m.bias.shape, generator=gen) * 0.2
+            m.running_mean.data = torch.randn(m.running_mean.shape, generator=gen) * 0.2
+            m.running_var.data = torch.rand(m.running_var.shape, generator=gen) + 0.5
+    arena = nn.flatten_parameters(block, torch.device('cuda', 0))
+    x_host = torch.randn(2, 32, 16, 16, generator=gen)
+    cotangent = torch.randn(2, 56, 16, 16, generator=gen)
+    results = {}
+    for prologue in (False, True):
+        fused.PROLOGUE = prologue
+        try:
+            arena.zero_grad()
+            x = F.leaf(dev(x_host), requires_grad=True)
+            y = block(x)
+            backward(y, grad=F.leaf(dev(cotangent)))
+            first = (y.cpu(), x.grad.cpu(), arena.grad.detach().cpu().clone())
+            arena.zero_grad()
+            x = F.leaf(dev(x_host), requires_grad=True)
+            y = block(x)
+            scalar = F.sum_all(F.mul(y, F.leaf(dev(cotangent))))
+            (gx,) = backward(scalar, inputs=[x], create_graph=True)
+            penalty = F.mean_all(F.square(F.add_scalar(F.row_norm(F.flatten2d(gx)), -1.0)))
+            backward(penalty)
+            results[prologue] = first + (gx.cpu(), arena.grad.detach().cpu().clone())
+        finally:
+            fused.PROLOGUE = True
+    for i, what in enumerate(('output', 'input gradient', 'parameter gradients', 'recorded input gradient',
+                              'penalty parameter gradients')):
+        close(results[True][i], results[False][i], 1e-4, 'in-kernel batch-norm: ' + what)
