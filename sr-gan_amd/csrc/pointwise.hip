@@ -32,6 +32,7 @@ struct PointwiseParams {
   int32_t tiles_m;
   int32_t k_per_split;
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
+  int32_t debug;        // tuning experiments (SRGAN_PW_DEBUG): 1 no epilogue stores, 2 no MFMAs, 4 no activation loads
   // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
@@ -145,11 +146,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
       const float bq = PRO ? fmaxf(fmaf(bcur[q], cf[q & 1].x, cf[q & 1].y), 0.f) : bcur[q];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq, acc[mi], 0, 0, 0);
+        if (!(p.debug & 2)) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq, acc[mi], 0, 0, 0);
       {   // unconditional (clamped) so that the slice stays one basic block; the last slice's loads are unused
         int k = k0 + BK + 2 * q + lhi;
         k = k < kend ? k : kend - 1;
-        bnxt[q] = b_lane[(int64_t)k * p.HW];
+        if (!(p.debug & 4)) bnxt[q] = b_lane[(int64_t)k * p.HW];
         if (q < EA) {
           const int ka = k0 + BK + a_k[q], m = m0 + a_m[q];
           const bool ok = ka < kend && m < p.CO;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
     }
   }
 
-  if (!live) return;
+  if (!live || (p.debug & 1)) return;
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
   float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
 #pragma unroll
@@ -223,6 +224,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
   p.N = N; p.CI = CI; p.CO = CO; p.HW = HW;
   p.in_bs = in_bs; p.out_bs = out_bs; p.w_so = w_so; p.w_si = w_si;
+  static const int debug = getenv("SRGAN_PW_DEBUG") ? atoi(getenv("SRGAN_PW_DEBUG")) : 0;
+  p.debug = debug;
   const int64_t groups = (int64_t)N * HW / 32;
   const int64_t col_blocks = (groups + 3) / 4;
   // Tallest row tile that still yields ~4 workgroups per CU; otherwise shorter tiles, then split over input channels.
