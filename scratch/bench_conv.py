@@ -28,3 +28,12 @@ for (n,c,h,w,k,r) in shapes:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)/reps
         print(f'   wgrad {c}->{k} k{r} @{h}x{w} B{n}: {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF/s', flush=True)
+    if os.environ.get('BWD'):
+        gy = F.leaf(torch.randn(n,k,h,w).cuda())
+        for _ in range(3): g = F.conv2d_backward_data(gy, wt, x.shape, (1, 1), (r//2, r//2))
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps): g = F.conv2d_backward_data(gy, wt, x.shape, (1, 1), (r//2, r//2))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)/reps
+        print(f'   bwd_data {k}->{c} k{r} @{h}x{w} B{n}: {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF/s', flush=True)

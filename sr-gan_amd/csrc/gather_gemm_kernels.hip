@@ -527,7 +527,9 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
 
 // 1x1 / stride 1 / unpadded on images whose pixel count is a multiple of 32: the register-streamed pointwise kernel.
 static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
-  return force == 0 && pointwise_enabled() && pointwise(g) && (g.H * g.W) % 32 == 0 && out_channels >= 8;
+  const int in_channels = out_channels == g.K ? g.C : g.K;     // forward: C -> K; data gradient: K -> C
+  return force == 0 && pointwise_enabled() && pointwise(g) && (g.H * g.W) % 32 == 0 && out_channels >= 8 &&
+         in_channels % 2 == 0;
 }
 
 // 3x3 / stride 1 / pad 1 with enough width to fill half of a 32-pixel MFMA column block: the LDS-halo kernel.

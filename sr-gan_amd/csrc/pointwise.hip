@@ -30,9 +30,9 @@ struct PointwiseParams {
   int64_t in_bs, out_bs;
   int32_t w_so, w_si;
   int32_t tiles_m;
+  int32_t m_base;       // first output row of this launch (a second launch covers a shorter remainder tile)
   int32_t k_per_split;
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
-  int32_t debug;        // tuning experiments (SRGAN_PW_DEBUG): 1 no epilogue stores, 2 no MFMAs, 4 no activation loads
   // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
@@ -47,19 +47,25 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   __shared__ float lds[2 * BK * LDA];
   __shared__ float2 coef[2][PRO ? BK : 1];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: keeps the address bases scalar
   const int tm = blockIdx.x % p.tiles_m;
   const int64_t group = (int64_t)(blockIdx.x / p.tiles_m) * 4 + wave;     // this wave's 32-pixel column group
   const int64_t pixel0 = group * 32;
   const int64_t total = (int64_t)p.N * p.HW;
   const bool live = pixel0 < total;                                     // whole groups only (HW % 32 == 0)
   const int n = live ? (int)(pixel0 / p.HW) : 0;
-  const int pix = live ? (int)(pixel0 - (int64_t)n * p.HW) + l31 : l31;
-  const int m0 = tm * BM;
+  const int pix0 = live ? (int)(pixel0 - (int64_t)n * p.HW) : 0;
+  const int pix = pix0 + l31;
+  const int m0 = p.m_base + tm * BM;
   const int kbeg = (int)blockIdx.y * p.k_per_split;
   const int kend = min(p.CI, kbeg + p.k_per_split);
 
-  const float* b_lane = p.in + (int64_t)n * p.in_bs + pix;
+  // Activation addresses: a wave-uniform 64-bit base per channel pair (scalar unit) + ONE 32-bit per-lane offset
+  // (pixel, and one image plane for the odd channel of the pair).  CI is even (checked by the caller), so a pair is
+  // clamped as a whole.
+  const float* b_wave = p.in + (int64_t)n * p.in_bs + pix0;
+  const uint32_t lane_off = (uint32_t)l31 + (uint32_t)lhi * (uint32_t)p.HW;
 
   // A staging coordinates: lanes walk the weight's contiguous direction.
   const bool k_contiguous = p.w_si == 1;
@@ -84,9 +90,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   auto fetch_a = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
-      const int k = k0 + a_k[e], m = m0 + a_m[e];
-      const bool ok = k < kend && m < p.CO;
-      ra[e] = p.w[ok ? m * p.w_so + k * p.w_si : 0];
+      const int k = min(k0 + a_k[e], kend - 1), m = min(m0 + a_m[e], p.CO - 1);   // clamped, masked at stage time
+      ra[e] = p.w[m * p.w_so + k * p.w_si];
     }
     fetch_c(k0);
   };
@@ -106,9 +111,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   auto fetch_b = [&](int k0, float (&dst)[KP]) {
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
-      int k = k0 + 2 * q + lhi;
-      k = k < kend ? k : kend - 1;          // clamped: the matching A rows are zero
-      dst[q] = b_lane[(int64_t)k * p.HW];
+      const int k = min(k0 + 2 * q, kend - 2);          // clamped pair: the matching A rows are zero
+      dst[q] = (b_wave + (int64_t)k * p.HW)[lane_off];
     }
   };
 
@@ -146,15 +150,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
       const float bq = PRO ? fmaxf(fmaf(bcur[q], cf[q & 1].x, cf[q & 1].y), 0.f) : bcur[q];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        if (!(p.debug & 2)) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq, acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq, acc[mi], 0, 0, 0);
       {   // unconditional (clamped) so that the slice stays one basic block; the last slice's loads are unused
-        int k = k0 + BK + 2 * q + lhi;
-        k = k < kend ? k : kend - 1;
-        if (!(p.debug & 4)) bnxt[q] = b_lane[(int64_t)k * p.HW];
+        const int k = min(k0 + BK + 2 * q, kend - 2);
+        bnxt[q] = (b_wave + (int64_t)k * p.HW)[lane_off];
         if (q < EA) {
-          const int ka = k0 + BK + a_k[q], m = m0 + a_m[q];
-          const bool ok = ka < kend && m < p.CO;
-          ra[q] = p.w[ok ? m * p.w_so + ka * p.w_si : 0];
+          const int ka = min(k0 + BK + a_k[q], kend - 1), m = min(m0 + a_m[q], p.CO - 1);
+          ra[q] = p.w[m * p.w_so + ka * p.w_si];
         }
         if (q == KP - 1) fetch_c(k0 + BK);
       }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
     }
   }
 
-  if (!live || (p.debug & 1)) return;
+  if (!live) return;
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
   float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
 #pragma unroll
@@ -224,8 +226,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
   p.N = N; p.CI = CI; p.CO = CO; p.HW = HW;
   p.in_bs = in_bs; p.out_bs = out_bs; p.w_so = w_so; p.w_si = w_si;
-  static const int debug = getenv("SRGAN_PW_DEBUG") ? atoi(getenv("SRGAN_PW_DEBUG")) : 0;
-  p.debug = debug;
+
   const int64_t groups = (int64_t)N * HW / 32;
   const int64_t col_blocks = (groups + 3) / 4;
   // Tallest row tile that still yields ~4 workgroups per CU; otherwise shorter tiles, then split over input channels.
@@ -233,7 +234,16 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   int mi = CO > 64 ? 4 : (CO > 32 ? 2 : 1);
   if (mi > mi_cap) mi = mi_cap;
   while (mi > 1 && col_blocks * ((CO + mi * 32 - 1) / (mi * 32)) < 1024) mi >>= 1;
-  p.tiles_m = (CO + mi * 32 - 1) / (mi * 32);
+  // Rows beyond the last full 128-row tile go to a second launch with a tile just tall enough for them (the data
+  // gradients of the bottlenecks have 64 + 32*l rows: a padded 128-row tile would waste up to 3/8 of the matrix work).
+  int rest = 0, rest_mi = 0;
+  if (mi == 4 && CO > 128 && CO % 128 != 0 && CO % 128 <= 64) {
+    rest = CO % 128;
+    rest_mi = rest <= 32 ? 1 : 2;
+  }
+  const int main_rows = CO - rest;
+  p.tiles_m = (main_rows + mi * 32 - 1) / (mi * 32);
+  p.m_base = 0;
   const int64_t blocks = col_blocks * p.tiles_m;
   const int slices = (CI + 63) / 64;
   int split = 1;
@@ -253,17 +263,24 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   } else {
     p.mode = accumulate ? 1 : 0;
   }
-  dim3 grid((unsigned)blocks, (unsigned)split, 1);
   profile_bracket_begin(stream);
   static const int bk = getenv("SRGAN_PW_BK") ? atoi(getenv("SRGAN_PW_BK")) : 32;
-  if (bk == 64) {
-    if (mi == 4) launch_pointwise<4, 64>(p, grid, stream);
-    else if (mi == 2) launch_pointwise<2, 64>(p, grid, stream);
-    else launch_pointwise<1, 64>(p, grid, stream);
-  } else {
-    if (mi == 4) launch_pointwise<4, 32>(p, grid, stream);
-    else if (mi == 2) launch_pointwise<2, 32>(p, grid, stream);
-    else launch_pointwise<1, 32>(p, grid, stream);
+  auto launch = [&](int mi_, dim3 grid) {
+    if (bk == 64) {
+      if (mi_ == 4) launch_pointwise<4, 64>(p, grid, stream);
+      else if (mi_ == 2) launch_pointwise<2, 64>(p, grid, stream);
+      else launch_pointwise<1, 64>(p, grid, stream);
+    } else {
+      if (mi_ == 4) launch_pointwise<4, 32>(p, grid, stream);
+      else if (mi_ == 2) launch_pointwise<2, 32>(p, grid, stream);
+      else launch_pointwise<1, 32>(p, grid, stream);
+    }
+  };
+  launch(mi, dim3((unsigned)blocks, (unsigned)split, 1));
+  if (rest > 0) {
+    p.m_base = main_rows;
+    p.tiles_m = 1;
+    launch(rest_mi, dim3((unsigned)col_blocks, (unsigned)split, 1));
   }
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);

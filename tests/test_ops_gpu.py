@@ -87,6 +87,9 @@ CONV_CASES = [
     (1, 36, 8, 12, 20, 1, 1, (1, 1), (0, 0)),
     (2, 64, 16, 18, 32, 1, 1, (1, 1), (0, 0)),
     (3, 896, 16, 16, 448, 1, 1, (1, 1), (0, 0)),
+    # data gradient with <= 128 output channels: the resident-weight kernel, remainder tiles of 96 / 64 rows
+    (2, 224, 16, 16, 128, 1, 1, (1, 1), (0, 0)),
+    (2, 192, 8, 32, 64, 1, 1, (1, 1), (0, 0)),
     # 3x3 / s1 / p1 shapes for the LDS-halo kernel (force = 0): all three channel-tile widths, ragged tiles,
     # fewer input channels than one chunk, split over input-channel chunks
     (2, 128, 32, 32, 32, 3, 3, (1, 1), (1, 1)),
