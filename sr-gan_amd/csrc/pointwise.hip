@@ -40,7 +40,9 @@ struct PointwiseParams {
 // PRO = frozen batch-norm + ReLU fused into the B-operand stream (reference crowd/models.py:338-341: norm1, relu1,
 // conv1): the per-channel (a, b) of the slice are staged in LDS next to the weight tile and every activation goes
 // through max(fma(x, a, b), 0) in registers on its way into the MFMA -- the normalised tensor never exists in HBM.
-template <int MI, int BK, bool PRO>
+// NI = 32-pixel column groups per wave (1 or 2): with two, every weight fragment read from LDS feeds two MFMAs and the
+// non-matrix instructions of a k-pair are amortised over 2*MI MFMAs.
+template <int MI, int BK, bool PRO, int NI>
 __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams p) {
   constexpr int BM = MI * 32, KP = BK / 2, LDA = BM + 1;
   constexpr int EA = BM * BK / 256;
@@ -50,10 +52,10 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: keeps the address bases scalar
   const int tm = blockIdx.x % p.tiles_m;
-  const int64_t group = (int64_t)(blockIdx.x / p.tiles_m) * 4 + wave;     // this wave's 32-pixel column group
-  const int64_t pixel0 = group * 32;
+  const int64_t group = (int64_t)(blockIdx.x / p.tiles_m) * 4 + wave;     // this wave's NI adjacent 32-pixel groups
+  const int64_t pixel0 = group * (32 * NI);
   const int64_t total = (int64_t)p.N * p.HW;
-  const bool live = pixel0 < total;                                     // whole groups only (HW % 32 == 0)
+  const bool live = pixel0 < total;                                     // whole groups only (HW % (32 * NI) == 0)
   const int n = live ? (int)(pixel0 / p.HW) : 0;
   const int pix0 = live ? (int)(pixel0 - (int64_t)n * p.HW) : 0;
   const int pix = pix0 + l31;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   }
 
   float ra[EA];
-  float b0[KP], b1[KP];
+  float b0[NI][KP], b1[NI][KP];
   float rc[4];                                 // PRO: raw batch-norm parameters of channel k0 + (tid % BK)
   auto fetch_c = [&](int k0) {
     if (PRO) {
@@ -108,32 +110,36 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
       coef[buffer][tid] = make_float2(ok ? a : 0.f, ok ? b : 0.f);
     }
   };
-  auto fetch_b = [&](int k0, float (&dst)[KP]) {
+  auto fetch_b = [&](int k0, float (&dst)[NI][KP]) {
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
       const int k = min(k0 + 2 * q, kend - 2);          // clamped pair: the matching A rows are zero
-      dst[q] = (b_wave + (int64_t)k * p.HW)[lane_off];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) dst[ni][q] = (b_wave + (int64_t)k * p.HW)[lane_off + 32 * ni];
     }
   };
 
-  f32x16 acc[MI];
+  f32x16 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   // One K-slice: prefetch the following slice (B into `bnxt`, A into registers), run this slice's MFMAs from `bcur`
   // and LDS buffer `buffer`, then publish the prefetched A tile into the other LDS buffer.  The two B register sets
   // are used ping-pong by the caller (explicitly unrolled by two) so that a slice's loads are in flight during the
   // whole previous slice of matrix work; a register copy at the end of the loop gets folded away by the compiler
   // and with it the prefetch distance.
-  auto slice = [&](int k0, const float (&bcur)[KP], float (&bnxt)[KP], int buffer) {
+  auto slice = [&](int k0, const float (&bcur)[NI][KP], float (&bnxt)[NI][KP], int buffer) {
     const bool more = k0 + BK < kend;
     const float* As = lds + buffer * (BK * LDA) + lhi * LDA + l31;
-    // Per k-pair q: (1) the A fragments of pair q + 1 are read from LDS, (2) this pair's MI MFMAs issue, (3) ONE
-    // B load and (at most) one A load of the NEXT slice are issued.  Spreading the global loads between the MFMAs
-    // keeps the in-order wave from stalling on a full memory queue in front of its matrix work (issuing a slice's 32
-    // loads back to back serialises "memory time + MFMA time").
+    // The next slice's WEIGHT (and batch-norm) loads all go out first: stage_a() below waits for them (vmcnt is
+    // in-order), so a load issued late in the slice would expose a memory round trip in front of every barrier.
+    // (A laboratory copy of this loop measured 97 vs 91 TF/s for "all first" vs "one per k-pair", and the
+    // sched_group_barrier pinning of the interleave measured slower than the compiler's own schedule.)
+    fetch_a(k0 + BK);
     float a[2][MI];
     float2 cf[2];
     const float2* cs = &coef[PRO ? buffer : 0][PRO ? lhi : 0];
@@ -147,24 +153,20 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
         for (int mi = 0; mi < MI; ++mi) a[(q + 1) & 1][mi] = As[(2 * (q + 1)) * LDA + mi * 32];
         if (PRO) cf[(q + 1) & 1] = cs[2 * (q + 1)];
       }
-      const float bq = PRO ? fmaxf(fmaf(bcur[q], cf[q & 1].x, cf[q & 1].y), 0.f) : bcur[q];
+      float bq[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        bq[ni] = PRO ? fmaxf(fmaf(bcur[ni][q], cf[q & 1].x, cf[q & 1].y), 0.f) : bcur[ni][q];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq, acc[mi], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq[ni], acc[mi][ni], 0, 0, 0);
       {   // unconditional (clamped) so that the slice stays one basic block; the last slice's loads are unused
         const int k = min(k0 + BK + 2 * q, kend - 2);
-        bnxt[q] = (b_wave + (int64_t)k * p.HW)[lane_off];
-        if (q < EA) {
-          const int ka = min(k0 + BK + a_k[q], kend - 1), m = min(m0 + a_m[q], p.CO - 1);
-          ra[q] = p.w[m * p.w_so + ka * p.w_si];
-        }
-        if (q == KP - 1) fetch_c(k0 + BK);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bnxt[ni][q] = (b_wave + (int64_t)k * p.HW)[lane_off + 32 * ni];
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, PRO ? MI + 1 : MI, 0);  // DS reads of the next pair
-      if (PRO) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         // this pair's fma + max
-      __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);                 // this pair's MFMAs
-      if (q < EA) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // next slice's global loads
-      else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     if (more) {
       stage_a(k0 + BK, lds + (buffer ^ 1) * (BK * LDA), buffer ^ 1);   // the other buffer: nobody reads it during this slice
@@ -192,12 +194,15 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
     for (int r = 0; r < 16; ++r) {
       const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
       if (o >= p.CO) continue;
-      float v = acc[mi][r];
-      if (add_bias) v += p.bias[o];
-      float* dst = out_lane + (int64_t)o * p.HW;
-      if (p.mode == 0) *dst = v;
-      else if (p.mode == 1) *dst += v;
-      else unsafeAtomicAdd(dst, v);
+      const float bias = add_bias ? p.bias[o] : 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float v = acc[mi][ni][r] + bias;
+        float* dst = out_lane + (int64_t)o * p.HW + 32 * ni;
+        if (p.mode == 0) *dst = v;
+        else if (p.mode == 1) *dst += v;
+        else unsafeAtomicAdd(dst, v);
+      }
     }
   }
 }
@@ -210,10 +215,10 @@ bool pointwise_enabled() {
   return !disabled;
 }
 
-template <int MI, int BK>
+template <int MI, int BK, int NI>
 static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t stream) {
-  if (p.bn_mean) hipLaunchKernelGGL((pointwise_kernel<MI, BK, true>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((pointwise_kernel<MI, BK, false>), grid, dim3(256), 0, stream, p);
+  if (p.bn_mean) hipLaunchKernelGGL((pointwise_kernel<MI, BK, true, NI>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, NI>), grid, dim3(256), 0, stream, p);
 }
 
 // bn (4 pointers: mean, inv_std, gamma, beta; NULL = none): the input is relu(batch_norm_eval(in)) on the fly.
@@ -227,17 +232,32 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   p.N = N; p.CI = CI; p.CO = CO; p.HW = HW;
   p.in_bs = in_bs; p.out_bs = out_bs; p.w_so = w_so; p.w_si = w_si;
 
-  const int64_t groups = (int64_t)N * HW / 32;
-  const int64_t col_blocks = (groups + 3) / 4;
+  // Two 32-pixel groups per wave (64 x 64 wave tile): a tuning variant (SRGAN_PW_NI=2).  In isolation it is up to
+  // 10 % faster on the K = 128 data gradients, inside the training step it measured 0.7 % slower: off by default.
+  static const int ni_cap = getenv("SRGAN_PW_NI") ? atoi(getenv("SRGAN_PW_NI")) : 1;
+  int ni = (HW % 64 == 0 && ni_cap >= 2) ? 2 : 1;
+  int64_t groups = (int64_t)N * HW / (32 * ni);
+  int64_t col_blocks = (groups + 3) / 4;
   // Tallest row tile that still yields ~4 workgroups per CU; otherwise shorter tiles, then split over input channels.
   static const int mi_cap = getenv("SRGAN_PW_MI") ? atoi(getenv("SRGAN_PW_MI")) : 4;
   int mi = CO > 64 ? 4 : (CO > 32 ? 2 : 1);
   if (mi > mi_cap) mi = mi_cap;
+  // NI = 2 pairs with the 64-row tile (acc 64 + 2 x 32 operand registers; 128 rows x 64 pixels would spill)
+  if (ni == 2) {
+    if (mi > 2) mi = 2;
+    if (mi < 2 || col_blocks * ((CO + 63) / 64) < 1024) {
+      ni = 1;
+      groups = (int64_t)N * HW / 32;
+      col_blocks = (groups + 3) / 4;
+      mi = CO > 64 ? 4 : (CO > 32 ? 2 : 1);
+      if (mi > mi_cap) mi = mi_cap;
+    }
+  }
   while (mi > 1 && col_blocks * ((CO + mi * 32 - 1) / (mi * 32)) < 1024) mi >>= 1;
   // Rows beyond the last full 128-row tile go to a second launch with a tile just tall enough for them (the data
   // gradients of the bottlenecks have 64 + 32*l rows: a padded 128-row tile would waste up to 3/8 of the matrix work).
   int rest = 0, rest_mi = 0;
-  if (mi == 4 && CO > 128 && CO % 128 != 0 && CO % 128 <= 64) {
+  if (ni == 1 && mi == 4 && CO > 128 && CO % 128 != 0 && CO % 128 <= 64) {
     rest = CO % 128;
     rest_mi = rest <= 32 ? 1 : 2;
   }
@@ -266,14 +286,16 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   profile_bracket_begin(stream);
   static const int bk = getenv("SRGAN_PW_BK") ? atoi(getenv("SRGAN_PW_BK")) : 32;
   auto launch = [&](int mi_, dim3 grid) {
-    if (bk == 64) {
-      if (mi_ == 4) launch_pointwise<4, 64>(p, grid, stream);
-      else if (mi_ == 2) launch_pointwise<2, 64>(p, grid, stream);
-      else launch_pointwise<1, 64>(p, grid, stream);
+    if (ni == 2) {
+      launch_pointwise<2, 32, 2>(p, grid, stream);
+    } else if (bk == 64) {
+      if (mi_ == 4) launch_pointwise<4, 64, 1>(p, grid, stream);
+      else if (mi_ == 2) launch_pointwise<2, 64, 1>(p, grid, stream);
+      else launch_pointwise<1, 64, 1>(p, grid, stream);
     } else {
-      if (mi_ == 4) launch_pointwise<4, 32>(p, grid, stream);
-      else if (mi_ == 2) launch_pointwise<2, 32>(p, grid, stream);
-      else launch_pointwise<1, 32>(p, grid, stream);
+      if (mi_ == 4) launch_pointwise<4, 32, 1>(p, grid, stream);
+      else if (mi_ == 2) launch_pointwise<2, 32, 1>(p, grid, stream);
+      else launch_pointwise<1, 32, 1>(p, grid, stream);
     }
   };
   launch(mi, dim3((unsigned)blocks, (unsigned)split, 1));
