@@ -43,6 +43,9 @@ def parse():
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-roofline', action='store_true')
     parser.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    parser.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL)')
+    parser.add_argument('--single-device', action='store_true',
+                        help='testing aid: every rank uses cuda:0 (with --backend gloo on a one-GPU box)')
     parser.add_argument('--shape-report', default=None, help='write the per-shape contraction timing table here')
     parser.add_argument('--reference-schedule', action='store_true',
                         help='replay the reference forward/backward order instead of sharing forwards')
@@ -162,13 +165,13 @@ def main():
     if world != args.gpus:
         if args.gpus != 1:
             raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = 0 if args.single_device else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dp = None
     if world > 1:
         import srgan_amd  # noqa: F401
         from srgan_amd.parallel import DataParallel
-        dp = DataParallel.from_environment('nccl')
+        dp = DataParallel.from_environment(args.backend)
     rank = dp.rank if dp else 0
     experiment = build_experiment(args, dp)
     labeled = experiment.infinite_iter(experiment.train_dataset_loader)

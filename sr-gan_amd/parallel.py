@@ -50,8 +50,8 @@ class DataParallel:
         if not dist.is_initialized():
             if backend is None:
                 backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-            if backend == 'nccl':
-                torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            if backend == 'nccl' and 'LOCAL_RANK' in os.environ and torch.cuda.device_count() > 1:
+                torch.cuda.set_device(int(os.environ['LOCAL_RANK']))
             dist.init_process_group(backend=backend)
         return cls()
 
