@@ -20,7 +20,10 @@ def current_device():
     here, so the rank's LOCAL_RANK selects it)."""
     if not torch.cuda.is_available():
         raise RuntimeError('srgan_amd needs a ROCm device: the training step has no CPU fallback')
-    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    index = int(os.environ.get('LOCAL_RANK', '0'))
+    if index >= torch.cuda.device_count():      # several ranks sharing one device (single-GPU tests over gloo)
+        index = torch.cuda.current_device()
+    return torch.device('cuda', index)
 
 
 class _LazyDevice:
