@@ -544,6 +544,42 @@ def cat_channels(parts):
     return _out(data, tuple(parts), backward, 'cat_channels')
 
 
+def cat_rows(parts):
+    """Concatenate along the leading (batch) dimension: one contiguous copy per part."""
+    trailing = tuple(parts[0].shape[1:])
+    counts = [p.shape[0] for p in parts]
+    data = _empty((sum(counts),) + trailing, parts[0].data)
+    start = 0
+    for part, count in zip(parts, counts):
+        if tuple(part.shape[1:]) != trailing:
+            raise ValueError('cat_rows: incompatible shapes')
+        _unary_raw(U_COPY, part.data, out=data[start:start + count])
+        start += count
+
+    def backward(g, needs):
+        grads, first = [], 0
+        for need, count in zip(needs, counts):
+            grads.append(narrow_rows(g, first, count) if need else None)
+            first += count
+        return tuple(grads)
+    return _out(data, tuple(parts), backward, 'cat_rows')
+
+
+def narrow_rows(x, first, count):
+    """Rows [first, first + count) of the leading dimension as a VIEW (no copy); the gradient is the cotangent
+    placed into a zero tensor of the full shape."""
+    total = x.shape[0]
+    if first < 0 or count < 0 or first + count > total:
+        raise ValueError('narrow_rows: range outside the leading dimension')
+    shape = tuple(x.shape)
+
+    def backward(g, needs):
+        full = _zeros(shape, g.data)
+        _unary_raw(U_COPY, g.data, out=full[first:first + count])
+        return (_out(full, (g,), lambda gg, n2: (narrow_rows(gg, first, count),), 'narrow_rows_backward'),)
+    return _out(x.data[first:first + count], (x,), backward, 'narrow_rows')
+
+
 def slice_channels(x, first, last):
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
