@@ -135,54 +135,62 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ gx,
                                                               float* __restrict__ out_gamma,
-                                                              float* __restrict__ out_beta, int C, int64_t HW,
+                                                              float* __restrict__ out_beta, int N, int C, int64_t HW,
                                                               int64_t g_bs, int64_t x_bs, int64_t gx_bs, int accumulate,
-                                                              int unscaled) {
+                                                              int unscaled, int images_per_block) {
+  // One workgroup = channel c of images [n0, n1): several images per workgroup when the planes are small (a
+  // 16 x 16 plane is one float4 per four lanes), so that every launch has ~1024 workgroups of useful size.
   __shared__ float scratch[4];
-  const int c = blockIdx.x, n = blockIdx.y;
-  const int64_t base = (int64_t)n * g_bs + (int64_t)c * HW;   // g / x / gx may be channel-slice views
-  const int64_t xbase = (int64_t)n * x_bs + (int64_t)c * HW;
-  const int64_t obase = (int64_t)n * gx_bs + (int64_t)c * HW;
+  const int c = blockIdx.x;
+  const int n0 = (int)blockIdx.y * images_per_block, n1 = min(N, n0 + images_per_block);
   const float mu = mean[c];
-  const float a = inv_std[c] * gamma[c];
-  const float b = __fsub_rn(beta[c], __fmul_rn(mu, a));       // = chan_coefficients() of the forward kernel
+  float a, b;
+  bn_coefficients(mu, inv_std[c], gamma[c], beta[c], a, b);   // the forward's own (a, b): bit-identical mask
   const float os = unscaled ? 1.f : a;                        // output scale
+  const int64_t plane = (int64_t)c * HW;
   float acc = 0.f, plain = 0.f;
-  if (((base | xbase | obase) & 3) == 0 && (HW & 3) == 0) {
-    const float4* g4 = reinterpret_cast<const float4*>(g + base);
-    const float4* x4 = reinterpret_cast<const float4*>(x + xbase);
-    float4* o4 = gx ? reinterpret_cast<float4*>(gx + obase) : nullptr;
-    for (int64_t i = threadIdx.x; i < (HW >> 2); i += 256) {
-      float4 gv = g4[i];
-      const float4 xv = x4[i];
+  const bool vec = ((g_bs | x_bs | gx_bs | HW) & 3) == 0 &&
+                   (((uintptr_t)g | (uintptr_t)x | (uintptr_t)gx) & 15) == 0;
+  if (vec) {
+    const int hw4 = (int)(HW >> 2);
+    const int total = (n1 - n0) * hw4;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+      const int nl = idx / hw4, i = idx - nl * hw4;
+      const int n = n0 + nl;
+      float4 gv = reinterpret_cast<const float4*>(g + (int64_t)n * g_bs + plane)[i];
+      const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)n * x_bs + plane)[i];
       if (RELU) {
         gv.x = fmaf(xv.x, a, b) > 0.f ? gv.x : 0.f; gv.y = fmaf(xv.y, a, b) > 0.f ? gv.y : 0.f;
         gv.z = fmaf(xv.z, a, b) > 0.f ? gv.z : 0.f; gv.w = fmaf(xv.w, a, b) > 0.f ? gv.w : 0.f;
       }
       acc += gv.x * (xv.x - mu) + gv.y * (xv.y - mu) + gv.z * (xv.z - mu) + gv.w * (xv.w - mu);
       plain += gv.x + gv.y + gv.z + gv.w;
-      if (o4) {
+      if (gx) {
+        float4* o4 = reinterpret_cast<float4*>(gx + (int64_t)n * gx_bs + plane) + i;
         float4 o = make_float4(gv.x * os, gv.y * os, gv.z * os, gv.w * os);
-        if (accumulate) { const float4 old = o4[i]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-        o4[i] = o;
+        if (accumulate) { const float4 old = *o4; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *o4 = o;
       }
     }
   } else {
-    for (int64_t i = threadIdx.x; i < HW; i += 256) {
-      float gv = g[base + i];
-      const float xv = x[xbase + i];
-      if (RELU) gv = fmaf(xv, a, b) > 0.f ? gv : 0.f;
-      acc += gv * (xv - mu);
-      plain += gv;
-      if (gx) gx[obase + i] = accumulate ? gx[obase + i] + gv * os : gv * os;
+    for (int n = n0; n < n1; ++n) {
+      const int64_t base = (int64_t)n * g_bs + plane, xbase = (int64_t)n * x_bs + plane, obase = (int64_t)n * gx_bs + plane;
+      for (int64_t i = threadIdx.x; i < HW; i += 256) {
+        float gv = g[base + i];
+        const float xv = x[xbase + i];
+        if (RELU) gv = fmaf(xv, a, b) > 0.f ? gv : 0.f;
+        acc += gv * (xv - mu);
+        plain += gv;
+        if (gx) gx[obase + i] = accumulate ? gx[obase + i] + gv * os : gv * os;
+      }
     }
   }
   if (out_gamma == nullptr) return;
-  const float total = block_sum_256(acc, scratch);
+  const float total_acc = block_sum_256(acc, scratch);
   __syncthreads();
   const float total_plain = block_sum_256(plain, scratch);
   if (threadIdx.x == 0) {
-    unsafeAtomicAdd(out_gamma + c, total * inv_std[c]);
+    unsafeAtomicAdd(out_gamma + c, total_acc * inv_std[c]);
     unsafeAtomicAdd(out_beta + c, total_plain);
   }
 }
@@ -333,10 +341,19 @@ int srgan_bn_act_bwd(const float* g, const float* x, const float* mean, const fl
   const int64_t dense = (int64_t)C * HW;
   const int64_t g_bs = g_batch_stride ? g_batch_stride : dense, x_bs = x_batch_stride ? x_batch_stride : dense;
   const int64_t gx_bs = gx_batch_stride ? gx_batch_stride : dense;
-  if (relu) hipLaunchKernelGGL(bn_act_bwd_rows_kernel<true>, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mean,
-                               inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, g_bs, x_bs, gx_bs, accumulate_gx, unscaled);
-  else hipLaunchKernelGGL(bn_act_bwd_rows_kernel<false>, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mean,
-                          inv_std, gamma, beta, gx, g_gamma, g_beta, C, HW, g_bs, x_bs, gx_bs, accumulate_gx, unscaled);
+  // Images per workgroup: an HBM-bound pass wants ~10 MB in flight (2048 resident workgroups x 12 KB), and a
+  // workgroup at least a few iterations of work (4096 elements) to amortise its reduction and two atomics.
+  int per = 1;
+  while (per < N && ((int64_t)C * ((N + per - 1) / per) > 2048 || (int64_t)per * HW < 4096) &&
+         (int64_t)C * ((N + 2 * per - 1) / (2 * per)) >= 1024)
+    per *= 2;
+  const int blocks_n = (N + per - 1) / per;
+  if (relu) hipLaunchKernelGGL(bn_act_bwd_rows_kernel<true>, dim3(C, blocks_n), dim3(256), 0, (hipStream_t)stream, g, x,
+                               mean, inv_std, gamma, beta, gx, g_gamma, g_beta, N, C, HW, g_bs, x_bs, gx_bs, accumulate_gx,
+                               unscaled, per);
+  else hipLaunchKernelGGL(bn_act_bwd_rows_kernel<false>, dim3(C, blocks_n), dim3(256), 0, (hipStream_t)stream, g, x, mean,
+                          inv_std, gamma, beta, gx, g_gamma, g_beta, N, C, HW, g_bs, x_bs, gx_bs, accumulate_gx, unscaled,
+                          per);
   return launch_status();
 }
 
