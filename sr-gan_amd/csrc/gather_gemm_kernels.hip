@@ -553,6 +553,11 @@ static bool use_wgrad3x3(const ConvGeom& g, const float* x, const float* gy, int
   return force == 0 && conv3x3_wgrad_enabled() && wgrad3x3_geometry(g) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
 }
 
+bool pointwise_ksplit_wanted(int32_t N, int32_t K, int32_t M, int32_t HW, bool fused_bn);
+int pointwise_ksplit_run(const float* in, int64_t in_bs, const float* w, const float* bias, float* out, int64_t out_bs,
+                         int32_t N, int32_t K, int32_t M, int32_t HW, int accumulate, hipStream_t stream,
+                         const float* const* bn);
+
 bool pointwise_wgrad_enabled();
 int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
                         int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
@@ -671,6 +676,9 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_fwd geometry");
   SRGAN_REQUIRE(x && w && y, SRGAN_EINVAL, "srgan_conv2d_fwd pointers");
   SRGAN_REQUIRE(g.y_bs == (int64_t)g.K * g.OH * g.OW || true, SRGAN_EINVAL, "");
+  if (use_pointwise(g, g.K, force_kernel) && ((uintptr_t)w & 15) == 0 &&
+      pointwise_ksplit_wanted(g.N, g.C, g.K, g.H * g.W, false))
+    return pointwise_ksplit_run(x, g.x_bs, w, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream, nullptr);
   if (use_pointwise(g, g.K, force_kernel))
     return pointwise_run(x, g.x_bs, w, g.C, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream);
   if (use_conv3x3(g, g.K, force_kernel))
@@ -750,6 +758,9 @@ int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const s
   SRGAN_REQUIRE(x && w && y && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu pointers");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 0), SRGAN_EUNSUPPORTED, "srgan_conv2d_fwd_bnrelu geometry support");
   const float* const coefficients[4] = {bn->mean, bn->inv_std, bn->gamma, bn->beta};
+  if (pointwise(g) && ((uintptr_t)w & 15) == 0 && pointwise_ksplit_wanted(g.N, g.C, g.K, g.H * g.W, true))
+    return pointwise_ksplit_run(x, g.x_bs, w, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream,
+                                coefficients);
   if (pointwise(g))
     return pointwise_run(x, g.x_bs, w, g.C, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream,
                          coefficients);

@@ -89,6 +89,9 @@ CONV_CASES = [
     (3, 896, 16, 16, 448, 1, 1, (1, 1), (0, 0)),
     # data gradient with <= 128 output channels: the resident-weight kernel, remainder tiles of 96 / 64 rows
     (2, 224, 16, 16, 128, 1, 1, (1, 1), (0, 0)),
+    # few pixels, many input channels: the forward takes the kernel that splits K over the waves of a workgroup
+    (2, 288, 16, 16, 100, 1, 1, (1, 1), (0, 0)),
+    (4, 1024, 8, 8, 136, 1, 1, (1, 1), (0, 0)),
     (2, 192, 8, 32, 64, 1, 1, (1, 1), (0, 0)),
     # 3x3 / s1 / p1 shapes for the LDS-halo kernel (force = 0): all three channel-tile widths, ragged tiles,
     # fewer input channels than one chunk, split over input-channel chunks
@@ -373,7 +376,8 @@ def test_fused_batch_norm_convolutions(F):
     lib = _lib.library()
     stream = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator().manual_seed(23)
-    for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 32, 32, 16, 16, 8, 3),
+    for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 320, 352, 16, 16, 96, 1),
+                                      (1, 512, 512, 8, 8, 40, 1), (2, 32, 32, 16, 16, 8, 3),
                                       (2, 128, 128, 32, 32, 32, 3), (1, 70, 96, 20, 24, 40, 3)]:
         pad = r // 2
         wide = torch.randn(n, total, h, w, generator=gen)
