@@ -103,6 +103,7 @@ CONV_CASES = [
     (3, 200, 20, 24, 40, 3, 3, (1, 1), (1, 1)),      # LDS-patch weight gradient: ragged channel chunks and tiles
     (4, 3, 96, 96, 16, 7, 7, (2, 2), (3, 3)),        # stem: the 3-row image gradient takes the few-rows kernel
     (2, 5, 72, 72, 7, 3, 3, (1, 1), (1, 1)),         # 5 and 7 rows (MR = 8) in the few-rows kernel
+    (8, 2, 256, 128, 3, 2, 2, (2, 2), (0, 0)),       # weight gradient 3 x 8 over K = 65536 pixels: lanes-along-K kernel
 ]
 
 
