@@ -41,10 +41,14 @@ constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range w
 // PRO = frozen batch-norm + ReLU fused into the patch staging (reference crowd/models.py:342-345: norm2, relu2,
 // conv2): the (a, b) of the workgroup's input channels sit in a small LDS table and every patch element goes through
 // max(fma(x, a, b), 0) when it is written to LDS; padding stays exactly 0 (the reference pads the activated tensor).
-template <int BM, int TH, int CI_T, bool PRO>
+// TW = tile width: 32, or 16 for 16-pixel-wide images, where a 32-lane column block is two image rows of 16 pixels
+// (a 32-wide tile would leave half of every MFMA's columns outside the image).
+template <int BM, int TH, int CI_T, bool PRO, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
-  constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PHPW = PH * PW;
-  constexpr int MI = BM / 32, NI = TH / 4;        // each of the 4 waves owns NI image rows of 32 pixels
+  constexpr int RPB = 32 / TW;                    // image rows per 32-lane column block
+  constexpr int ROWS = TH * RPB;                  // image rows of the workgroup's tile
+  constexpr int PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
+  constexpr int MI = BM / 32, NI = TH / 4;        // each of the 4 waves owns NI column blocks
   constexpr int LDW = BM + 1;
   constexpr int PATCH = CI_T * PHPW, WTS = CI_T * 9 * BM;
   constexpr int NP = (PATCH + 255) / 256, NW = (WTS + 255) / 256;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
   const int tx = block % p.tiles_x; block /= p.tiles_x;
   const int ty = block % p.tiles_y;
   const int n = block / p.tiles_y;
-  const int m0 = tm * BM, y0 = ty * TH, x0 = tx * TW;
+  const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
   const int cbeg = (int)blockIdx.y * p.ci_per_split;
   const int cend = min(p.CI, cbeg + p.ci_per_split);
   const int HW = p.H * p.W;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
   // Per-lane LDS bases: the lane half selects the odd channel of a pair (constant offset), lanes 0..31 walk pixels
   // (B) or output channels (A); everything else below is a compile-time immediate.
   const float* a_base = wt + lhi * 9 * LDW + l31;
-  const float* b_base = patch + lhi * PHPW + (wave * NI) * PW + l31;
+  const float* b_base = patch + lhi * PHPW + ((wave * NI) * RPB + l31 / TW) * PW + l31 % TW;
 
   if (cbeg < cend) {
     fetch(cbeg);
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) a[mi] = a_cp[tap * LDW + mi * 32];
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) b[ni] = b_cp[(ni + kh) * PW + kw];
+          for (int ni = 0; ni < NI; ++ni) b[ni] = b_cp[(ni * RPB + kh) * PW + kw];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -186,11 +190,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
   }
 
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
-  const int x = x0 + l31;
+  const int x = x0 + l31 % TW;
   float* out_n = p.out + (int64_t)n * p.out_bs;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int y = y0 + wave * NI + ni;
+    const int y = y0 + (wave * NI + ni) * RPB + l31 / TW;
     if (y >= p.H || x >= p.W) continue;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -209,15 +213,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
   }
 }
 
-template <int BM, int CI_T>
-static void launch_conv3(const Conv3Params& p, int th, dim3 grid, hipStream_t stream) {
+template <int BM, int CI_T, int TW>
+static void launch_conv3_w(const Conv3Params& p, int th, dim3 grid, hipStream_t stream) {
   if (p.bn_mean) {
-    if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, true>), grid, dim3(256), 0, stream, p);
+    if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
   } else {
-    if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, false>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, false>), grid, dim3(256), 0, stream, p);
+    if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, false, TW>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, false, TW>), grid, dim3(256), 0, stream, p);
   }
+}
+
+template <int BM, int CI_T>
+static void launch_conv3(const Conv3Params& p, int th, int tw, dim3 grid, hipStream_t stream) {
+  if (tw == 16) launch_conv3_w<BM, CI_T, 16>(p, 4, grid, stream);      // 16-wide tiles always use 4 column blocks
+  else launch_conv3_w<BM, CI_T, 32>(p, th, grid, stream);
 }
 
 // Declared in gather_gemm_kernels.hip: records a launch for the bench's live event timing.
@@ -243,13 +253,17 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   p.in_bs = in_bs; p.out_bs = out_bs;
   p.debug = getenv("SRGAN_CONV3_DEBUG") ? atoi(getenv("SRGAN_CONV3_DEBUG")) : 0;
   p.w_so = w_so; p.w_si = w_si; p.w_skh = w_skh; p.w_skw = w_skw; p.w_base = w_base;
-  p.tiles_x = (W + 31) / 32;
+  const int tw = W <= 16 ? 16 : 32;      // 16-wide images: a 32-lane column block = two image rows (no dead columns)
+  p.tiles_x = (W + tw - 1) / tw;
   // Tile choice: the widest output-channel tile (fewest re-reads of the input patch) and the 8-row pixel tile, as
   // long as that still gives ~2 workgroups per CU; otherwise narrower / shorter tiles; input-channel splitting (fp32
   // atomics into a pre-zeroed output) only as the last resort and never below two chunks per workgroup.
   int bm = CO > 64 ? 128 : (CO > 32 ? 64 : 32);
-  int th = bm == 128 ? 4 : 8;            // 128 rows always use 4 pixel rows (64 accumulator registers per lane)
-  auto count = [&](int bm_, int th_) { return (int64_t)N * ((H + th_ - 1) / th_) * p.tiles_x * ((CO + bm_ - 1) / bm_); };
+  int th = (bm == 128 || tw == 16) ? 4 : 8;   // 128 rows / 16-wide tiles always use 4 column blocks per workgroup
+  auto rows = [&](int th_) { return th_ * (32 / tw); };
+  auto count = [&](int bm_, int th_) {
+    return (int64_t)N * ((H + rows(th_) - 1) / rows(th_)) * p.tiles_x * ((CO + bm_ - 1) / bm_);
+  };
   while (count(bm, th) < 512) {
     if (th == 8) th = 4;
     else if (bm > 32) { bm >>= 1; th = 4; }
@@ -257,7 +271,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   }
   const int ci_t = bm == 128 ? 4 : (bm == 64 ? 8 : 16);     // keeps the staged registers + accumulators <= 256
   p.tiles_m = (CO + bm - 1) / bm;
-  p.tiles_y = (H + th - 1) / th;
+  p.tiles_y = (H + rows(th) - 1) / rows(th);
   const int64_t blocks = count(bm, th);
   const int chunks = (CI + ci_t - 1) / ci_t;
   int split = 1;
@@ -279,9 +293,9 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);
   profile_bracket_begin(stream);
-  if (bm == 32) launch_conv3<32, 16>(p, th, grid, stream);
-  else if (bm == 64) launch_conv3<64, 8>(p, th, grid, stream);
-  else launch_conv3<128, 4>(p, 4, grid, stream);
+  if (bm == 32) launch_conv3<32, 16>(p, th, tw, grid, stream);
+  else if (bm == 64) launch_conv3<64, 8>(p, th, tw, grid, stream);
+  else launch_conv3<128, 4>(p, 4, tw, grid, stream);
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * H * W, (int64_t)CI * 9, 2, bm, th * 32, split);
   return status;
