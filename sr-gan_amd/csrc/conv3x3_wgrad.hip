@@ -220,8 +220,9 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   // walker so that the atomic pass (32 x 288 floats per workgroup) is amortised.
   static const int resident = getenv("SRGAN_WGRAD3_WGS") ? atoi(getenv("SRGAN_WGRAD3_WGS")) : 1024;
   static const int depth_override = getenv("SRGAN_WGRAD3_DEPTH") ? atoi(getenv("SRGAN_WGRAD3_DEPTH")) : 0;
-  // measured on 128 -> 32 channels, batch 16: 64x64 images best at 8 tiles per walker, 32x32 at 4, 16x16 at 1
-  const int depth = depth_override > 0 ? depth_override : (p.tiles >= 1024 ? 8 : (p.tiles >= 256 ? 4 : 1));
+  // measured on 128 -> 32 channels, batch 16: 64x64 images best at 8 tiles per walker, 32x32 at 4, 16x16 at 1 (batch
+  // 48 at 16x16 = 192 tiles: 48 us at depth 1 -- 768 workgroups x 9216 atomics -- so 4 from 128 tiles up)
+  const int depth = depth_override > 0 ? depth_override : (p.tiles >= 1024 ? 8 : (p.tiles >= 128 ? 4 : 1));
   int walkers = resident / (ci_chunks * co_chunks);
   if (walkers > (p.tiles + depth - 1) / depth) walkers = (p.tiles + depth - 1) / depth;
   if (walkers < 1) walkers = 1;
