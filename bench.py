@@ -43,6 +43,8 @@ def parse():
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-roofline', action='store_true')
     parser.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    parser.add_argument('--overlap-dnn', action='store_true',
+                        help='enqueue the DNN step on a second stream (faster step, per-kernel timings not attributable)')
     parser.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL)')
     parser.add_argument('--single-device', action='store_true',
                         help='testing aid: every rank uses cuda:0 (with --backend gloo on a one-GPU box)')
@@ -64,6 +66,7 @@ def build_experiment(args, dp):
     settings.gradient_penalty_multiplier, settings.map_multiplier = 1e2, 1e-3
     settings.learning_rate = 1e-4
     settings.reference_schedule = args.reference_schedule
+    settings.overlap_dnn_step = args.overlap_dnn
     experiment = CrowdExperiment(settings)
     experiment.dp = dp
     seed_all(0)

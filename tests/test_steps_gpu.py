@@ -226,14 +226,15 @@ def crowd_inputs(generator, batch, size):
 @pytest.mark.parametrize('name,size,steps,reference_schedule', [
     ('g7b_crowd64', 64, 2, False), ('g7b_crowd64', 64, 1, True), ('g7c_crowd64_gp_active', 64, 1, False),
     ('g7c_crowd64_gp_active', 64, 1, True), ('g7_crowd224', 224, 1, False)])
-def test_crowd_steps(pkg, name, size, steps, reference_schedule):
+def test_crowd_steps(pkg, name, size, steps, reference_schedule, overlap=False):
     from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
     g = load_golden(name)
     batch = int(g['batch_size'])
     experiment = make_experiment(
         lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
         dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
-             gradient_penalty_multiplier=1e2, map_multiplier=1e-3, reference_schedule=reference_schedule), crowd=True)
+             gradient_penalty_multiplier=1e2, map_multiplier=1e-3, reference_schedule=reference_schedule,
+             overlap_dnn_step=overlap), crowd=True)
     scale = float(g['d_scale'])
     if scale != 1.0:
         with torch.no_grad():
@@ -312,3 +313,9 @@ def test_vgg224(pkg):
     check(result, golden_scalars(g, 0), 'vgg step 0')
     assert_close(experiment.labeled_features.cpu().numpy(), g['s0/labeled_features'], rtol=RTOL, atol=1e-4,
                  what='vgg features')
+
+
+def test_crowd_step_with_the_dnn_step_on_a_second_stream(pkg):
+    """settings.overlap_dnn_step: the DNN step enqueued on a side stream, concurrent with the GAN step -- same
+    results as the sequential order (golden g7b, two steps)."""
+    test_crowd_steps(pkg, 'g7b_crowd64', 64, 2, False, overlap=True)
