@@ -319,3 +319,23 @@ def test_crowd_step_with_the_dnn_step_on_a_second_stream(pkg):
     """settings.overlap_dnn_step: the DNN step enqueued on a side stream, concurrent with the GAN step -- same
     results as the sequential order (golden g7b, two steps)."""
     test_crowd_steps(pkg, 'g7b_crowd64', 64, 2, False, overlap=True)
+
+
+def test_crowd_step_at_the_benchmark_size_matches_the_oracle(pkg):
+    """512 x 512 (the bench.py configuration's image size; batch 1, i.e. 3 stacked examples through D): the five
+    logged losses and the post-Adam discriminator / generator weights against the CPU oracle.  Exercises every kernel
+    on the benchmark's plane sizes (128 ... 16 pixels) instead of the goldens' 64 / 224."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as entry
+    experiment, oracle = entry.step_against_oracle(512, 1, tag='crowd512')
+    for name, ours, theirs in (('D', experiment.D, oracle.D), ('G', experiment.G, oracle.G), ('DNN', experiment.DNN, oracle.DNN)):
+        reference = dict(theirs.named_parameters())
+        for pname, p in ours.named_parameters():
+            expected = reference[pname].detach().numpy()
+            got = p.detach().cpu().numpy()
+            # Adam's first step moves every element by ~lr * sign(gradient): elements whose gradient is at rounding
+            # level may differ by two learning rates; the bulk must agree.
+            assert np.abs(got - expected).max() <= 2.2e-4 + 1e-3 * np.abs(expected).max(), f'{name} {pname}'
+            assert np.abs(got - expected).mean() <= 2e-5 + 1e-4 * np.abs(expected).mean(), f'{name} {pname} (mean)'
