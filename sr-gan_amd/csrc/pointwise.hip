@@ -253,7 +253,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
       if (mi > mi_cap) mi = mi_cap;
     }
   }
-  while (mi > 1 && col_blocks * ((CO + mi * 32 - 1) / (mi * 32)) < 1024) mi >>= 1;
+  static const int min_wgs = getenv("SRGAN_PW_MIN_WGS") ? atoi(getenv("SRGAN_PW_MIN_WGS")) : 1024;
+  while (mi > 1 && col_blocks * ((CO + mi * 32 - 1) / (mi * 32)) < min_wgs) mi >>= 1;
   // Rows beyond the last full 128-row tile go to a second launch with a tile just tall enough for them (the data
   // gradients of the bottlenecks have 64 + 32*l rows: a padded 128-row tile would waste up to 3/8 of the matrix work).
   int rest = 0, rest_mi = 0;
@@ -267,8 +268,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   const int64_t blocks = col_blocks * p.tiles_m;
   const int slices = (CI + 63) / 64;
   int split = 1;
-  if (blocks < 768 && slices >= 2) {
-    split = (int)((1024 + blocks - 1) / blocks);
+  if (blocks < (min_wgs * 3) / 4 && slices >= 2) {
+    split = (int)((min_wgs + blocks - 1) / blocks);
     if (split > slices) split = slices;
     if (split < 1) split = 1;
   }

@@ -372,6 +372,28 @@ def test_adam_matches_torch(F):
 
 
 @gpu
+def test_row_stacking_ops(F):
+    """cat_rows / narrow_rows (the stacked discriminator pass): values, views and both gradients."""
+    from srgan_amd.tape import backward
+    gen = torch.Generator().manual_seed(31)
+    a, b = torch.randn(3, 4, 5, generator=gen), torch.randn(2, 4, 5, generator=gen)
+    av, bv = F.leaf(dev(a), requires_grad=True), F.leaf(dev(b), requires_grad=True)
+    stacked = F.cat_rows([av, bv])
+    close(stacked, torch.cat([a, b]), 0.0, 'cat_rows')
+    middle = F.narrow_rows(stacked, 1, 3)
+    close(middle, torch.cat([a, b])[1:4], 0.0, 'narrow_rows')
+    assert middle.data.data_ptr() == stacked.data.data_ptr() + 4 * 20        # a view, not a copy
+    cotangent = torch.randn(3, 4, 5, generator=gen)
+    backward(middle, grad=F.leaf(dev(cotangent)))
+    expected = torch.zeros(5, 4, 5)
+    expected[1:4] = cotangent
+    close(av.grad, expected[:3], 0.0, 'cat_rows / narrow_rows gradient (first part)')
+    close(bv.grad, expected[3:], 0.0, 'cat_rows / narrow_rows gradient (second part)')
+    with pytest.raises(ValueError):
+        F.narrow_rows(stacked, 4, 3)
+
+
+@gpu
 def test_fused_batch_norm_convolutions(F):
     """srgan_conv2d_fwd_bnrelu / srgan_conv2d_bwd_weight_bnrelu (normalisation evaluated inside the convolution
     kernels) against the two-step form relu(bn(x)) -> conv of torch, 1x1 and 3x3, dense and channel-slice inputs."""
