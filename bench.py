@@ -101,6 +101,40 @@ def pmc_traffic_per_launch():
         return None
 
 
+def hbm_kernel_rates(experiment):
+    """The HBM-bound pieces of the step, timed live with events on the launch stream and priced on their
+    ALGORITHMIC bytes: the generator's Adam update (16 B read + 12 B written per parameter) and the
+    one-pass batch-norm backward on a dense-block-3 sized tensor (g and x read, gx written: 12 B per element)."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd import _lib
+    lib = _lib.library()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn, reps):
+        fn()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(reps):
+            fn()
+        stop.record()
+        stop.synchronize()
+        return start.elapsed_time(stop) / reps * 1e-3
+    optimizer = experiment.g_optimizer
+    params = optimizer.arena.numel
+    adam_s = timed(optimizer.step, 3)
+    n, c, hw = 16, 1024, 32 * 32
+    g, x, gx = (torch.randn(n, c, hw, device='cuda') for _ in range(3))
+    mean, inv, gamma, beta = (torch.rand(c, device='cuda') + 0.5 for _ in range(4))
+    grads = torch.zeros(2, c, device='cuda')
+    bn_s = timed(lambda: lib.srgan_bn_act_bwd(g.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(),
+                                             beta.data_ptr(), 1, gx.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                                             n, c, hw, 0, 0, 0, 0, 0, stream), 20)
+    return {'peak_GBps': 8000.0,
+            'adam': {'achieved_GBps': 28.0 * params / adam_s / 1e9, 'bytes_per_parameter': 28, 'parameters': params},
+            'batch_norm_backward': {'achieved_GBps': 12.0 * n * c * hw / bn_s / 1e9, 'bytes_per_element': 12,
+                                    'shape': [n, c, 32, 32]}}
+
+
 def usable_cores():
     """Host cores this process may actually use: the CPU affinity mask capped by the cgroup CPU quota (the GPU
     box exposes 256 logical CPUs under a 16-CPU quota; oversubscribing it stalls the oracle for hours)."""
@@ -239,6 +273,8 @@ def main():
             'logical_gflop_per_step': flops.value / 1e9, 'mfma_share_of_flops': mfma_flops.value / max(flops.value, 1.0),
             'avg_launch_us': 1e3 * kernel_ms.value / max(launches.value, 1),
         }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        result['hbm_kernels'] = hbm_kernel_rates(experiment)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args.image_size)
     if rank == 0:
