@@ -2,7 +2,7 @@
 
 ``image_size`` generalises the classifier's ``512*7*7`` input to ``512*(S/32)**2`` (SURVEY.md §8d config 2);
 at 224 it is the reference graph.  The (B, 1) un-squeezed output is kept as in the reference (Appendix A.12).
-Pretrained-weight download is unavailable offline; ``pretrained=True`` raises."""
+Pretrained weights are never downloaded: ``pretrained`` takes a state dict / path (see ``vgg16``)."""
 import math
 
 from torch import nn as torch_nn
@@ -64,7 +64,26 @@ class VGG(nn.Module):
                 m.bias.data.zero_()
 
 
+VGG16_WEIGHTS_ENV = 'SRGAN_VGG16_WEIGHTS'
+
+
 def vgg16(pretrained=False, **kwargs):
+    """reference age/vgg.py:151-162.  ``pretrained``: a torchvision vgg16 state dict, a path to one, or True = the path
+    in SRGAN_VGG16_WEIGHTS (no download here).  As in the reference the dict is applied with ``strict=False`` to
+    modules named ``feature_layers`` / ``classifier`` / ``final_layer``, so of torchvision's keys (``features.*``,
+    ``classifier.{0,3,6}.*``) only ``classifier.0`` lands -- a reference quirk reproduced as is."""
+    import os
     if pretrained:
-        raise RuntimeError('pretrained VGG-16 weights need a download; load a checkpoint with load_state_dict')
-    return VGG(make_layers(cfg['D']), **kwargs)
+        kwargs['init_weights'] = False
+    model = VGG(make_layers(cfg['D']), **kwargs)
+    if pretrained:
+        source = pretrained
+        if source is True:
+            source = os.environ.get(VGG16_WEIGHTS_ENV)
+            if not source:
+                raise RuntimeError(f'pretrained=True needs the torchvision vgg16 state dict on disk: set {VGG16_WEIGHTS_ENV}')
+        if isinstance(source, (str, os.PathLike)):
+            import torch
+            source = torch.load(source, map_location='cpu')
+        model.load_state_dict(source, strict=False)
+    return model

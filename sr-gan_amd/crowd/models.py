@@ -105,8 +105,6 @@ class KnnDenseNetCat(nn.Module):
     def __init__(self, growth_rate=32, block_config=(6, 12, 48, 32), num_init_features=64, bn_size=4, drop_rate=0,
                  pretrained=False, label_patch_size=224, image_size=None):
         super().__init__()
-        if pretrained:
-            raise RuntimeError('torchvision densenet201 weights need a download; use load_state_dict instead')
         image_size = image_size or label_patch_size
         self.label_patch_size = image_size
         self.dense_blocks = nn.ModuleList()
@@ -137,6 +135,8 @@ class KnnDenseNetCat(nn.Module):
                 m.bias.data.zero_()
             elif isinstance(m, torch_nn.Linear):
                 m.bias.data.zero_()
+        if pretrained:      # the trunk only, before the heads exist -- as in the reference (crowd/models.py:1103-1129)
+            self.load_torchvision_densenet201(pretrained)
         self.map_module1 = MapModule(in_features=widths[0], input_size=image_size // 8, label_size=image_size)
         self.map_module2 = MapModule(in_features=widths[1], input_size=image_size // 16, label_size=image_size)
         self.map_module3 = MapModule(in_features=widths[2], input_size=image_size // 32, label_size=image_size)
@@ -145,6 +145,46 @@ class KnnDenseNetCat(nn.Module):
         self.final_pool_size = image_size // 32
         self.features = None
         self._density_cache = None
+
+    TORCHVISION_WEIGHTS_ENV = 'SRGAN_DENSENET201_WEIGHTS'
+
+    @staticmethod
+    def rename_torchvision_keys(state_dict):
+        """torchvision ``densenet201`` state-dict keys -> this trunk's keys (reference crowd/models.py:1103-1127):
+        old checkpoints spell dense-layer members ``norm.1`` / ``conv.2`` (dots are no longer legal in module names)
+        -> ``norm1`` / ``conv2``; ``features.denseblockN`` -> ``dense_blocks.denseblockN``; ``features.transitionN``
+        -> ``transition_layers.transitionN``; ``features.norm5`` -> ``norm5``; the other ``features.*`` (stem) ->
+        ``conv_layer1.*``; the ImageNet classifier is dropped."""
+        import re
+        legacy = re.compile(r'^(.*denselayer\d+\.(?:norm|relu|conv))\.((?:[12])\.(?:weight|bias|running_mean|running_var))$')
+        renamed = OrderedDict()
+        for key, value in state_dict.items():
+            if key.startswith('classifier.'):
+                continue
+            match = legacy.match(key)
+            if match:
+                key = match.group(1) + match.group(2)
+            key = key.replace('features.denseblock', 'dense_blocks.denseblock')
+            key = key.replace('features.transition', 'transition_layers.transition')
+            key = key.replace('features.', '') if 'norm5' in key else key.replace('features.', 'conv_layer1.')
+            renamed[key] = value
+        return renamed
+
+    def load_torchvision_densenet201(self, source=True):
+        """Loads ImageNet densenet201 weights into the trunk (strictly: every trunk tensor must be present).
+        ``source``: a state dict, a path to one saved with ``torch.save``, or True = the path in the environment
+        variable SRGAN_DENSENET201_WEIGHTS (this build never downloads: there is no network on the training boxes)."""
+        import os
+        if source is True:
+            source = os.environ.get(self.TORCHVISION_WEIGHTS_ENV)
+            if not source:
+                raise RuntimeError('pretrained=True needs the torchvision densenet201 state dict on disk: set '
+                                   f'{self.TORCHVISION_WEIGHTS_ENV} to its path (the reference downloads it, '
+                                   'crowd/models.py:1110; this build does not touch the network)')
+        if isinstance(source, (str, os.PathLike)):
+            import torch
+            source = torch.load(source, map_location="cpu")
+        self.load_state_dict(self.rename_torchvision_keys(source), strict=True)
 
     def _density(self, batch_size, like):
         cache = self._density_cache
