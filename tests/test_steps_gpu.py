@@ -339,3 +339,52 @@ def test_crowd_step_at_the_benchmark_size_matches_the_oracle(pkg):
             # level may differ by two learning rates; the bulk must agree.
             assert np.abs(got - expected).max() <= 2.2e-4 + 1e-3 * np.abs(expected).max(), f'{name} {pname}'
             assert np.abs(got - expected).mean() <= 2e-5 + 1e-4 * np.abs(expected).mean(), f'{name} {pname} (mean)'
+
+
+def test_training_loop_and_checkpoint_interchange(pkg, tmp_path):
+    """H1 (srgan.py:52-129): ``Experiment.train()`` end to end on the coefficient task -- loop, learning-rate
+    schedule, validation summaries, ``model_<step>.pth`` -- then the checkpoint loads (strictly) into the oracle's
+    plain-torch modules and reproduces the predictions on the CPU, and a second experiment continues from it."""
+    import os
+    from srgan_amd.settings import Settings
+    from srgan_amd.coefficient.srgan import CoefficientExperiment
+    from srgan_amd.srgan import as_var
+    from srgan_amd.tape import no_grad
+    from oracle import models as OM
+
+    def settings(steps):
+        s = Settings()
+        s.trial_name, s.logs_directory = 'loop', str(tmp_path)
+        s.steps_to_run, s.summary_step_period = steps, 3
+        s.batch_size, s.labeled_dataset_size, s.unlabeled_dataset_size, s.validation_dataset_size = 64, 128, 512, 64
+        s.gradient_penalty_multiplier = 1e1
+        s.skip_completed_experiment = False
+        return s
+    first = CoefficientExperiment(settings(6))
+    first.train()
+    checkpoint_path = os.path.join(first.trial_directory, 'model_6.pth')
+    assert os.path.exists(checkpoint_path)
+    checkpoint = torch.load(checkpoint_path, map_location='cpu')
+    assert set(checkpoint) == {'DNN', 'dnn_optimizer', 'D', 'd_optimizer', 'G', 'g_optimizer', 'step'}
+    assert checkpoint['d_optimizer']['state'][0]['step'] == 6 and checkpoint['step'] == 6
+    tags = first.gan_summary_writer.scalars
+    assert '1 Validation Error/MAE' in tags and 'Discriminator/Gradient Penalty' in tags
+    # the reference-side modules accept the checkpoint as is
+    oracle_d, oracle_g = OM.CoefficientMLP(10), OM.CoefficientGenerator(10)
+    oracle_d.load_state_dict(checkpoint['D'], strict=True)
+    oracle_g.load_state_dict(checkpoint['G'], strict=True)
+    examples = torch.from_numpy(first.validation_dataset.examples.astype(np.float32))
+    with no_grad():
+        ours = first.D(as_var(examples)).cpu().numpy()
+    assert_close(ours, oracle_d(examples).detach().numpy(), rtol=1e-4, atol=1e-5, what='D predictions from the checkpoint')
+    reference_optimizer = torch.optim.Adam(oracle_d.parameters(), lr=1e-4)
+    reference_optimizer.load_state_dict(checkpoint['d_optimizer'])          # torch.optim.Adam-compatible
+    # continue the same trial: weights, Adam moments and the step counter come back
+    resumed_settings = settings(8)
+    resumed_settings.trial_name = os.path.basename(first.trial_directory)
+    resumed_settings.continue_existing_experiments = True
+    second = CoefficientExperiment(resumed_settings)
+    second.train()
+    assert second.starting_step == 7
+    assert second.d_optimizer.step_count == 6 + 1            # steps 7 .. 7 (steps_to_run = 8 is exclusive)
+    assert os.path.exists(os.path.join(second.trial_directory, 'model_8.pth'))
