@@ -583,9 +583,44 @@ def g8b_vgg():
     save('g8b_vgg224', **out)
 
 
+def g9_crowd_sliding_window():
+    """``CrowdExperiment.predict_full_example`` (crowd/srgan.py:332-395) -- sliding-window patches
+    of a full image through the discriminator, per-pixel averaging of the overlapping predictions.  The reference
+    resizes each predicted density patch with ``scipy.misc.imresize`` (removed from SciPy); here the prediction
+    already has the patch size, where that call is the identity, so the stand-in below only accepts that case."""
+    import scipy.misc
+    from crowd.srgan import CrowdExperiment
+    from crowd.data import CrowdExample
+
+    def imresize_identity(array, size, mode=None):
+        assert tuple(array.shape) == tuple(size) and mode == 'F'
+        return np.asarray(array, dtype=np.float32)
+    scipy.misc.imresize = imresize_identity
+    size = 64
+    experiment = _image_experiment(_crowd_builders(size), 4, CROWD_MULTIPLIERS, crowd=True)
+    experiment.settings.image_patch_size = size
+    experiment.settings.test_sliding_window_size = 24
+    experiment.settings.number_of_data_workers = 0
+    experiment.settings.pin_memory = False
+    for module in (experiment.D, experiment.DNN, experiment.G):
+        module.eval()
+    generator = np.random.RandomState(5)
+    out = {'image_size': np.array(size), 'window_step': np.array(24), 'batch_size': np.array(4)}
+    out.update(checksum_arrays('init_ck/D', experiment.D))
+    for index, shape in enumerate([(100, 150), (64, 64), (40, 90)]):     # larger, exact and smaller than a patch
+        image = generator.randint(0, 256, size=shape + (3,)).astype(np.uint8)
+        example = CrowdExample(image=image, label=np.zeros(shape, dtype=np.float32))
+        with torch.no_grad():
+            count, label = CrowdExperiment.predict_full_example(experiment, example, experiment.D)
+        out[f'e{index}/image'] = image
+        out[f'e{index}/count'] = np.array(count, dtype=np.float64)
+        out[f'e{index}/label_abs_sum'] = np.array(np.abs(label).sum(), dtype=np.float64)
+    save('g9_crowd_sliding_window', **out)
+
+
 ALL = {'g0': g0_toydata, 'g1': g1_distance, 'g2': g2_sgan_math, 'g3': g3_coefficient_srgan,
        'g4': g4_coefficient_sgan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
-       'g8b': g8b_vgg}
+       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window}
 
 if __name__ == '__main__':
     wanted = sys.argv[1:] or ['all']

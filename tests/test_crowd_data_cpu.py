@@ -1,0 +1,23 @@
+"""Host-side sliding-window bookkeeping of the crowd inference path (sr-gan_amd/crowd/data.py; reference
+crowd/data.py:370-453,521-560).  The end-to-end result is pinned on the GPU against golden g9."""
+import numpy as np
+
+
+def test_sliding_window_positions_and_padding():
+    import srgan_amd  # noqa: F401
+    from srgan_amd.crowd.data import CrowdExample, ImageSlidingWindowDataset, extract_padded_patch, negative_one_to_one
+    image = np.arange(100 * 150 * 3, dtype=np.int64).reshape(100, 150, 3) % 256
+    image = image.astype(np.uint8)
+    dataset = ImageSlidingWindowDataset(CrowdExample(image=image), image_patch_size=64, window_step_size=24)
+    assert dataset.y_positions == [32, 56, 68] and dataset.x_positions == [32, 56, 80, 104, 118]
+    assert len(dataset) == 15
+    patch, x, y = dataset[7]                     # row 1, column 2
+    assert (x, y) == (80, 56) and tuple(patch.shape) == (3, 64, 64)
+    expected = negative_one_to_one(image[56 - 32:56 + 32, 80 - 32:80 + 32]).transpose(2, 0, 1)
+    np.testing.assert_array_equal(patch.numpy(), expected)
+    # a centre closer than half a patch to the top-left corner: zero padding, centre moved
+    small = np.full((40, 90, 3), 200, dtype=np.uint8)
+    padded = extract_padded_patch(small, 8, 32, 64)
+    assert padded.shape == (64, 64, 3)
+    assert (padded[:24] == 0).all() and (padded[24:] == 200).all()        # 32 - 8 rows of padding on top
+    assert float(negative_one_to_one(np.array([[[0, 255, 127]]], dtype=np.uint8)).min()) == -1.0

@@ -388,3 +388,33 @@ def test_training_loop_and_checkpoint_interchange(pkg, tmp_path):
     assert second.starting_step == 7
     assert second.d_optimizer.step_count == 6 + 1            # steps 7 .. 7 (steps_to_run = 8 is exclusive)
     assert os.path.exists(os.path.join(second.trial_directory, 'model_8.pth'))
+
+
+def test_crowd_sliding_window_inference(pkg):
+    """``CrowdExperiment.predict_full_example`` against the reference's own function (golden g9:
+    images larger than, equal to and smaller than one patch; window step 24, batches of 4)."""
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
+    from srgan_amd.crowd.data import CrowdExample, ImageSlidingWindowDataset
+    g = load_golden('g9_crowd_sliding_window')
+    size = int(g['image_size'])
+    experiment = make_experiment(
+        lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
+        dict(batch_size=int(g['batch_size']), image_patch_size=size, test_sliding_window_size=int(g['window_step'])),
+        crowd=True)
+    for pname, p in experiment.D.named_parameters():
+        assert_close(checksum(p), g[f'init_ck/D/{pname}'], rtol=1e-9, atol=1e-12, what=f'init {pname}')
+    finish_setup(experiment)
+    experiment.eval_mode()
+    for index in range(3):
+        image = g[f'e{index}/image']
+        example = CrowdExample(image=image, label=np.zeros(image.shape[:2], dtype=np.float32))
+        count, density = experiment.predict_full_example(example, experiment.D)
+        assert density.shape == image.shape[:2]
+        assert_close(count, float(g[f'e{index}/count']), rtol=RTOL, what=f'example {index} count')
+        assert_close(float(np.abs(density).sum()), float(g[f'e{index}/label_abs_sum']), rtol=RTOL, atol=1e-6,
+                     what=f'example {index} density')
+    # window bookkeeping: a 40 x 90 image with 64-pixel patches has one (padded) row of centres
+    dataset = ImageSlidingWindowDataset(CrowdExample(image=g['e2/image']), size, int(g['window_step']))
+    assert dataset.y_positions == [8] and dataset.x_positions == [32, 56, 58]
+    patch, x, y = dataset[0]
+    assert tuple(patch.shape) == (3, size, size) and float(patch.min()) >= -1.0 and float(patch.max()) <= 1.0
