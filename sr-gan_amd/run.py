@@ -11,6 +11,7 @@ from .age.sgan import AgeSganExperiment
 from .age.srgan import AgeExperiment
 from .coefficient.sgan import CoefficientSganExperiment
 from .coefficient.srgan import CoefficientExperiment
+from .crowd.dnn import CrowdDnnExperiment
 from .crowd.srgan import CrowdExperiment
 from .driving.srgan import DrivingExperiment
 from .settings import Settings, convert_to_settings_list, ApplicationName, MethodName
@@ -46,7 +47,7 @@ def build_settings(application_name, method_name):
         settings_.labeled_dataset_size = [500]
         settings_.gradient_penalty_multiplier = 1e1
     elif application_name == ApplicationName.crowd:
-        experiment_class = {MethodName.srgan: CrowdExperiment}[method_name]
+        experiment_class = {MethodName.srgan: CrowdExperiment, MethodName.dnn: CrowdDnnExperiment}[method_name]
         settings_.matching_loss_multiplier = [1e3]
         settings_.contrasting_loss_multiplier = [1e2]
         settings_.batch_size = 15

@@ -418,3 +418,50 @@ def test_crowd_sliding_window_inference(pkg):
     assert dataset.y_positions == [8] and dataset.x_positions == [32, 56, 58]
     patch, x, y = dataset[0]
     assert tuple(patch.shape) == (3, size, size) and float(patch.min()) >= -1.0 and float(patch.max()) <= 1.0
+
+
+def test_dnn_only_experiment(pkg, tmp_path):
+    """SURVEY.md 8(f) N3, the DNN method (reference dnn.py:15-100, crowd/dnn.py:20): the DNN-only loop end to end on the
+    coefficient task (checkpoint with the reference's three keys), and the crowd mix-in's step equal to the DNN step of
+    the full crowd experiment on identical weights."""
+    import os
+    from srgan_amd.settings import Settings
+    from srgan_amd.coefficient.dnn import CoefficientDnnExperiment
+    from srgan_amd.crowd.dnn import CrowdDnnExperiment
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
+    from srgan_amd.utility import SummaryWriter, seed_all
+    s = Settings()
+    s.trial_name, s.logs_directory, s.steps_to_run, s.summary_step_period = 'dnn', str(tmp_path), 5, 2
+    s.batch_size, s.labeled_dataset_size, s.unlabeled_dataset_size, s.validation_dataset_size = 64, 128, 512, 64
+    s.skip_completed_experiment = False
+    experiment = CoefficientDnnExperiment(s)
+    experiment.train()
+    checkpoint = torch.load(os.path.join(experiment.trial_directory, 'model_5.pth'), map_location='cpu')
+    assert set(checkpoint) == {'DNN', 'dnn_optimizer', 'step'}
+    assert experiment.D is None and experiment.G is None
+    assert '1 Validation Error/MAE' in experiment.dnn_summary_writer.scalars
+    losses = [v for _, v in experiment.dnn_summary_writer.scalars['Discriminator/Labeled Loss']]
+    assert len(losses) >= 2 and all(np.isfinite(losses))
+    # crowd: same DNN weights, same batch -> same loss and same updated weights as the full experiment's DNN step
+    size = 64
+    full = make_experiment(
+        lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
+        dict(batch_size=2, map_multiplier=1e-3), crowd=True)
+    crowd_settings = Settings()
+    crowd_settings.batch_size, crowd_settings.image_patch_size, crowd_settings.map_multiplier = 2, size, 1e-3
+    alone = CrowdDnnExperiment(crowd_settings)
+    seed_all(0)
+    alone.model_setup()
+    alone.DNN.load_state_dict(full.DNN.state_dict())
+    alone.dnn_summary_writer = SummaryWriter()
+    finish_setup(full)
+    alone.prepare_optimizers()
+    alone.train_mode()
+    generator = torch.Generator().manual_seed(3)
+    x, y, _ = crowd_inputs(generator, 2, size)
+    full.dnn_training_step(x.cuda(), tuple(t.cuda() for t in y), 0)
+    alone.dnn_training_step(x.cuda(), tuple(t.cuda() for t in y), 0)
+    assert_close(alone.dnn_summary_writer.scalars['Discriminator/Labeled Loss'][-1][1],
+                 full.dnn_summary_writer.scalars['Discriminator/Labeled Loss'][-1][1], rtol=1e-6, what='DNN loss')
+    for (name, ours), (_, theirs) in zip(alone.DNN.named_parameters(), full.DNN.named_parameters()):
+        assert_close(ours.detach().cpu().numpy(), theirs.detach().cpu().numpy(), rtol=1e-5, atol=2.2e-4, what=name)
