@@ -24,6 +24,8 @@ class AgeExperiment(Experiment):
                                                            seed=settings.labeled_dataset_seed, dp=self.dp)
         self.unlabeled_dataset_loader = SyntheticLoader.images(settings.batch_size, self._size(), (10.0, 95.0),
                                                                seed=100, dp=self.dp)
+        self.validation_dataset_loader = SyntheticLoader.images(settings.batch_size, self._size(), (10.0, 95.0),
+                                                                seed=101, dp=self.dp, pool=1)
 
     def model_setup(self):
         """reference age/srgan.py:42-51 (``pretrained=True`` VGG weights need a download: load a checkpoint)."""
@@ -38,4 +40,5 @@ class AgeExperiment(Experiment):
             self.DNN = Discriminator(image_size=size)
 
     def validation_summaries(self, step):
-        pass
+        """MAE / MSE of DNN and D on the train and validation batches (reference age/srgan.py:52-71,92-107)."""
+        self.regression_validation_summaries()

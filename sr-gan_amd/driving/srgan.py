@@ -18,6 +18,8 @@ class DrivingExperiment(Experiment):
                                                            seed=settings.labeled_dataset_seed, dp=self.dp)
         self.unlabeled_dataset_loader = SyntheticLoader.images(settings.batch_size, self.image_size, (-angle, angle),
                                                                seed=100, dp=self.dp)
+        self.validation_dataset_loader = SyntheticLoader.images(settings.batch_size, self.image_size, (-angle, angle),
+                                                                seed=101, dp=self.dp, pool=1)
 
     def model_setup(self):
         self.G = Generator(image_size=self.image_size)
@@ -25,4 +27,5 @@ class DrivingExperiment(Experiment):
         self.DNN = Discriminator(image_size=self.image_size)
 
     def validation_summaries(self, step):
-        pass
+        """MAE / NMAE / MSE of DNN and D on the train and validation batches (reference driving/srgan.py:48-67,87-104)."""
+        self.regression_validation_summaries(normalized=True)

@@ -543,6 +543,40 @@ class Experiment(ABC):
         self.load_models(with_optimizers=False)
         self.eval_mode()
 
+    def regression_evaluation_epoch(self, network, dataset, summary_writer, summary_name, comparison_value=None,
+                                    normalized=False):
+        """MAE / MSE (and NMAE = MAE / label range with ``normalized``) of ``network`` over ``dataset`` -- any
+        iterable of ``(examples, labels)`` batches -- as summary scalars; ratio to ``comparison_value`` (the DNN's MAE)
+        when given.  Forward passes only (reference age/srgan.py:92-107, driving/srgan.py:87-104)."""
+        predictions, labels = [], []
+        self.join_dnn_stream()
+        with no_grad():
+            for examples, batch_labels in dataset:
+                predicted = network(as_var(examples))
+                predictions.append(predicted.cpu().numpy().reshape(-1).astype(np.float64))
+                labels.append(np.asarray(batch_labels.cpu() if hasattr(batch_labels, 'cpu') else batch_labels,
+                                         dtype=np.float64).reshape(-1))
+        predictions, labels = np.concatenate(predictions), np.concatenate(labels)
+        mae = float(np.abs(predictions - labels).mean())
+        summary_writer.add_scalar('{}/MAE'.format(summary_name), mae)
+        if normalized:
+            summary_writer.add_scalar('{}/NMAE'.format(summary_name), mae / float(labels.max() - labels.min()))
+        summary_writer.add_scalar('{}/MSE'.format(summary_name), float((np.abs(predictions - labels) ** 2).mean()))
+        if comparison_value is not None:
+            summary_writer.add_scalar('{}/Ratio MAE GAN DNN'.format(summary_name), mae / comparison_value)
+        return mae
+
+    def regression_validation_summaries(self, normalized=False):
+        """DNN and D on the train and validation batches, D's validation MAE relative to the DNN's (reference
+        age/srgan.py:52-71, driving/srgan.py:48-67; the image grids are out of scope)."""
+        train, validation = self.train_dataset_loader, self.validation_dataset_loader
+        self.regression_evaluation_epoch(self.DNN, train, self.dnn_summary_writer, '2 Train Error', normalized=normalized)
+        dnn_mae = self.regression_evaluation_epoch(self.DNN, validation, self.dnn_summary_writer, '1 Validation Error',
+                                                   normalized=normalized)
+        self.regression_evaluation_epoch(self.D, train, self.gan_summary_writer, '2 Train Error', normalized=normalized)
+        self.regression_evaluation_epoch(self.D, validation, self.gan_summary_writer, '1 Validation Error',
+                                         comparison_value=dnn_mae, normalized=normalized)
+
     @staticmethod
     def infinite_iter(dataset):
         while True:

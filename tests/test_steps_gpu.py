@@ -465,3 +465,33 @@ def test_dnn_only_experiment(pkg, tmp_path):
                  full.dnn_summary_writer.scalars['Discriminator/Labeled Loss'][-1][1], rtol=1e-6, what='DNN loss')
     for (name, ours), (_, theirs) in zip(alone.DNN.named_parameters(), full.DNN.named_parameters()):
         assert_close(ours.detach().cpu().numpy(), theirs.detach().cpu().numpy(), rtol=1e-5, atol=2.2e-4, what=name)
+
+
+def test_regression_evaluation_epochs(pkg):
+    """the age / driving evaluation epochs (forward passes only): MAE / MSE / NMAE / the GAN-to-DNN
+    ratio as summary scalars, checked against the oracle's plain-torch discriminator on the CPU."""
+    from srgan_amd.settings import Settings
+    from srgan_amd.driving.srgan import DrivingExperiment
+    from srgan_amd.utility import SummaryWriter, seed_all
+    from oracle import models as OM
+    s = Settings()
+    s.batch_size = 8
+    experiment = DrivingExperiment(s)
+    experiment.image_size = 64
+    seed_all(0)
+    experiment.dataset_setup()
+    experiment.model_setup()
+    finish_setup(experiment)
+    experiment.dnn_summary_writer, experiment.gan_summary_writer = SummaryWriter(), SummaryWriter()
+    experiment.eval_mode()
+    experiment.validation_summaries(0)
+    gan, dnn = experiment.gan_summary_writer.scalars, experiment.dnn_summary_writer.scalars
+    for tag in ('1 Validation Error/MAE', '1 Validation Error/NMAE', '1 Validation Error/MSE', '2 Train Error/MAE'):
+        assert tag in gan and tag in dnn, tag
+    oracle_d = OM.DCGANDiscriminator(64)
+    oracle_d.load_state_dict(experiment.D.state_dict())
+    images, angles = experiment.validation_dataset_loader.batches[0]
+    expected = float((oracle_d(images.cpu()).detach().reshape(-1) - angles.cpu()).abs().mean())
+    assert_close(gan['1 Validation Error/MAE'][-1][1], expected, rtol=RTOL, what='D validation MAE')
+    ratio = gan['1 Validation Error/MAE'][-1][1] / dnn['1 Validation Error/MAE'][-1][1]
+    assert_close(gan['1 Validation Error/Ratio MAE GAN DNN'][-1][1], ratio, rtol=1e-9, what='ratio')
