@@ -6,10 +6,13 @@ template <int ACC>
 __global__ __launch_bounds__(256) void peak(float* out, int iters, float a0, float b0) {
   f32x16 acc[ACC];
   for (int i = 0; i < ACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  float a = a0 + threadIdx.x, b = b0;
+  // operands: 'random-looking' per-lane values (data-dependent power: constant operands clock higher)
+  const unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+  float a = a0 * ((float)((h >> 8) & 0xffff) / 32768.f - 1.f), b = b0 * ((float)((h >> 12) & 0xffff) / 32768.f - 1.f);
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    a = -a;     // keeps the accumulators bounded and the operand bits toggling
   }
   float s = 0.f;
   for (int i = 0; i < ACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
