@@ -188,23 +188,24 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   if (!live) return;
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
   float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
+  // Three straight-line passes selected once (store / accumulate / atomic): with the mode tested per element the
+  // 16 * MI stores of a lane are separated by branches and cannot be issued back to back.
+  auto emit = [&](auto&& write) {
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (o >= p.CO) continue;
-      const float bias = add_bias ? p.bias[o] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (o >= p.CO) continue;
+        const float bias = add_bias ? p.bias[o] : 0.f;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const float v = acc[mi][ni][r] + bias;
-        float* dst = out_lane + (int64_t)o * p.HW + 32 * ni;
-        if (p.mode == 0) *dst = v;
-        else if (p.mode == 1) *dst += v;
-        else unsafeAtomicAdd(dst, v);
+        for (int ni = 0; ni < NI; ++ni) write(out_lane + (int64_t)o * p.HW + 32 * ni, acc[mi][ni][r] + bias);
       }
     }
-  }
+  };
+  if (p.mode == 0) emit([](float* dst, float v) { *dst = v; });
+  else if (p.mode == 1) emit([](float* dst, float v) { *dst += v; });
+  else emit([](float* dst, float v) { unsafeAtomicAdd(dst, v); });
 }
 
 int profile_bracket_begin(hipStream_t stream);
