@@ -27,6 +27,8 @@ def test_oracle_is_only_used_as_the_checker():
     for name in os.listdir(ROOT):
         if name.endswith('.py') and name not in allowed:
             assert not pattern.search(open(os.path.join(ROOT, name)).read()), name
+    for path in python_files(os.path.join(ROOT, 'scratch')):
+        assert not pattern.search(open(path).read()), f'{path}: tuning aids must not use the oracle either'
     bench = open(os.path.join(ROOT, 'bench.py')).read()
     # in bench.py the oracle appears only inside the cpu_baseline leg
     for match in pattern.finditer(bench):
