@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
   const float os = unscaled ? 1.f : a;                        // output scale
   const int64_t plane = (int64_t)c * HW;
   float acc = 0.f, plain = 0.f;
+  const bool nontemporal_store = !accumulate;          // a fresh gradient tensor: consumed by a later kernel, not this one
   const bool vec = ((g_bs | x_bs | gx_bs | HW) & 3) == 0 &&
                    (((uintptr_t)g | (uintptr_t)x | (uintptr_t)gx) & 15) == 0;
   if (vec) {
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
     for (int idx = threadIdx.x; idx < total; idx += 256) {
       const int nl = idx / hw4, i = idx - nl * hw4;
       const int n = n0 + nl;
-      float4 gv = reinterpret_cast<const float4*>(g + (int64_t)n * g_bs + plane)[i];
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f graw = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g + (int64_t)n * g_bs + plane) + i);   // read once
+      float4 gv = make_float4(graw.x, graw.y, graw.z, graw.w);
       const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)n * x_bs + plane)[i];
       if (RELU) {
         gv.x = fmaf(xv.x, a, b) > 0.f ? gv.x : 0.f; gv.y = fmaf(xv.y, a, b) > 0.f ? gv.y : 0.f;
@@ -169,7 +172,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
         float4* o4 = reinterpret_cast<float4*>(gx + (int64_t)n * gx_bs + plane) + i;
         float4 o = make_float4(gv.x * os, gv.y * os, gv.z * os, gv.w * os);
         if (accumulate) { const float4 old = *o4; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-        *o4 = o;
+        if (nontemporal_store) {
+          v4f oraw; oraw.x = o.x; oraw.y = o.y; oraw.z = o.z; oraw.w = o.w;
+          __builtin_nontemporal_store(oraw, reinterpret_cast<v4f*>(o4));
+        } else {
+          *o4 = o;
+        }
       }
     }
   } else {
