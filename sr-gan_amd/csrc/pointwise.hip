@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
       }
     }
   };
-  if (p.mode == 0) emit([](float* dst, float v) { *dst = v; });
+  if (p.mode == 0) emit([](float* dst, float v) { __builtin_nontemporal_store(v, dst); });   // consumed by a later kernel
   else if (p.mode == 1) emit([](float* dst, float v) { *dst += v; });
   else emit([](float* dst, float v) { unsafeAtomicAdd(dst, v); });
 }
