@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
         float v = acc[mi][ni][r];
         if (add_bias) v += p.bias[o];
         float* dst = out_n + (int64_t)o * HW + y * p.W + x;
-        if (p.mode == 0) *dst = v;
+        if (p.mode == 0) __builtin_nontemporal_store(v, dst);      // consumed by a later kernel, not by this one
         else if (p.mode == 1) *dst += v;
         else unsafeAtomicAdd(dst, v);
       }

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void chan_affine_rows_kernel(const float* __re
       float v = fmaf(x ? x[xb + i] : 1.f, a, b);
       if (RELU) v = fmaxf(v, 0.f);
       if (mask) v = mask[mb + i] > 0.f ? v : 0.f;
-      y[yb + i] = accumulate ? y[yb + i] + v : v;
+      if (accumulate) y[yb + i] += v;
+      else __builtin_nontemporal_store(v, y + yb + i);
     }
   }
 }
