@@ -30,6 +30,7 @@ struct PointwiseParams {
   int64_t in_bs, out_bs;
   int32_t w_so, w_si;
   int32_t tiles_m;
+  int32_t xcd_remap;    // grid.x is a multiple of 8 and tiles_m > 1: XCD-aware workgroup order
   int32_t m_base;       // first output row of this launch (a second launch covers a shorter remainder tile)
   int32_t k_per_split;
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
@@ -51,8 +52,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: keeps the address bases scalar
-  const int tm = blockIdx.x % p.tiles_m;
-  const int64_t group = (int64_t)(blockIdx.x / p.tiles_m) * 4 + wave;     // this wave's NI adjacent 32-pixel groups
+  // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2),
+  // while the row tiles that share one activation column block have consecutive LOGICAL ids -- so logical id =
+  // (hardware id % 8) * (grid / 8) + hardware id / 8 keeps them on one XCD and the activations are fetched into one L2.
+  int bid = (int)blockIdx.x;
+  if (p.xcd_remap) bid = (bid & 7) * ((int)gridDim.x >> 3) + (bid >> 3);
+  const int tm = bid % p.tiles_m;
+  const int64_t group = (int64_t)(bid / p.tiles_m) * 4 + wave;           // this wave's NI adjacent 32-pixel groups
   const int64_t pixel0 = group * (32 * NI);
   const int64_t total = (int64_t)p.N * p.HW;
   const bool live = pixel0 < total;                                     // whole groups only (HW % (32 * NI) == 0)
@@ -300,10 +306,13 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
       else launch_pointwise<1, 32, 1>(p, grid, stream);
     }
   };
+  static const bool no_xcd = getenv("SRGAN_NO_XCD_ORDER") != nullptr;
+  p.xcd_remap = (!no_xcd && p.tiles_m > 1 && blocks % 8 == 0) ? 1 : 0;
   launch(mi, dim3((unsigned)blocks, (unsigned)split, 1));
   if (rest > 0) {
     p.m_base = main_rows;
     p.tiles_m = 1;
+    p.xcd_remap = 0;
     launch(rest_mi, dim3((unsigned)col_blocks, (unsigned)split, 1));
   }
   const int status = launch_status();
