@@ -107,23 +107,13 @@ int srgan_chan_affine(const float* x, const float* mean, const float* scale_a, c
 int srgan_chan_affine_act(const float* x, const float* mean, const float* scale_a, const float* scale_b,
                           const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C, int64_t HW,
                           void* stream);
-/* Both parameter gradients of a frozen batch-norm (optionally followed by ReLU, mask = its output) in one pass into
- * one [2, C] buffer: out[c] = inv_std[c] * sum g*[mask>0]*(x - mean[c]) (gamma), out[C + c] = sum g*[mask>0] (beta). */
-int srgan_bn_param_grads(const float* g, const float* x, const float* mask, const float* mean, const float* inv_std,
-                         float* g_gamma_beta, int32_t N, int32_t C, int64_t HW, void* stream);
-
-/* The same on channel-slice views: image n of x / mask / y starts at n * its batch stride (0 = dense), and
+/* srgan_chan_affine_act on channel-slice views: image n of x / mask / y starts at n * its batch stride (0 = dense), and
  * accumulate != 0 adds into y.  Used by the concat-free dense block: batch-norm reads a slice of the block
  * buffer; its input gradient is accumulated into a slice of the block's gradient buffer. */
 int srgan_chan_affine_act_strided(const float* x, const float* mean, const float* scale_a, const float* scale_b,
                                   const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C,
                                   int64_t HW, int64_t x_batch_stride, int64_t mask_batch_stride, int64_t y_batch_stride,
                                   int accumulate, void* stream);
-/* srgan_bn_param_grads, ADDED (fp32 atomics) into separate gamma / beta gradient buffers; x may be a view. */
-int srgan_bn_param_grads_accumulate(const float* g, const float* x, const float* mask, const float* mean,
-                                    const float* inv_std, float* g_gamma, float* g_beta, int32_t N, int32_t C,
-                                    int64_t HW, int64_t x_batch_stride, void* stream);
-
 /* Whole backward of frozen batch-norm (+ReLU when relu != 0) in one pass over (g, x): the activation mask is
  * recomputed from x (y = fma(x, a, b), a = inv_std*gamma, b = beta - mean*a, exactly the forward's arithmetic);
  * gx (=,+=) g*[y>0]*a (gx may be NULL; g / x / gx may be channel-slice views, batch stride 0 = dense; unscaled != 0

@@ -38,13 +38,11 @@ SIGNATURES = {
     'srgan_fill': ([vp, i64, f32, vp], ctypes.c_int),
     'srgan_chan_affine': ([vp, vp, vp, vp, vp, vp, i32, i32, i64, vp], ctypes.c_int),
     'srgan_chan_affine_act': ([vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, i32, i32, i64, vp], ctypes.c_int),
-    'srgan_bn_param_grads': ([vp, vp, vp, vp, vp, vp, i32, i32, i64, vp], ctypes.c_int),
     'srgan_chan_affine_act_strided': ([vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, i32, i32, i64, i64, i64, i64,
                                        ctypes.c_int, vp], ctypes.c_int),
     'srgan_bn_act_bwd': ([vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, i32, i32, i64, i64, i64, i64, ctypes.c_int,
                           ctypes.c_int, vp],
                          ctypes.c_int),
-    'srgan_bn_param_grads_accumulate': ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, vp], ctypes.c_int),
     'srgan_chan_reduce': ([vp, vp, vp, vp, vp, i32, i32, i64, ctypes.c_int, vp], ctypes.c_int),
     'srgan_row_max': ([vp, vp, i32, i32, vp], ctypes.c_int),
     'srgan_nearest_bin_onehot': ([vp, vp, vp, i32, i32, vp], ctypes.c_int),

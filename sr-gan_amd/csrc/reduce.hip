@@ -77,53 +77,6 @@ __global__ __launch_bounds__(256) void chan_reduce_block_kernel(const float* __r
   }
 }
 
-// Both batch-norm parameter gradients, one workgroup per (channel, image) row, float4 loads, two fp32 atomics per
-// workgroup into a pre-zeroed [2, C] buffer (out = gamma gradient, out + C = beta gradient).
-__global__ __launch_bounds__(256) void bn_param_grads_rows_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                                  const float* __restrict__ mask,
-                                                                  const float* __restrict__ mean,
-                                                                  const float* __restrict__ inv_std,
-                                                                  float* __restrict__ out_gamma,
-                                                                  float* __restrict__ out_beta, int C, int64_t HW,
-                                                                  int64_t x_bs) {
-  __shared__ float scratch[4];
-  const int c = blockIdx.x, n = blockIdx.y;
-  const int64_t base = ((int64_t)n * C + c) * HW;          // g and mask are dense
-  const int64_t xbase = (int64_t)n * x_bs + (int64_t)c * HW;  // x may be a channel-slice view
-  const float mu = mean ? mean[c] : 0.f;
-  float acc = 0.f, plain = 0.f;
-  if (((base | xbase) & 3) == 0 && (HW & 3) == 0) {
-    const float4* g4 = reinterpret_cast<const float4*>(g + base);
-    const float4* x4 = reinterpret_cast<const float4*>(x + xbase);
-    const float4* m4 = mask ? reinterpret_cast<const float4*>(mask + base) : nullptr;
-    for (int64_t i = threadIdx.x; i < (HW >> 2); i += 256) {
-      float4 gv = g4[i];
-      const float4 xv = x4[i];
-      if (m4) {
-        const float4 mv = m4[i];
-        gv.x = mv.x > 0.f ? gv.x : 0.f; gv.y = mv.y > 0.f ? gv.y : 0.f;
-        gv.z = mv.z > 0.f ? gv.z : 0.f; gv.w = mv.w > 0.f ? gv.w : 0.f;
-      }
-      acc += gv.x * (xv.x - mu) + gv.y * (xv.y - mu) + gv.z * (xv.z - mu) + gv.w * (xv.w - mu);
-      plain += gv.x + gv.y + gv.z + gv.w;
-    }
-  } else {
-    for (int64_t i = threadIdx.x; i < HW; i += 256) {
-      float gv = g[base + i];
-      if (mask) gv = mask[base + i] > 0.f ? gv : 0.f;
-      acc += gv * (x[xbase + i] - mu);
-      plain += gv;
-    }
-  }
-  const float total = block_sum_256(acc, scratch);
-  __syncthreads();
-  const float total_plain = block_sum_256(plain, scratch);
-  if (threadIdx.x == 0) {
-    unsafeAtomicAdd(out_gamma + c, total * (inv_std ? inv_std[c] : 1.f));
-    unsafeAtomicAdd(out_beta + c, total_plain);
-  }
-}
-
 // Whole backward of a frozen batch-norm (+ReLU) in ONE pass over (g, x): the activation mask is recomputed from x
 // with the forward's own arithmetic (fma(x, a, b) > 0), the input gradient g*[y>0]*a is written (or accumulated
 // into a channel-slice view), and both parameter gradients leave as two fp32 atomics per workgroup.  One workgroup
@@ -309,32 +262,6 @@ int srgan_chan_reduce(const float* a, const float* b, const float* mean, const f
   if (!accumulate) SRGAN_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s));
   hipLaunchKernelGGL(chan_reduce_rows_kernel, dim3(C, N * segs), dim3(256), 0, s, a, b, mean, scale, out, C, HW,
                      segs);
-  return launch_status();
-}
-
-int srgan_bn_param_grads(const float* g, const float* x, const float* mask, const float* mean, const float* inv_std,
-                         float* g_gamma_beta, int32_t N, int32_t C, int64_t HW, void* stream) {
-  SRGAN_REQUIRE(g && x && g_gamma_beta && N > 0 && C > 0 && HW > 0 && N <= 65535, SRGAN_EINVAL,
-                "srgan_bn_param_grads arguments");
-  hipStream_t s = (hipStream_t)stream;
-  if (C >= 256 && (int64_t)N * HW <= 8192) {
-    hipLaunchKernelGGL(chan_reduce_block_kernel, dim3(C), dim3(256), 0, s, g, x, mask, mean, inv_std, g_gamma_beta,
-                       g_gamma_beta + C, N, C, HW, 0);
-    return launch_status();
-  }
-  SRGAN_HIP(hipMemsetAsync(g_gamma_beta, 0, (size_t)2 * C * sizeof(float), s));
-  hipLaunchKernelGGL(bn_param_grads_rows_kernel, dim3(C, N), dim3(256), 0, s, g, x, mask, mean, inv_std, g_gamma_beta,
-                     g_gamma_beta + C, C, HW, (int64_t)C * HW);
-  return launch_status();
-}
-
-int srgan_bn_param_grads_accumulate(const float* g, const float* x, const float* mask, const float* mean,
-                                    const float* inv_std, float* g_gamma, float* g_beta, int32_t N, int32_t C,
-                                    int64_t HW, int64_t x_batch_stride, void* stream) {
-  SRGAN_REQUIRE(g && x && g_gamma && g_beta && N > 0 && C > 0 && HW > 0 && N <= 65535, SRGAN_EINVAL,
-                "srgan_bn_param_grads_accumulate arguments");
-  hipLaunchKernelGGL(bn_param_grads_rows_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, x, mask, mean, inv_std,
-                     g_gamma, g_beta, C, HW, x_batch_stride ? x_batch_stride : (int64_t)C * HW);
   return launch_status();
 }
 

@@ -62,9 +62,7 @@ class SganExperiment(Experiment, ABC):
                 self.fake_loss_calculation(unlabeled_examples, fake_examples))
 
     def interpolate_loss_calculation(self, interpolates):
-        from .tape import higher_order
-        with higher_order():      # this forward is differentiated twice
-            loss = self._binary_loss(interpolates, 0.0)
+        loss = self._binary_loss(interpolates, 0.0)        # differentiated twice
         return F.scale(loss, self.settings.gradient_penalty_multiplier)
 
     def generator_loss_calculation(self, fake_examples, unlabeled_examples):

@@ -28,7 +28,7 @@ from . import functional as F
 from . import nn
 from .optim import Adam
 from .settings import Settings
-from .tape import Var, backward, no_grad, higher_order
+from .tape import Var, backward, no_grad
 from .utility import SummaryWriter, MixtureModel, current_device, make_directory_name_unique, seed_all
 
 
@@ -495,8 +495,7 @@ class Experiment(ABC):
 
     def interpolate_loss_calculation(self, interpolates):
         """Per-example feature norm of the interpolates (reference srgan.py:377-381)."""
-        with higher_order():      # this forward is differentiated twice
-            _ = self.D(interpolates)
+        _ = self.D(interpolates)            # differentiated twice: every node's backward is itself recorded
         self.interpolates_features = self.D.features
         return F.row_norm(F.flatten2d(self.interpolates_features))
 

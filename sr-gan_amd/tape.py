@@ -37,25 +37,6 @@ def enable_grad():
         _grad_enabled = previous
 
 
-_higher_order = False
-
-
-def higher_order_enabled():
-    return _higher_order
-
-
-@contextlib.contextmanager
-def higher_order():
-    """Forwards built inside this context may be differentiated twice (``backward(..., create_graph=True)``):
-    modules use differentiable primitive ops instead of first-order fused nodes."""
-    global _higher_order
-    previous, _higher_order = _higher_order, True
-    try:
-        yield
-    finally:
-        _higher_order = previous
-
-
 class Node:
     """One recorded operation: its inputs and a function mapping the output gradient to input gradients."""
     __slots__ = ('inputs', 'input_requires', 'backward', 'name')
