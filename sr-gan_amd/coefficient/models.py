@@ -49,6 +49,19 @@ class MLP(nn.Module):
         return F.view(out, (out.shape[0],)) if out.shape[1] == 1 else out
 
 
+class DgganMLP(MLP):
+    """50 -> h -> h -> h -> 2: (predicted value, real/fake score) per example (reference coefficient/models.py:53-72)."""
+
+    def __init__(self, hidden_size=10):
+        super().__init__(hidden_size, outputs=2)
+
+    def forward(self, x):
+        out = super().forward(x)                                   # [B, 2]
+        columns = F.view(out, (out.shape[0], 2, 1, 1))
+        return (F.view(F.slice_channels(columns, 0, 1), (out.shape[0],)),
+                F.view(F.slice_channels(columns, 1, 2), (out.shape[0],)))
+
+
 class SganMLP(MLP):
     """50 -> 100 -> 100 -> 100 -> bins, no feature tap (reference coefficient/models.py:75-93)."""
 

@@ -9,6 +9,7 @@ import os
 
 from .age.sgan import AgeSganExperiment
 from .age.srgan import AgeExperiment
+from .coefficient.dggan import CoefficientDgganExperiment
 from .coefficient.sgan import CoefficientSganExperiment
 from .coefficient.srgan import CoefficientExperiment
 from .crowd.dnn import CrowdDnnExperiment
@@ -39,7 +40,8 @@ def build_settings(application_name, method_name):
         settings_.gradient_penalty_multiplier = 1e2
     elif application_name == ApplicationName.coefficient:
         experiment_class = {MethodName.srgan: CoefficientExperiment,
-                            MethodName.sgan: CoefficientSganExperiment}[method_name]
+                            MethodName.sgan: CoefficientSganExperiment,
+                            MethodName.dggan: CoefficientDgganExperiment}[method_name]
         settings_.matching_loss_multiplier = [1e-1, 1e0, 1e1]
         settings_.contrasting_loss_multiplier = [1e-1, 1e0, 1e1]
         settings_.batch_size = 5000

@@ -297,6 +297,13 @@ def g4_coefficient_sgan():
     _coefficient(CoefficientSganExperiment, 'g4_coefficient_sgan', steps=2, batch_size=64)
 
 
+def g4b_coefficient_dggan():
+    """the dual-goal GAN on the coefficient task (coefficient/dggan.py:13-64), discriminator scaled
+    so that the gradient penalty (on the per-example fake scores) is active."""
+    from coefficient.dggan import CoefficientDgganExperiment
+    _coefficient(CoefficientDgganExperiment, 'g4b_coefficient_dggan_gp_active', steps=2, batch_size=64, seed_offset=1)
+
+
 # ----------------------------------------------------------------------------------------------- image models
 class _ImageExperiment(ref_srgan.Experiment):
     """The reference Experiment with only the three abstract hooks filled in."""
@@ -619,7 +626,7 @@ def g9_crowd_sliding_window():
 
 
 ALL = {'g0': g0_toydata, 'g1': g1_distance, 'g2': g2_sgan_math, 'g3': g3_coefficient_srgan,
-       'g4': g4_coefficient_sgan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
+       'g4': g4_coefficient_sgan, 'g4b': g4b_coefficient_dggan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
        'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window}
 
 if __name__ == '__main__':

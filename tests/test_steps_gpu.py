@@ -494,3 +494,42 @@ def test_regression_evaluation_epochs(pkg):
     assert_close(gan['1 Validation Error/MAE'][-1][1], expected, rtol=RTOL, what='D validation MAE')
     ratio = gan['1 Validation Error/MAE'][-1][1] / dnn['1 Validation Error/MAE'][-1][1]
     assert_close(gan['1 Validation Error/Ratio MAE GAN DNN'][-1][1], ratio, rtol=1e-9, what='ratio')
+
+
+@pytest.mark.parametrize('reference_schedule', [False, True])
+def test_coefficient_dggan(pkg, reference_schedule):
+    """the dual-goal GAN step (reference coefficient/dggan.py:13-64) against golden g4b (gradient
+    penalty active on the per-example scores): logged losses, gradient norms, post-Adam weights."""
+    from srgan_amd.coefficient.dggan import CoefficientDgganExperiment
+    from srgan_amd.coefficient.models import DgganMLP, Generator
+    g = load_golden('g4b_coefficient_dggan_gp_active')
+
+    class _Experiment(CoefficientDgganExperiment):
+        def dataset_setup(self):
+            pass
+
+        def validation_summaries(self, step):
+            pass
+    from srgan_amd.settings import Settings
+    from srgan_amd.utility import SummaryWriter, seed_all
+    settings = Settings()
+    settings.batch_size, settings.gradient_penalty_multiplier = int(g['batch_size']), 1e1
+    settings.reference_schedule = reference_schedule
+    experiment = _Experiment(settings)
+    seed_all(0)
+    experiment.model_setup()
+    experiment.dnn_summary_writer, experiment.gan_summary_writer = SummaryWriter(), SummaryWriter()
+    for module, prefix in ((experiment.D, 'init/D'), (experiment.DNN, 'init/DNN'), (experiment.G, 'init/G')):
+        module.load_state_dict(golden_state(g, prefix))
+    finish_setup(experiment)
+    for step in range(int(g['steps'])):
+        x, y, u = (dev(g[f's{step}/{k}']) for k in ('x', 'y', 'u'))
+        result = run_step(experiment, x, y, u, step, g)
+        check(result, golden_scalars(g, step), f'dggan step {step}')
+        assert_close(experiment.gradient_norm.cpu().numpy(), g[f's{step}/gradient_norm'], rtol=RTOL, atol=1e-6,
+                     what='gradient_norm')
+    assert float(g['s0/gradient_penalty']) > 1.0
+    for name, module in (('D', experiment.D), ('G', experiment.G), ('DNN', experiment.DNN)):
+        for key, value in golden_state(g, f'final/{name}').items():
+            assert_close(module.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=2e-5,
+                         what=f'final {name} {key}')
