@@ -243,7 +243,7 @@ def g2_sgan_math():
 
 
 # ----------------------------------------------------------------------------------------------- g3/g4
-def _coefficient(experiment_class, name, steps, batch_size=256, seed_offset=0):
+def _coefficient(experiment_class, name, steps, batch_size=256, seed_offset=0, d_scale=3.0):
     settings = Settings()
     settings.batch_size = batch_size
     settings.labeled_dataset_size = 2 * batch_size
@@ -268,7 +268,7 @@ def _coefficient(experiment_class, name, steps, batch_size=256, seed_offset=0):
         # Scale the discriminator so that the gradient penalty is active (SURVEY.md §8c constraint 3).
         with torch.no_grad():
             for p in experiment.D.parameters():
-                p.mul_(3.0)
+                p.mul_(d_scale)
         out.update(state_arrays('init/D', experiment.D))
     labeled = experiment.infinite_iter(experiment.train_dataset_loader)
     unlabeled = experiment.infinite_iter(experiment.unlabeled_dataset_loader)
@@ -295,6 +295,10 @@ def g3_coefficient_srgan():
 def g4_coefficient_sgan():
     from coefficient.sgan import CoefficientSganExperiment
     _coefficient(CoefficientSganExperiment, 'g4_coefficient_sgan', steps=2, batch_size=64)
+    # the SGAN penalty differentiates a batch-MEAN scalar (sgan.py:58), so per-example gradient norms are 1/B of the
+    # SRGAN ones: a much larger discriminator scale is needed before any of them exceeds 1
+    _coefficient(CoefficientSganExperiment, 'g4c_coefficient_sgan_gp_active', steps=2, batch_size=64, seed_offset=1,
+                 d_scale=8.0)
 
 
 def g4b_coefficient_dggan():

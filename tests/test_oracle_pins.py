@@ -111,8 +111,9 @@ def test_coefficient_first_step_gradients():
         assert_close(value.numpy(), g[f's0/d_grad/{key}'], rtol=1e-5, atol=1e-7, what=f'd_grad {key}')
 
 
-def test_coefficient_sgan_steps():
-    g = load_golden('g4_coefficient_sgan')
+@pytest.mark.parametrize('name', ['g4_coefficient_sgan', 'g4c_coefficient_sgan_gp_active'])
+def test_coefficient_sgan_steps(name):
+    g = load_golden(name)
     experiment = build_coefficient(g, sgan=True)
     results = replay(experiment, g, 2)
     check_scalars(results, g, rtol=1e-5, atol=1e-7)

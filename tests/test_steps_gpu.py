@@ -134,9 +134,10 @@ def test_coefficient_first_step_gradients(pkg):
         assert_close(parameter.grad.cpu().numpy(), expected, rtol=RTOL, atol=1e-4 * scale, what=f'G grad {name}')
 
 
-def test_coefficient_sgan(pkg):
+@pytest.mark.parametrize('name', ['g4_coefficient_sgan', 'g4c_coefficient_sgan_gp_active'])
+def test_coefficient_sgan(pkg, name):
     from srgan_amd.coefficient.models import SganMLP, Generator
-    g = load_golden('g4_coefficient_sgan')
+    g = load_golden(name)
     experiment = make_experiment(lambda: (Generator(), SganMLP(10), SganMLP(10)), dict(batch_size=int(g['batch_size'])),
                                  sgan_bins=torch.linspace(-3, 3, 10))
     for module, prefix in ((experiment.D, 'init/D'), (experiment.DNN, 'init/DNN'), (experiment.G, 'init/G')):
@@ -146,6 +147,8 @@ def test_coefficient_sgan(pkg):
         x, y, u = (dev(g[f's{step}/{k}']) for k in ('x', 'y', 'u'))
         result = run_step(experiment, x, y, u, step, g)
         check(result, golden_scalars(g, step), f'sgan step {step}')
+    if 'gp_active' in name:
+        assert result['gradient_penalty'] > 10.0
     for key, value in golden_state(g, 'final/D').items():
         assert_close(experiment.D.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=2e-5, what=key)
 
