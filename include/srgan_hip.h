@@ -163,6 +163,17 @@ int srgan_crowd_map_l1_fwd(const float* maps, const float* target, float* rows, 
                            void* stream);
 int srgan_crowd_map_l1_bwd(const float* maps, const float* target, const float* g_rows, float* g_maps, int32_t B,
                            int32_t Cm, int64_t HW, void* stream);
+/* Training-batch assembly of the crowd application on the device (replaces the reference's 4-worker NumPy patch
+ * extractor, crowd/shanghai_tech_data.py:76-104 with crowd/data.py:41-128,370-453): example b = the P x P patch centred
+ * on (ys[b], xs[b]) of scene b (images_u8[b]: uint8 RGB [H, W, 3]; labels[b] / maps[b]: float [H, W]; all device
+ * pointers, the pointer tables and the int32 arrays live on the device too), mirrored left-right when flips[b] != 0,
+ * image normalised to [-1, 1] and planar: out_images [B, 3, P, P], out_labels / out_maps [B, P, P] (labels / maps and
+ * their outputs may be NULL).  Pixels outside the scene are 0 before normalisation (-1 after), 0 in label / map. */
+int srgan_crowd_extract_patches(const void* const* images_u8, const float* const* labels, const float* const* maps,
+                                const int32_t* heights, const int32_t* widths, const int32_t* ys, const int32_t* xs,
+                                const int32_t* flips, int32_t B, int32_t P, float* out_images, float* out_labels,
+                                float* out_maps, void* stream);
+
 /* Adam on a flat arena, torch.optim.Adam defaults and operation order (reference srgan.py:131-138,266,297,305);
  * `step` is the 1-based update count. */
 int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

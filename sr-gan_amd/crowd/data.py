@@ -62,3 +62,74 @@ class ImageSlidingWindowDataset:
         y, x = self.y_positions[y_index], self.x_positions[x_index]
         patch = negative_one_to_one(extract_padded_patch(self.image, y, x, self.image_patch_size))
         return torch.from_numpy(np.ascontiguousarray(patch.transpose((2, 0, 1)))), x, y
+
+
+class DeviceCrowdPatchLoader:
+    """Endless training batches cut ON THE DEVICE from full crowd scenes that stay resident in HBM:
+    the reference's ``ShanghaiTechTransformedDataset`` + ``DataLoader(num_workers=4)`` pipeline (random position
+    uniform over every valid patch centre of every scene, ``RandomHorizontalFlip``, [-1, 1] normalisation, CHW layout;
+    crowd/shanghai_tech_data.py:47-107) with one kernel launch per batch instead of per-example NumPy work.
+
+    ``examples``: ``CrowdExample``s with uint8 ``image`` (H, W, 3) and float ``label`` / ``map`` (H, W).  Yields
+    ``(image f32[B, 3, P, P], label f32[B, P, P], map f32[B, P, P])`` device tensors -- the batch contract of
+    ``CrowdExperiment``.  Positions and flips come from a private ``numpy`` generator (the reference's
+    multi-process workers make its own stream irreproducible anyway)."""
+
+    def __init__(self, examples, batch_size, image_patch_size=224, seed=0, device=None, flip=True):
+        from .. import _lib
+        from ..utility import current_device
+        self._lib = _lib
+        self.device = device or current_device()
+        self.batch_size, self.patch_size, self.flip = batch_size, image_patch_size, flip
+        self.generator = np.random.RandomState(seed)
+        half = image_patch_size // 2
+        self.images, self.labels, self.maps, self.shapes, self.start_indexes = [], [], [], [], []
+        self.length = 0
+        for example in examples:
+            height, width = example.image.shape[0], example.image.shape[1]
+            self.images.append(torch.from_numpy(np.ascontiguousarray(example.image, dtype=np.uint8)).to(self.device))
+            self.labels.append(torch.from_numpy(np.ascontiguousarray(example.label, dtype=np.float32)).to(self.device))
+            self.maps.append(torch.from_numpy(np.ascontiguousarray(example.map, dtype=np.float32)).to(self.device))
+            self.shapes.append((height, width))
+            self.start_indexes.append(self.length)
+            # every centre whose patch lies inside the scene; a scene smaller than a patch has none, as upstream
+            self.length += max(height - 2 * half + 1, 0) * max(width - 2 * half + 1, 0)
+        if self.length == 0:
+            raise ValueError('no scene is as large as one patch')
+
+    def draw_positions(self):
+        """(scene index, y, x, flip) of one batch: a uniform draw over all valid centres (reference
+        crowd/shanghai_tech_data.py:83-98) and a fair coin per example (crowd/data.py:104)."""
+        half = self.patch_size // 2
+        draws = []
+        for _ in range(self.batch_size):
+            index = int(self.generator.randint(self.length))
+            scene = int(np.searchsorted(self.start_indexes, index, side='right') - 1)
+            height, width = self.shapes[scene]
+            columns = width - 2 * half + 1
+            y_index, x_index = divmod(index - self.start_indexes[scene], columns)
+            draws.append((scene, half + y_index, half + x_index, int(self.flip and self.generator.randint(2))))
+        return draws
+
+    def batch_for(self, draws):
+        """The device batch of explicit ``(scene, y, x, flip)`` draws."""
+        count, size = len(draws), self.patch_size
+        pointers = lambda tensors: torch.tensor([tensors[d[0]].data_ptr() for d in draws], dtype=torch.int64)
+        table = torch.stack([pointers(self.images), pointers(self.labels), pointers(self.maps)]).to(self.device)
+        numbers = torch.tensor([[self.shapes[d[0]][0] for d in draws], [self.shapes[d[0]][1] for d in draws],
+                                [d[1] for d in draws], [d[2] for d in draws], [d[3] for d in draws]],
+                               dtype=torch.int32).to(self.device)
+        image = torch.empty((count, 3, size, size), dtype=torch.float32, device=self.device)
+        label = torch.empty((count, size, size), dtype=torch.float32, device=self.device)
+        map_ = torch.empty((count, size, size), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        self._lib.check(self._lib.library().srgan_crowd_extract_patches(
+            table[0].data_ptr(), table[1].data_ptr(), table[2].data_ptr(), numbers[0].data_ptr(), numbers[1].data_ptr(),
+            numbers[2].data_ptr(), numbers[3].data_ptr(), numbers[4].data_ptr(), count, size, image.data_ptr(),
+            label.data_ptr(), map_.data_ptr(), stream), 'srgan_crowd_extract_patches')
+        self._keep_alive = (table, numbers)          # the kernel reads the tables asynchronously
+        return image, label, map_
+
+    def __iter__(self):
+        while True:
+            yield self.batch_for(self.draw_positions())

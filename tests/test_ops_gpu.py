@@ -543,3 +543,39 @@ def test_fused_dense_block_with_in_kernel_batch_norm(F):
     for i, what in enumerate(('output', 'input gradient', 'parameter gradients', 'recorded input gradient',
                               'penalty parameter gradients')):
         close(results[True][i], results[False][i], 1e-4, 'in-kernel batch-norm: ' + what)
+
+
+@gpu
+def test_device_side_crowd_patch_batches(F):
+    """srgan_crowd_extract_patches / DeviceCrowdPatchLoader against the host-side NumPy transforms
+    of the reference pipeline (patch around a centre with zero padding, left-right flip, [-1, 1] normalisation, CHW)."""
+    from srgan_amd.crowd.data import CrowdExample, DeviceCrowdPatchLoader, extract_padded_patch, negative_one_to_one
+    generator = np.random.RandomState(11)
+    scenes = []
+    for shape in [(70, 90), (64, 64), (100, 81)]:
+        scenes.append(CrowdExample(image=generator.randint(0, 256, size=shape + (3,)).astype(np.uint8),
+                                   label=generator.rand(*shape).astype(np.float32),
+                                   map_=generator.rand(*shape).astype(np.float32)))
+    size = 64
+    loader = DeviceCrowdPatchLoader(scenes, batch_size=6, image_patch_size=size, seed=3)
+    assert loader.length == 7 * 27 + 1 + 37 * 18
+    # explicit draws, including centres whose patch leaves the scene (padding) and both flip states
+    draws = [(0, 32, 32, 0), (0, 38, 58, 1), (1, 32, 32, 1), (2, 68, 49, 0), (0, 5, 80, 0), (2, 99, 2, 1)]
+    image, label, map_ = loader.batch_for(draws)
+    for index, (scene, y, x, flip) in enumerate(draws):
+        example = scenes[scene]
+        expected_image = negative_one_to_one(extract_padded_patch(example.image, y, x, size))
+        expected_label = extract_padded_patch(example.label[:, :, None], y, x, size)[:, :, 0]
+        expected_map = extract_padded_patch(example.map[:, :, None], y, x, size)[:, :, 0]
+        if flip:
+            expected_image, expected_label, expected_map = (np.flip(a, axis=1) for a in
+                                                            (expected_image, expected_label, expected_map))
+        close(image[index], torch.from_numpy(expected_image.transpose(2, 0, 1).copy()), 1e-6, f'patch image {index}')
+        close(label[index], torch.from_numpy(expected_label.copy()), 0.0, f'patch label {index}')
+        close(map_[index], torch.from_numpy(expected_map.copy()), 0.0, f'patch map {index}')
+    batch = next(iter(loader))                       # random draws stay inside the scenes
+    assert tuple(batch[0].shape) == (6, 3, size, size) and tuple(batch[1].shape) == (6, size, size)
+    assert float(batch[0].min()) >= -1.0 and float(batch[0].max()) <= 1.0
+    for scene, y, x, flip in loader.draw_positions():
+        height, width = loader.shapes[scene]
+        assert 32 <= y <= height - 32 and 32 <= x <= width - 32 and flip in (0, 1)

@@ -536,3 +536,28 @@ def test_coefficient_dggan(pkg, reference_schedule):
         for key, value in golden_state(g, f'final/{name}').items():
             assert_close(module.state_dict()[key].cpu().numpy(), value.numpy(), rtol=RTOL, atol=2e-5,
                          what=f'final {name} {key}')
+
+
+def test_crowd_step_fed_by_the_device_patch_loader(pkg):
+    """batches cut on the device from resident full scenes satisfy the crowd batch contract -- one
+    full iteration (DNN step + GAN step) runs on them and yields finite losses."""
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
+    from srgan_amd.crowd.data import CrowdExample, DeviceCrowdPatchLoader
+    size, batch = 64, 2
+    generator = np.random.RandomState(2)
+    scenes = [CrowdExample(image=generator.randint(0, 256, size=(96, 128, 3)).astype(np.uint8),
+                           label=(generator.rand(96, 128) < 0.003).astype(np.float32),
+                           map_=generator.rand(96, 128).astype(np.float32)) for _ in range(3)]
+    experiment = make_experiment(
+        lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
+        dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
+             gradient_penalty_multiplier=1e2, map_multiplier=1e-3), crowd=True)
+    finish_setup(experiment)
+    labeled = iter(DeviceCrowdPatchLoader(scenes, batch, size, seed=0))
+    unlabeled = iter(DeviceCrowdPatchLoader(scenes, batch, size, seed=100))
+    x, heads, knn = next(labeled)
+    u = next(unlabeled)[0]
+    experiment.dnn_training_step(x, (heads, knn), 0)
+    experiment.gan_training_step(x, (heads, knn), u, 0)
+    values = [v[-1][1] for v in experiment.gan_summary_writer.scalars.values()]
+    assert len(values) >= 6 and all(np.isfinite(values))
