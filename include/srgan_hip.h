@@ -63,13 +63,20 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
  * norm -> relu -> conv triples, reference crowd/models.py:338-345): the normalised tensor is never written to HBM.
  * Zero padding applies to the activated tensor, as in the reference sequence.  Supported geometries: 1x1 / stride 1 /
  * unpadded on images of a multiple of 32 pixels, and 3x3 / stride 1 / pad 1 with W >= 16 (weight gradient: W % 4 ==
- * 0, C >= 32; forward: C <= 512); srgan_conv2d_bnrelu_supported(desc, pass) (pass 0 forward, 2 weight gradient)
- * returns 1 when the fused form exists, otherwise the caller materialises the activation (srgan_chan_affine_act)
- * and uses the plain entry points.  Results are identical to that two-step form up to summation order. */
+ * 0, C >= 32; forward: C <= 512); srgan_conv2d_bnrelu_supported(desc, pass) (pass 0 forward, 1 data gradient,
+ * 2 weight gradient) returns 1 when the fused form exists, otherwise the caller materialises the activation
+ * (srgan_chan_affine_act) and uses the plain entry points.  Results are identical to that two-step form up to
+ * summation order.
+ * srgan_conv2d_bwd_data_bnrelu is the backward of the triple w.r.t. x in one kernel: gx (=, +=)
+ * conv_bwd_data(gy, w) * [batch_norm(x) > 0] * inv_std * gamma, with x and gx sharing desc->x_batch_stride (gx may be
+ * a channel-slice view that is accumulated into), plus -- when g_gamma / g_beta are given (both or neither) -- the
+ * batch-norm parameter gradients accumulated into them.  Equals srgan_conv2d_bwd_data followed by srgan_bn_act_bwd. */
 typedef struct srgan_bn_relu { const float* mean; const float* inv_std; const float* gamma; const float* beta; } srgan_bn_relu;
 int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass);
 int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
                             const float* bias, float* y, void* stream);
+int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
+                                 const float* x, float* gx, float* g_gamma, float* g_beta, int accumulate, void* stream);
 int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,
                                    float* gw, int accumulate, void* stream);
 

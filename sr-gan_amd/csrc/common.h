@@ -45,6 +45,15 @@ __device__ __forceinline__ void bn_coefficients(float mean, float inv_std, float
   b = __fsub_rn(beta, __fmul_rn(mean, a));
 }
 
+// Backward of relu(batch_norm_eval(x)) applied in the epilogue of a data-gradient kernel (pointwise.hip, conv3x3.hip):
+// x is the tensor the normalisation read (batch stride x_bs, same channels as the kernel's output), bn = {mean,
+// inv_std, gamma, beta}; g_gamma / g_beta (both or neither) are accumulated into.
+struct BnBackwardEpilogue {
+  const float* x; int64_t x_bs;
+  const float* bn[4];
+  float* g_gamma; float* g_beta;
+};
+
 // Grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs x 8, never more than the work.
 inline unsigned stream_grid(int64_t work_items, int per_block) {
   int64_t blocks = (work_items + per_block - 1) / per_block;

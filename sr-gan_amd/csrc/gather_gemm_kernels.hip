@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void gg_reduce_partials_kernel(const GatherGem
 }
 
 // Grow-only per-stream workspace for the partial sums (launches on one stream are ordered, so reuse is safe).
-static float* partial_workspace(size_t bytes, hipStream_t stream) {
+float* partial_workspace(size_t bytes, hipStream_t stream) {
   struct Slot { float* ptr = nullptr; size_t bytes = 0; };
   static std::map<hipStream_t, Slot> slots;
   Slot& slot = slots[stream];
@@ -602,7 +602,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
 bool pointwise_enabled();
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
                   int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream,
-                  const float* const* bn = nullptr);
+                  const float* const* bn = nullptr, const BnBackwardEpilogue* epilogue = nullptr);
 
 // 1x1 / stride 1 / unpadded on images whose pixel count is a multiple of 32: the register-streamed pointwise kernel.
 static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
@@ -827,6 +827,7 @@ int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
     if (pointwise(g)) return use_pointwise(g, g.K, 0) ? 1 : 0;
     return (use_conv3x3(g, g.K, 0) && g.C <= 512) ? 1 : 0;
   }
+  if (pass == 1) return (pointwise(g) && use_pointwise(g, g.C, 0)) ? 1 : 0;
   if (pass == 2) {
     if (pointwise(g)) return pointwise_wgrad_geometry(g) ? 1 : 0;
     return (conv3x3_wgrad_enabled() && wgrad3x3_geometry(g)) ? 1 : 0;
@@ -849,6 +850,23 @@ int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const s
                          coefficients);
   return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, 0, (hipStream_t)stream,
                      coefficients);
+}
+
+int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
+                                 const float* x, float* gx, float* g_gamma, float* g_beta, int accumulate, void* stream) {
+  ConvGeom g;
+  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_data_bnrelu geometry");
+  SRGAN_REQUIRE(gy && w && x && gx && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_bwd_data_bnrelu pointers");
+  SRGAN_REQUIRE((g_gamma == nullptr) == (g_beta == nullptr), SRGAN_EINVAL,
+                "srgan_conv2d_bwd_data_bnrelu parameter gradients (both or neither)");
+  SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 1), SRGAN_EUNSUPPORTED,
+                "srgan_conv2d_bwd_data_bnrelu geometry support");
+  BnBackwardEpilogue epilogue;
+  epilogue.x = x; epilogue.x_bs = g.x_bs;
+  epilogue.bn[0] = bn->mean; epilogue.bn[1] = bn->inv_std; epilogue.bn[2] = bn->gamma; epilogue.bn[3] = bn->beta;
+  epilogue.g_gamma = g_gamma; epilogue.g_beta = g_beta;
+  return pointwise_run(gy, g.y_bs, w, 1, g.C, nullptr, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
+                       (hipStream_t)stream, nullptr, &epilogue);
 }
 
 int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,

@@ -16,6 +16,7 @@
 // Roofline: fp32 MFMA 157.3 TF/s, or HBM when CI is small; algorithmic bytes 4 * (CI + CO) per pixel.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace srgan {
 
@@ -36,15 +37,38 @@ struct PointwiseParams {
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
   // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
+  // EPI: the output rows go through the backward of relu(batch_norm_eval(epi_x)) on their way out (bn_* then describe
+  // the OUTPUT channels): out (=, +=) acc * [fma(x, a, b) > 0] * a, and the two parameter-gradient row sums of this
+  // workgroup's 128 pixels are written to epi_partial[q][column block][CO] (q = 0 beta, 1 gamma before inv_std).
+  const float* epi_x; int64_t epi_x_bs;
+  float* epi_partial; int32_t epi_cols;
 };
+
+// Sum over the 32 lanes of each half of the wave, valid in lanes 16-31 / 48-63: four rotations inside the rows of 16
+// (DPP row_ror) and one row broadcast (row_bcast:15 into rows 1 and 3) -- five VALU instructions, no LDS.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += dpp_move<0x128, 0xF>(v);
+  v += dpp_move<0x124, 0xF>(v);
+  v += dpp_move<0x122, 0xF>(v);
+  v += dpp_move<0x121, 0xF>(v);
+  v += dpp_move<0x142, 0xA>(v);
+  return v;
+}
 
 // PRO = frozen batch-norm + ReLU fused into the B-operand stream (reference crowd/models.py:338-341: norm1, relu1,
 // conv1): the per-channel (a, b) of the slice are staged in LDS next to the weight tile and every activation goes
 // through max(fma(x, a, b), 0) in registers on its way into the MFMA -- the normalised tensor never exists in HBM.
 // NI = 32-pixel column groups per wave (1 or 2): with two, every weight fragment read from LDS feeds two MFMAs and the
 // non-matrix instructions of a k-pair are amortised over 2*MI MFMAs.
-template <int MI, int BK, bool PRO, int NI>
-__global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams p) {
+// EPI = the backward of a frozen batch-norm + ReLU fused into the epilogue of a data gradient (reference
+// crowd/models.py:338-341 backwards: conv1 -> relu1 -> norm1): see PointwiseParams::epi_x.
+template <int MI, int BK, bool PRO, int NI, bool EPI = false>
+__global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(const PointwiseParams p) {
+  static_assert(!EPI || (!PRO && NI == 1), "the batch-norm backward epilogue pairs with the plain single-group kernel");
   constexpr int BM = MI * 32, KP = BK / 2, LDA = BM + 1;
   constexpr int EA = BM * BK / 256;
   __shared__ float lds[2 * BK * LDA];
@@ -180,6 +204,20 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
     }
   };
 
+  // EPI state (declared here so that both phases see it)
+  const float* x_lane = p.epi_x + (int64_t)n * p.epi_x_bs + pix;
+  float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
+  const bool sums_wanted = p.epi_partial != nullptr;
+  float xs[2][16], olds[2][16];
+  auto fetch = [&](int mi, float (&x)[16], float (&old)[16], auto accumulate) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = min(m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, p.CO - 1);
+      x[r] = x_lane[(int64_t)o * p.HW];
+      if constexpr (decltype(accumulate)::value) old[r] = out_lane[(int64_t)o * p.HW];
+    }
+  };
+
   if (kbeg < kend) {
     fetch_a(kbeg);
     fetch_b(kbeg, b0);
@@ -191,9 +229,67 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
     }
   }
 
+  if (EPI) {
+    // Loads first, stores last: the compiler cannot prove that the stores do not alias x or the accumulated gradient,
+    // so a load issued after a store waits for it.  The loads of 32-row block mi + 1 are issued before block mi is
+    // written (two register sets); block 0's go out before the coefficient table is built.  (Requesting block 0
+    // before the K loop measured the same and costs 32 registers = one workgroup per CU of occupancy at 64 rows.)
+    if (p.mode == 0) fetch(0, xs[0], olds[0], std::false_type{});
+    else fetch(0, xs[0], olds[0], std::true_type{});
+    __syncthreads();                               // every wave is done with the weight tiles: the LDS is reused
+    float* table = lds;                            // [BM][4]: a, b, mean of output row m0 + i
+    float* sums = lds + BM * 4;                    // [4 waves][2][BM]
+    if (tid < BM) {
+      const int o = min(m0 + tid, p.CO - 1);
+      const float mu = p.bn_mean[o];
+      float a, b;
+      bn_coefficients(mu, p.bn_inv[o], p.bn_gamma[o], p.bn_beta[o], a, b);   // the forward's own (a, b): same mask
+      table[tid * 4 + 0] = a; table[tid * 4 + 1] = b; table[tid * 4 + 2] = mu;
+    }
+    __syncthreads();
+    auto emit = [&](auto accumulate) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        if (mi + 1 < MI) fetch(mi + 1, xs[(mi + 1) & 1], olds[(mi + 1) & 1], accumulate);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const int o = m0 + row;
+          const bool ok = live && o < p.CO;
+          const float4 t = *reinterpret_cast<const float4*>(table + row * 4);
+          const float xv = xs[mi & 1][r];
+          const float v = (ok && fmaf(xv, t.x, t.y) > 0.f) ? acc[mi][0][r] : 0.f;
+          if (ok) {
+            float* dst = out_lane + (int64_t)o * p.HW;
+            if constexpr (decltype(accumulate)::value) *dst = olds[mi & 1][r] + v * t.x;
+            else __builtin_nontemporal_store(v * t.x, dst);
+          }
+          if (sums_wanted) {
+            const float plain = half_wave_sum(v), centred = half_wave_sum(v * (xv - t.z));
+            if (l31 == 31) {
+              sums[(wave * 2 + 0) * BM + row] = plain;
+              sums[(wave * 2 + 1) * BM + row] = centred;
+            }
+          }
+        }
+      }
+    };
+    if (p.mode == 0) emit(std::false_type{});
+    else emit(std::true_type{});
+    if (sums_wanted) {
+      __syncthreads();
+      if (tid < 2 * BM) {
+        const int q = tid / BM, row = tid - q * BM;
+        const float total = (sums[(0 * 2 + q) * BM + row] + sums[(1 * 2 + q) * BM + row]) +
+                            (sums[(2 * 2 + q) * BM + row] + sums[(3 * 2 + q) * BM + row]);
+        const int o = m0 + row;
+        if (o < p.CO) p.epi_partial[((int64_t)q * p.epi_cols + bid / p.tiles_m) * p.CO + o] = total;
+      }
+    }
+    return;
+  }
   if (!live) return;
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
-  float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
   // Three straight-line passes selected once (store / accumulate / atomic): with the mode tested per element the
   // 16 * MI stores of a lane are separated by branches and cannot be issued back to back.
   auto emit = [&](auto&& write) {
@@ -214,8 +310,35 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const PointwiseParams
   else emit([](float* dst, float v) { unsafeAtomicAdd(dst, v); });
 }
 
+// Second level of the fused batch-norm backward's parameter gradients: column sums of partial[q][column block][CO]
+// (lanes along the channels: coalesced rows), a few segments of column blocks per channel, one atomic per segment.
+__global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __restrict__ partial, int cols, int CO,
+                                                                const float* __restrict__ inv_std,
+                                                                float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                                int cols_per_segment) {
+  __shared__ float scratch[2][4][64];
+  const int lane_c = (int)threadIdx.x & 63, rl = (int)threadIdx.x >> 6;
+  const int c = (int)blockIdx.x * 64 + lane_c;
+  const int first = (int)blockIdx.y * cols_per_segment, last = min(cols, first + cols_per_segment);
+  float plain = 0.f, centred = 0.f;
+  if (c < CO)
+    for (int cb = first + rl; cb < last; cb += 4) {
+      plain += partial[(int64_t)cb * CO + c];
+      centred += partial[((int64_t)cols + cb) * CO + c];
+    }
+  scratch[0][rl][lane_c] = plain;
+  scratch[1][rl][lane_c] = centred;
+  __syncthreads();
+  if (rl != 0 || c >= CO) return;
+  plain = (scratch[0][0][lane_c] + scratch[0][1][lane_c]) + (scratch[0][2][lane_c] + scratch[0][3][lane_c]);
+  centred = (scratch[1][0][lane_c] + scratch[1][1][lane_c]) + (scratch[1][2][lane_c] + scratch[1][3][lane_c]);
+  unsafeAtomicAdd(g_beta + c, plain);
+  unsafeAtomicAdd(g_gamma + c, centred * inv_std[c]);
+}
+
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+float* partial_workspace(size_t bytes, hipStream_t stream);
 
 bool pointwise_enabled() {
   static const bool disabled = getenv("SRGAN_NO_POINTWISE") != nullptr;
@@ -224,6 +347,11 @@ bool pointwise_enabled() {
 
 template <int MI, int BK, int NI>
 static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t stream) {
+  if (p.epi_x) {
+    if constexpr (BK == 32 && NI == 1)
+      hipLaunchKernelGGL((pointwise_kernel<MI, 32, false, 1, true>), grid, dim3(256), 0, stream, p);
+    return;
+  }
   if (p.bn_mean) hipLaunchKernelGGL((pointwise_kernel<MI, BK, true, NI>), grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, NI>), grid, dim3(256), 0, stream, p);
 }
@@ -231,8 +359,9 @@ static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t st
 // bn (4 pointers: mean, inv_std, gamma, beta; NULL = none): the input is relu(batch_norm_eval(in)) on the fly.
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
                   int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream,
-                  const float* const* bn) {
+                  const float* const* bn, const BnBackwardEpilogue* epilogue) {
   PointwiseParams p;
+  p.epi_x = nullptr; p.epi_x_bs = 0; p.epi_partial = nullptr; p.epi_cols = 0;
   p.in = in; p.w = w; p.out = out; p.bias = bias;
   p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
@@ -242,11 +371,13 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   // Two 32-pixel groups per wave (64 x 64 wave tile): a tuning variant (SRGAN_PW_NI=2).  In isolation it is up to
   // 10 % faster on the K = 128 data gradients, inside the training step it measured 0.7 % slower: off by default.
   static const int ni_cap = getenv("SRGAN_PW_NI") ? atoi(getenv("SRGAN_PW_NI")) : 1;
-  int ni = (HW % 64 == 0 && ni_cap >= 2) ? 2 : 1;
+  int ni = (HW % 64 == 0 && ni_cap >= 2 && !epilogue) ? 2 : 1;
   int64_t groups = (int64_t)N * HW / (32 * ni);
   int64_t col_blocks = (groups + 3) / 4;
   // Tallest row tile that still yields ~4 workgroups per CU; otherwise shorter tiles, then split over input channels.
-  static const int mi_cap = getenv("SRGAN_PW_MI") ? atoi(getenv("SRGAN_PW_MI")) : 4;
+  static const int mi_cap_long = getenv("SRGAN_PW_MI") ? atoi(getenv("SRGAN_PW_MI")) : 2;
+  static const int mi_cap_short = getenv("SRGAN_PW_MI_SHORT") ? atoi(getenv("SRGAN_PW_MI_SHORT")) : mi_cap_long;
+  const int mi_cap = CI <= 128 ? mi_cap_short : mi_cap_long;
   int mi = CO > 64 ? 4 : (CO > 32 ? 2 : 1);
   if (mi > mi_cap) mi = mi_cap;
   // NI = 2 pairs with the 64-row tile (acc 64 + 2 x 32 operand registers; 128 rows x 64 pixels would spill)
@@ -275,7 +406,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   const int64_t blocks = col_blocks * p.tiles_m;
   const int slices = (CI + 63) / 64;
   int split = 1;
-  if (blocks < (min_wgs * 3) / 4 && slices >= 2) {
+  if (blocks < (min_wgs * 3) / 4 && slices >= 2 && !epilogue) {   // (the fused epilogue needs whole sums per workgroup)
     split = (int)((min_wgs + blocks - 1) / blocks);
     if (split > slices) split = slices;
     if (split < 1) split = 1;
@@ -291,8 +422,19 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   } else {
     p.mode = accumulate ? 1 : 0;
   }
+  if (epilogue) {
+    SRGAN_REQUIRE(!bn && !bias, SRGAN_EINVAL, "pointwise batch-norm backward epilogue: no prologue, no bias");
+    p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
+    p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
+    p.epi_cols = (int32_t)col_blocks;
+    if (epilogue->g_gamma) {
+      p.epi_partial = partial_workspace((size_t)2 * col_blocks * CO * sizeof(float), stream);
+      SRGAN_REQUIRE(p.epi_partial, (int)hipErrorOutOfMemory, "pointwise batch-norm backward workspace");
+    }
+  }
   profile_bracket_begin(stream);
-  static const int bk = getenv("SRGAN_PW_BK") ? atoi(getenv("SRGAN_PW_BK")) : 32;
+  static const int bk_env = getenv("SRGAN_PW_BK") ? atoi(getenv("SRGAN_PW_BK")) : 32;
+  const int bk = epilogue ? 32 : bk_env;
   auto launch = [&](int mi_, dim3 grid) {
     if (ni == 2) {
       launch_pointwise<2, 32, 2>(p, grid, stream);
@@ -314,6 +456,13 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     p.tiles_m = 1;
     p.xcd_remap = 0;
     launch(rest_mi, dim3((unsigned)col_blocks, (unsigned)split, 1));
+  }
+  if (p.epi_partial) {
+    int segments = (int)(col_blocks / 32);
+    segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
+    const int per = (int)((col_blocks + segments - 1) / segments);
+    hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((CO + 63) / 64, (unsigned)((col_blocks + per - 1) / per)), dim3(256), 0,
+                       stream, p.epi_partial, (int)col_blocks, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, per);
   }
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);

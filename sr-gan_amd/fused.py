@@ -33,6 +33,7 @@ from .nn import parameter_var
 
 ENABLED = True      # tests flip this to compare the fused block with the primitive path
 PROLOGUE = True     # batch-norm + ReLU evaluated inside the convolution kernels (tests flip this too)
+EPILOGUE = True     # batch-norm + ReLU backward evaluated in the epilogue of the data-gradient kernels
 
 
 def _ptr(tensor, offset_elements=0):
@@ -70,6 +71,10 @@ def dense_block(x, layers):
     probe1 = _desc(n, c0, h, w, width, 1, 1, 1, 0, buffer_bs, 0)
     probe2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
     prologue = PROLOGUE and all(lib.srgan_conv2d_bnrelu_supported(d, kind) for d in (probe1, probe2) for kind in (0, 2))
+    # backward of norm1 -> relu1 -> conv1 w.r.t. the block buffer in one kernel (batch-norm backward in the epilogue
+    # of the data gradient, accumulated straight into the gradient buffer)
+    epilogue1 = EPILOGUE and prologue and bool(lib.srgan_conv2d_bnrelu_supported(
+        _desc(n, c0, h, w, width, 1, 1, 1, 0, buffer_bs, 0), 1))
 
     def bn_struct(norm):
         inv, mean = norm._inverse_std()
@@ -151,15 +156,21 @@ def dense_block(x, layers):
             elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc1, t1.data_ptr(), g_b1.data_ptr(),
                         layer.conv1.weight.grad.data_ptr(), 1, 0, stream)
-            g_t1 = _empty((n, cin, h, w), device)
-            F._call('srgan_conv2d_bwd_data', desc1, g_b1.data_ptr(), layer.conv1.weight.data_ptr(), None, g_t1.data_ptr(),
-                    0, 0, stream)
-            # batch-norm 1 backward: parameter gradients, and the gradient w.r.t. the layer's (view) input
-            # accumulated into the leading channels of the gradient buffer, in one pass
-            F._call('srgan_bn_act_bwd', g_t1.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, gbuf.data_ptr(),
-                    layer.norm1.weight.grad.data_ptr() if want_params else None,
-                    layer.norm1.bias.grad.data_ptr() if want_params else None, n, cin, hw, 0, buffer_bs, buffer_bs, 1, 0,
-                    stream)
+            if epilogue1:
+                F._call('srgan_conv2d_bwd_data_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0),
+                        g_b1.data_ptr(), layer.conv1.weight.data_ptr(), bn_struct(layer.norm1), buffer.data_ptr(),
+                        gbuf.data_ptr(), layer.norm1.weight.grad.data_ptr() if want_params else None,
+                        layer.norm1.bias.grad.data_ptr() if want_params else None, 1, stream)
+            else:
+                g_t1 = _empty((n, cin, h, w), device)
+                F._call('srgan_conv2d_bwd_data', desc1, g_b1.data_ptr(), layer.conv1.weight.data_ptr(), None,
+                        g_t1.data_ptr(), 0, 0, stream)
+                # batch-norm 1 backward: parameter gradients, and the gradient w.r.t. the layer's (view) input
+                # accumulated into the leading channels of the gradient buffer, in one pass
+                F._call('srgan_bn_act_bwd', g_t1.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1,
+                        gbuf.data_ptr(), layer.norm1.weight.grad.data_ptr() if want_params else None,
+                        layer.norm1.bias.grad.data_ptr() if want_params else None, n, cin, hw, 0, buffer_bs, buffer_bs,
+                        1, 0, stream)
             if recorded:
                 # The forward node itself may still be back-propagated later (the penalty also depends on the
                 # parameters through the forward activations), so nothing of `saved` is released here; the double

@@ -343,6 +343,92 @@ def test_crowd_step_at_the_benchmark_size_matches_the_oracle(pkg):
             assert np.abs(got - expected).mean() <= 2e-5 + 1e-4 * np.abs(expected).mean(), f'{name} {pname} (mean)'
 
 
+def _hip_and_oracle_step(experiment_class, configure, oracle_networks, size, batch, d_scale):
+    """One dnn + gan step of a task experiment on the HIP path and of the oracle composed from the same
+    architecture, from identical weights (state copied HIP -> oracle), inputs and random draws."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as entry
+    from srgan_amd.settings import Settings
+    from srgan_amd.utility import SummaryWriter, seed_all
+    from oracle.experiment import OracleExperiment, Draws
+    entry._cap_host_threads(torch)
+    settings = Settings()
+    settings.batch_size = batch
+    settings.matching_loss_multiplier, settings.contrasting_loss_multiplier = 1e2, 1e1
+    settings.gradient_penalty_multiplier = 1e2
+    experiment = experiment_class(settings)
+    configure(experiment)
+    seed_all(0)
+    experiment.model_setup()
+    with torch.no_grad():                       # scale D so that the gradient penalty is active
+        for module in experiment.D.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.Linear)):
+                module.weight.mul_(d_scale)
+    oracle_g, oracle_d, oracle_dnn = oracle_networks()
+    for ours, theirs in ((experiment.G, oracle_g), (experiment.D, oracle_d), (experiment.DNN, oracle_dnn)):
+        theirs.load_state_dict({k: v.detach().clone() for k, v in ours.state_dict().items()}, strict=True)
+    oracle = OracleExperiment(entry.settings_for_oracle(settings), oracle_d, oracle_dnn, oracle_g)
+    experiment.dnn_summary_writer, experiment.gan_summary_writer = SummaryWriter(), SummaryWriter()
+    finish_setup(experiment)
+    height, width = (size, size) if isinstance(size, int) else size
+    generator = torch.Generator().manual_seed(1)
+    x = torch.rand(batch, 3, height, width, generator=generator) * 2 - 1
+    u = torch.rand(batch, 3, height, width, generator=generator) * 2 - 1
+    y = torch.rand(batch, generator=generator) * 85 + 10
+    draws = Draws(torch.randn(batch, 256, generator=generator), torch.randn(batch, 256, generator=generator),
+                  torch.rand(batch, 1, 1, 1, generator=generator))
+    experiment.injected_draws = {'z_d': draws.z_d, 'z_g': draws.z_g, 'alpha': draws.alpha}
+    experiment.dnn_training_step(x.cuda(), y.cuda(), 0)
+    experiment.gan_training_step(x.cuda(), y.cuda(), u.cuda(), 0)
+    torch.cuda.synchronize()
+    oracle.dnn_training_step(x, y)
+    expected = oracle.gan_training_step(x, y, u, 0, draws)
+    got = {k: float(v.item()) for k, v in experiment.last_losses.items() if v is not None}
+    for key in ('labeled_loss', 'unlabeled_loss', 'fake_loss', 'gradient_penalty', 'generator_loss'):
+        assert_close(got[key], expected[key], rtol=RTOL, atol=0.0, what=key)
+    assert expected['gradient_penalty'] > 1.0
+    for name, ours, theirs in (('D', experiment.D, oracle_d), ('G', experiment.G, oracle_g),
+                               ('DNN', experiment.DNN, oracle_dnn)):
+        reference = dict(theirs.named_parameters())
+        for pname, p in ours.named_parameters():
+            want, have = reference[pname].detach().numpy(), p.detach().cpu().numpy()
+            # Adam's first step moves every element by ~lr * sign(gradient): rounding-level gradients may flip
+            assert np.abs(have - want).max() <= 2.2e-4 + 1e-3 * np.abs(want).max(), f'{name} {pname}'
+            assert np.abs(have - want).mean() <= 2e-5 + 1e-4 * np.abs(want).mean(), f'{name} {pname} (mean)'
+
+
+def test_age_vgg_step_at_64_pixels_matches_the_oracle(pkg, monkeypatch):
+    """BASELINE.json configs[1]: age SRGAN with the VGG-16 discriminator on 64x64 faces,
+    classifier in-features 512 * (64 / 32)^2.  The 224^2 graph is pinned to the reference by g8b_vgg224; here the
+    same layers at 64^2 against the oracle's VGG16(image_size=64)."""
+    import srgan_amd.age.srgan as age
+    from oracle import models as OM
+    monkeypatch.setattr(age, 'model_architecture', 'vgg')       # module-level switch, as in reference age/srgan.py:14
+
+    def configure(experiment):
+        experiment.image_size = 64
+    _hip_and_oracle_step(age.AgeExperiment, configure,
+                         lambda: (OM.DCGANGenerator(image_size=64), OM.VGG16(1, 64), OM.VGG16(1, 64)),
+                         size=64, batch=8, d_scale=1.3)
+
+
+def test_driving_step_on_rectangular_frames_matches_the_oracle(pkg):
+    """BASELINE.json configs[4]: the driving DCGAN pair on 64x192 frames -- the seed
+    transposed convolution and the discriminator's last convolution have the rectangular (4, 12) kernel."""
+    from srgan_amd.driving.srgan import DrivingExperiment
+    from oracle import models as OM
+    size = (64, 192)
+
+    def configure(experiment):
+        experiment.image_size = size
+    _hip_and_oracle_step(DrivingExperiment, configure,
+                         lambda: (OM.DCGANGenerator(image_size=size), OM.DCGANDiscriminator(image_size=size),
+                                  OM.DCGANDiscriminator(image_size=size)),
+                         size=size, batch=8, d_scale=2.2)
+
+
 def test_training_loop_and_checkpoint_interchange(pkg, tmp_path):
     """H1 (srgan.py:52-129): ``Experiment.train()`` end to end on the coefficient task -- loop, learning-rate
     schedule, validation summaries, ``model_<step>.pth`` -- then the checkpoint loads (strictly) into the oracle's
