@@ -34,7 +34,25 @@ struct Conv3Params {
   int32_t debug;        // tuning experiments only (SRGAN_CONV3_DEBUG): 1 = no re-staging, 2 = no MFMA
   // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
+  // EPI: the output goes through the backward of relu(batch_norm_eval(epi_x)) on its way out (bn_* then describe the
+  // OUTPUT channels, see BnBackwardEpilogue); epi_partial[q][workgroup tile][CO] receives the parameter-gradient sums
+  const float* epi_x; int64_t epi_x_bs;
+  float* epi_partial; int32_t epi_tiles;
 };
+
+// Sum over the 32 lanes of each half of the wave, valid in lanes 16-31 / 48-63 (DPP row rotations + row broadcast).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move3(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum3(float v) {
+  v += dpp_move3<0x128, 0xF>(v);
+  v += dpp_move3<0x124, 0xF>(v);
+  v += dpp_move3<0x122, 0xF>(v);
+  v += dpp_move3<0x121, 0xF>(v);
+  v += dpp_move3<0x142, 0xA>(v);
+  return v;
+}
 
 constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range whose (a, b) fit the LDS table
 
@@ -43,8 +61,12 @@ constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range w
 // max(fma(x, a, b), 0) when it is written to LDS; padding stays exactly 0 (the reference pads the activated tensor).
 // TW = tile width: 32, or 16 for 16-pixel-wide images, where a 32-lane column block is two image rows of 16 pixels
 // (a 32-wide tile would leave half of every MFMA's columns outside the image).
-template <int BM, int TH, int CI_T, bool PRO, int TW>
+// EPI = the backward of a frozen batch-norm + ReLU fused into the epilogue of the data gradient (reference
+// crowd/models.py:342-345 backwards: conv2 -> relu2 -> norm2): out = acc * [fma(x, a, b) > 0] * a, plus the workgroup's
+// two parameter-gradient row sums (store mode only, no split over input channels).
+template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
+  static_assert(!EPI || !PRO, "the batch-norm backward epilogue pairs with the plain kernel");
   constexpr int RPB = 32 / TW;                    // image rows per 32-lane column block
   constexpr int ROWS = TH * RPB;                  // image rows of the workgroup's tile
   constexpr int PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
@@ -189,9 +211,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     }
   }
 
-  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
   const int x = x0 + l31 % TW;
   float* out_n = p.out + (int64_t)n * p.out_bs;
+  if (EPI) {
+    // (the K loop ends with a barrier: the LDS is free)
+    float* table = lds;                            // [BM][4]: a, b, mean of output row m0 + i
+    float* sums = lds + BM * 4;                    // [4 waves][2][BM]
+    if (tid < BM) {
+      const int o = min(m0 + tid, p.CO - 1);
+      const float mu = p.bn_mean[o];
+      float a, b;
+      bn_coefficients(mu, p.bn_inv[o], p.bn_gamma[o], p.bn_beta[o], a, b);   // the forward's own (a, b): same mask
+      table[tid * 4 + 0] = a; table[tid * 4 + 1] = b; table[tid * 4 + 2] = mu;
+    }
+    __syncthreads();
+    const float* x_n = p.epi_x + (int64_t)n * p.epi_x_bs;
+    const bool sums_wanted = p.epi_partial != nullptr;
+    int pix[NI];
+    bool inside[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int y = y0 + (wave * NI + ni) * RPB + l31 / TW;
+      inside[ni] = y < p.H && x < p.W;
+      pix[ni] = inside[ni] ? y * p.W + x : 0;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      float xs[NI][16];                            // loads first, stores last (the stores may alias for all the compiler knows)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = min(m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, p.CO - 1);
+          xs[ni][r] = x_n[(int64_t)o * HW + pix[ni]];
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int o = m0 + row;
+        const float4 t = *reinterpret_cast<const float4*>(table + row * 4);
+        float plain = 0.f, centred = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const bool ok = inside[ni] && o < p.CO;
+          const float v = (ok && fmaf(xs[ni][r], t.x, t.y) > 0.f) ? acc[mi][ni][r] : 0.f;
+          if (ok) __builtin_nontemporal_store(v * t.x, out_n + (int64_t)o * HW + pix[ni]);
+          plain += v;
+          centred += v * (xs[ni][r] - t.z);
+        }
+        if (sums_wanted) {
+          plain = half_wave_sum3(plain);
+          centred = half_wave_sum3(centred);
+          if (l31 == 31) {
+            sums[(wave * 2 + 0) * BM + row] = plain;
+            sums[(wave * 2 + 1) * BM + row] = centred;
+          }
+        }
+      }
+    }
+    if (sums_wanted) {
+      __syncthreads();
+      if (tid < 2 * BM) {
+        const int q = tid / BM, row = tid - q * BM;
+        const float total = (sums[(0 * 2 + q) * BM + row] + sums[(1 * 2 + q) * BM + row]) +
+                            (sums[(2 * 2 + q) * BM + row] + sums[(3 * 2 + q) * BM + row]);
+        const int o = m0 + row;
+        if (o < p.CO) p.epi_partial[((int64_t)q * p.epi_tiles + (int)blockIdx.x / p.tiles_m) * p.CO + o] = total;
+      }
+    }
+    return;
+  }
+  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int y = y0 + (wave * NI + ni) * RPB + l31 / TW;
@@ -215,7 +305,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
 
 template <int BM, int CI_T, int TW>
 static void launch_conv3_w(const Conv3Params& p, int th, dim3 grid, hipStream_t stream) {
-  if (p.bn_mean) {
+  if (p.epi_x) {                       // (the plan admits the epilogue for 32- and 64-row tiles only)
+    if constexpr (BM <= 64) {
+      if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, false, TW, true>), grid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, false, TW, true>), grid, dim3(256), 0, stream, p);
+    }
+  } else if (p.bn_mean) {
     if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
   } else {
@@ -239,49 +334,75 @@ bool conv3x3_enabled() {
   return !disabled;
 }
 
-// out = conv3x3(in, w) (+ bias), generic weight strides (forward and flipped-tap data gradient share the kernel).
-// The caller guarantees dense-or-strided NCHW, 3x3 / stride 1 / pad 1.  `accumulate` adds into out.
-int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
-                int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
-                int32_t W, int accumulate, hipStream_t stream, const float* const* bn) {
-  Conv3Params p;
-  p.in = in; p.w = w; p.out = out; p.bias = bias;
-  p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
-  p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
-  SRGAN_REQUIRE(bn == nullptr || CI <= CONV3_PRO_MAX_CI, SRGAN_EUNSUPPORTED, "conv3x3 fused batch-norm channel count");
-  p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
-  p.in_bs = in_bs; p.out_bs = out_bs;
-  p.debug = getenv("SRGAN_CONV3_DEBUG") ? atoi(getenv("SRGAN_CONV3_DEBUG")) : 0;
-  p.w_so = w_so; p.w_si = w_si; p.w_skh = w_skh; p.w_skw = w_skw; p.w_base = w_base;
+// Tile choice: the widest output-channel tile (fewest re-reads of the input patch) and the 8-row pixel tile, as long
+// as that still gives ~2 workgroups per CU; otherwise narrower / shorter tiles; input-channel splitting (fp32 atomics
+// into a pre-zeroed output) only as the last resort and never below two chunks per workgroup.
+struct Conv3Plan { int bm, th, tw, ci_t, tiles_x, tiles_y, tiles_m, split, chunks_per; int64_t blocks; };
+
+static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) {
+  Conv3Plan plan;
   const int tw = W <= 16 ? 16 : 32;      // 16-wide images: a 32-lane column block = two image rows (no dead columns)
-  p.tiles_x = (W + tw - 1) / tw;
-  // Tile choice: the widest output-channel tile (fewest re-reads of the input patch) and the 8-row pixel tile, as
-  // long as that still gives ~2 workgroups per CU; otherwise narrower / shorter tiles; input-channel splitting (fp32
-  // atomics into a pre-zeroed output) only as the last resort and never below two chunks per workgroup.
+  plan.tw = tw;
+  plan.tiles_x = (W + tw - 1) / tw;
+  static const int bm_cap = getenv("SRGAN_CONV3_BM") ? atoi(getenv("SRGAN_CONV3_BM")) : 64;   // 64 rows: +0.4 % in-step over 128
   int bm = CO > 64 ? 128 : (CO > 32 ? 64 : 32);
+  if (bm > bm_cap) bm = bm_cap;
   int th = (bm == 128 || tw == 16) ? 4 : 8;   // 128 rows / 16-wide tiles always use 4 column blocks per workgroup
   auto rows = [&](int th_) { return th_ * (32 / tw); };
   auto count = [&](int bm_, int th_) {
-    return (int64_t)N * ((H + rows(th_) - 1) / rows(th_)) * p.tiles_x * ((CO + bm_ - 1) / bm_);
+    return (int64_t)N * ((H + rows(th_) - 1) / rows(th_)) * plan.tiles_x * ((CO + bm_ - 1) / bm_);
   };
   while (count(bm, th) < 512) {
     if (th == 8) th = 4;
     else if (bm > 32) { bm >>= 1; th = 4; }
     else break;
   }
-  const int ci_t = bm == 128 ? 4 : (bm == 64 ? 8 : 16);     // keeps the staged registers + accumulators <= 256
-  p.tiles_m = (CO + bm - 1) / bm;
-  p.tiles_y = (H + rows(th) - 1) / rows(th);
-  const int64_t blocks = count(bm, th);
-  const int chunks = (CI + ci_t - 1) / ci_t;
+  plan.bm = bm; plan.th = th;
+  plan.ci_t = bm == 128 ? 4 : (bm == 64 ? 8 : 16);     // keeps the staged registers + accumulators <= 256
+  plan.tiles_m = (CO + bm - 1) / bm;
+  plan.tiles_y = (H + rows(th) - 1) / rows(th);
+  plan.blocks = count(bm, th);
+  const int chunks = (CI + plan.ci_t - 1) / plan.ci_t;
   int split = 1;
-  if (blocks < 384 && chunks >= 4) {
-    split = (int)((512 + blocks - 1) / blocks);
+  if (plan.blocks < 384 && chunks >= 4) {
+    split = (int)((512 + plan.blocks - 1) / plan.blocks);
     if (split > chunks / 2) split = chunks / 2;
   }
-  const int chunks_per = (chunks + split - 1) / split;
-  p.ci_per_split = chunks_per * ci_t;
-  split = (chunks + chunks_per - 1) / chunks_per;
+  plan.chunks_per = (chunks + split - 1) / split;
+  plan.split = (chunks + plan.chunks_per - 1) / plan.chunks_per;
+  return plan;
+}
+
+// The batch-norm backward epilogue needs whole sums in one workgroup (no split) and a 32- or 64-row tile.
+bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) {
+  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W);
+  return plan.split == 1 && plan.bm <= 64;
+}
+
+void bn_partial_reduce_run(const float* partial, int tiles, int CO, const float* inv_std, float* g_gamma, float* g_beta,
+                           hipStream_t stream);
+float* partial_workspace(size_t bytes, hipStream_t stream);
+
+// out = conv3x3(in, w) (+ bias), generic weight strides (forward and flipped-tap data gradient share the kernel).
+// The caller guarantees dense-or-strided NCHW, 3x3 / stride 1 / pad 1.  `accumulate` adds into out.
+int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
+                int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
+                int32_t W, int accumulate, hipStream_t stream, const float* const* bn, const BnBackwardEpilogue* epilogue) {
+  Conv3Params p;
+  p.in = in; p.w = w; p.out = out; p.bias = bias;
+  p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
+  p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
+  p.epi_x = nullptr; p.epi_x_bs = 0; p.epi_partial = nullptr; p.epi_tiles = 0;
+  SRGAN_REQUIRE(bn == nullptr || CI <= CONV3_PRO_MAX_CI, SRGAN_EUNSUPPORTED, "conv3x3 fused batch-norm channel count");
+  p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
+  p.in_bs = in_bs; p.out_bs = out_bs;
+  p.debug = getenv("SRGAN_CONV3_DEBUG") ? atoi(getenv("SRGAN_CONV3_DEBUG")) : 0;
+  p.w_so = w_so; p.w_si = w_si; p.w_skh = w_skh; p.w_skw = w_skw; p.w_base = w_base;
+  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W);
+  const int bm = plan.bm, th = plan.th, tw = plan.tw, split = plan.split;
+  p.tiles_x = plan.tiles_x; p.tiles_y = plan.tiles_y; p.tiles_m = plan.tiles_m;
+  p.ci_per_split = plan.chunks_per * plan.ci_t;
+  const int64_t blocks = plan.blocks;
   SRGAN_REQUIRE(blocks < (int64_t)1 << 31 && split <= 65535, SRGAN_ERANGE, "conv3x3 grid");
   if (split > 1) {
     if (!accumulate)
@@ -291,11 +412,24 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   } else {
     p.mode = accumulate ? 1 : 0;
   }
+  if (epilogue) {
+    SRGAN_REQUIRE(!bn && !bias && !accumulate && split == 1 && bm <= 64, SRGAN_EUNSUPPORTED,
+                  "conv3x3 batch-norm backward epilogue (store mode, unsplit, <= 64-row tile)");
+    p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
+    p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
+    p.epi_tiles = (int32_t)(blocks / plan.tiles_m);
+    if (epilogue->g_gamma) {
+      p.epi_partial = partial_workspace((size_t)2 * p.epi_tiles * CO * sizeof(float), stream);
+      SRGAN_REQUIRE(p.epi_partial, (int)hipErrorOutOfMemory, "conv3x3 batch-norm backward workspace");
+    }
+  }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);
   profile_bracket_begin(stream);
   if (bm == 32) launch_conv3<32, 16>(p, th, tw, grid, stream);
   else if (bm == 64) launch_conv3<64, 8>(p, th, tw, grid, stream);
   else launch_conv3<128, 4>(p, 4, tw, grid, stream);
+  if (p.epi_partial)
+    bn_partial_reduce_run(p.epi_partial, p.epi_tiles, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * H * W, (int64_t)CI * 9, 2, bm, th * 32, split);
   return status;

@@ -597,7 +597,9 @@ int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int
 bool conv3x3_enabled();
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
-                int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
+                int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
+                const BnBackwardEpilogue* epilogue = nullptr);
+bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 
 bool pointwise_enabled();
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
@@ -827,7 +829,10 @@ int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
     if (pointwise(g)) return use_pointwise(g, g.K, 0) ? 1 : 0;
     return (use_conv3x3(g, g.K, 0) && g.C <= 512) ? 1 : 0;
   }
-  if (pass == 1) return (pointwise(g) && use_pointwise(g, g.C, 0)) ? 1 : 0;
+  if (pass == 1) {
+    if (pointwise(g)) return use_pointwise(g, g.C, 0) ? 1 : 0;
+    return (use_conv3x3(g, g.C, 0) && conv3x3_epilogue_supported(g.N, g.K, g.C, g.H, g.W)) ? 1 : 0;
+  }
   if (pass == 2) {
     if (pointwise(g)) return pointwise_wgrad_geometry(g) ? 1 : 0;
     return (conv3x3_wgrad_enabled() && wgrad3x3_geometry(g)) ? 1 : 0;
@@ -865,8 +870,12 @@ int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, c
   epilogue.x = x; epilogue.x_bs = g.x_bs;
   epilogue.bn[0] = bn->mean; epilogue.bn[1] = bn->inv_std; epilogue.bn[2] = bn->gamma; epilogue.bn[3] = bn->beta;
   epilogue.g_gamma = g_gamma; epilogue.g_beta = g_beta;
-  return pointwise_run(gy, g.y_bs, w, 1, g.C, nullptr, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
-                       (hipStream_t)stream, nullptr, &epilogue);
+  if (pointwise(g))
+    return pointwise_run(gy, g.y_bs, w, 1, g.C, nullptr, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
+                         (hipStream_t)stream, nullptr, &epilogue);
+  SRGAN_REQUIRE(!accumulate, SRGAN_EUNSUPPORTED, "srgan_conv2d_bwd_data_bnrelu 3x3: gx is stored, not accumulated");
+  return conv3x3_run(gy, g.y_bs, w, 8, 9, g.C * 9, -3, -1, nullptr, gx, g.x_bs, g.N, g.K, g.C, g.H, g.W, 0,
+                     (hipStream_t)stream, nullptr, &epilogue);
 }
 
 int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,

@@ -340,6 +340,16 @@ int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
 float* partial_workspace(size_t bytes, hipStream_t stream);
 
+// g_beta[c] += sum_t partial[0][t][c];  g_gamma[c] += inv_std[c] * sum_t partial[1][t][c]   (t = workgroup tiles)
+void bn_partial_reduce_run(const float* partial, int tiles, int CO, const float* inv_std, float* g_gamma, float* g_beta,
+                           hipStream_t stream) {
+  int segments = tiles / 32;
+  segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
+  const int per = (tiles + segments - 1) / segments;
+  hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((CO + 63) / 64, (unsigned)((tiles + per - 1) / per)), dim3(256), 0, stream,
+                     partial, tiles, CO, inv_std, g_gamma, g_beta, per);
+}
+
 bool pointwise_enabled() {
   static const bool disabled = getenv("SRGAN_NO_POINTWISE") != nullptr;
   return !disabled;
@@ -457,13 +467,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     p.xcd_remap = 0;
     launch(rest_mi, dim3((unsigned)col_blocks, (unsigned)split, 1));
   }
-  if (p.epi_partial) {
-    int segments = (int)(col_blocks / 32);
-    segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
-    const int per = (int)((col_blocks + segments - 1) / segments);
-    hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((CO + 63) / 64, (unsigned)((col_blocks + per - 1) / per)), dim3(256), 0,
-                       stream, p.epi_partial, (int)col_blocks, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, per);
-  }
+  if (p.epi_partial) bn_partial_reduce_run(p.epi_partial, (int)col_blocks, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
   profile_bracket_end(stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);
   return status;

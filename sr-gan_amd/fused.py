@@ -75,6 +75,7 @@ def dense_block(x, layers):
     # of the data gradient, accumulated straight into the gradient buffer)
     epilogue1 = EPILOGUE and prologue and bool(lib.srgan_conv2d_bnrelu_supported(
         _desc(n, c0, h, w, width, 1, 1, 1, 0, buffer_bs, 0), 1))
+    epilogue2 = EPILOGUE and prologue and bool(lib.srgan_conv2d_bnrelu_supported(probe2, 1))
 
     def bn_struct(norm):
         inv, mean = norm._inverse_std()
@@ -141,13 +142,20 @@ def dense_block(x, layers):
             elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc2, t2.data_ptr(), g_new, layer.conv2.weight.grad.data_ptr(), 1, 0,
                         stream)
-            g_t2 = _empty(b1.shape, device)
-            F._call('srgan_conv2d_bwd_data', desc2, g_new, layer.conv2.weight.data_ptr(), None, g_t2.data_ptr(), 0, 0,
-                    stream)
             g_b1 = _empty(b1.shape, device)
-            F._call('srgan_bn_act_bwd', g_t2.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1, g_b1.data_ptr(),
-                    layer.norm2.weight.grad.data_ptr() if want_params else None,
-                    layer.norm2.bias.grad.data_ptr() if want_params else None, n, width, hw, 0, 0, 0, 0, 0, stream)
+            if epilogue2:
+                F._call('srgan_conv2d_bwd_data_bnrelu', desc2, g_new, layer.conv2.weight.data_ptr(),
+                        bn_struct(layer.norm2), b1.data_ptr(), g_b1.data_ptr(),
+                        layer.norm2.weight.grad.data_ptr() if want_params else None,
+                        layer.norm2.bias.grad.data_ptr() if want_params else None, 0, stream)
+            else:
+                g_t2 = _empty(b1.shape, device)
+                F._call('srgan_conv2d_bwd_data', desc2, g_new, layer.conv2.weight.data_ptr(), None, g_t2.data_ptr(), 0, 0,
+                        stream)
+                F._call('srgan_bn_act_bwd', g_t2.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1,
+                        g_b1.data_ptr(), layer.norm2.weight.grad.data_ptr() if want_params else None,
+                        layer.norm2.bias.grad.data_ptr() if want_params else None, n, width, hw, 0, 0, 0, 0, 0, stream)
+                del g_t2
             desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
             if want_params and prologue:
                 F._call('srgan_conv2d_bwd_weight_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0),

@@ -439,46 +439,57 @@ def test_fused_batch_norm_convolutions(F):
 @gpu
 def test_fused_batch_norm_backward_in_the_data_gradient(F):
     """srgan_conv2d_bwd_data_bnrelu (data gradient of norm -> relu -> conv w.r.t. the normalisation's input in one
-    kernel, parameter gradients included) against torch autograd of the two-step form; x / gx are channel-slice views
-    of wider buffers, gx is stored or accumulated, row counts with and without a remainder tile."""
+    kernel, parameter gradients included) against torch autograd of the two-step form.  1x1: x / gx are channel-slice
+    views of wider buffers, gx stored or accumulated, row counts with and without a remainder tile.  3x3: dense x / gx
+    (stored), gy a channel-slice view, 16- and 32-wide tiles, ragged heights."""
     from srgan_amd import _lib
     lib = _lib.library()
     stream = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator().manual_seed(29)
-    for (n, c, total, h, w, k) in [(2, 48, 80, 16, 16, 32), (3, 160, 160, 8, 32, 128), (2, 192, 224, 32, 32, 128),
-                                   (1, 512, 512, 8, 8, 40), (4, 96, 256, 64, 64, 128), (2, 300, 300, 16, 16, 128)]:
+    for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 192, 224, 32, 32, 128, 1),
+                                      (1, 512, 512, 8, 8, 40, 1), (4, 96, 256, 64, 64, 128, 1), (2, 300, 300, 16, 16, 128, 1),
+                                      (4, 128, 128, 32, 32, 32, 3), (16, 128, 128, 16, 16, 32, 3), (2, 128, 128, 64, 64, 32, 3),
+                                      (3, 40, 40, 20, 24, 16, 3), (16, 128, 128, 64, 64, 32, 3)]:
+        pad = r // 2
         wide = torch.randn(n, total, h, w, generator=gen)
         x = wide[:, :c].clone().requires_grad_(True)
         mean, var = torch.randn(c, generator=gen) * 0.3, torch.rand(c, generator=gen) + 0.5
         gamma = (torch.rand(c, generator=gen) + 0.5).requires_grad_(True)
         beta = (torch.randn(c, generator=gen) * 0.3).requires_grad_(True)
-        weight = torch.randn(k, c, 1, 1, generator=gen) / c ** 0.5
-        y = TF.conv2d(TF.batch_norm(x, mean, var, gamma, beta, training=False, eps=1e-5).relu(), weight)
-        gy = torch.randn(y.shape, generator=gen)
+        weight = torch.randn(k, c, r, r, generator=gen) / (c * r * r) ** 0.5
+        y = TF.conv2d(TF.batch_norm(x, mean, var, gamma, beta, training=False, eps=1e-5).relu(), weight, None, 1, pad)
+        gy_wide = torch.randn(n, k + 8, h, w, generator=gen)        # the 3x3 cases read gy through a channel-slice view
+        gy = gy_wide[:, 4:4 + k]
         gx_ref, ggamma_ref, gbeta_ref = torch.autograd.grad(y, (x, gamma, beta), gy)
         d = {name: dev(t.detach()) for name, t in dict(wide=wide, mean=mean, inv=(var + 1e-5).rsqrt(), gamma=gamma,
-                                                       beta=beta, weight=weight, gy=gy).items()}
-        desc = _lib.ConvDesc(n, c, h, w, k, 1, 1, 1, 1, 0, 0, h, w, total * h * w, 0)
+                                                       beta=beta, weight=weight, gy_wide=gy_wide,
+                                                       gy=gy.contiguous()).items()}
+        if r == 1:
+            desc = _lib.ConvDesc(n, c, h, w, k, 1, 1, 1, 1, 0, 0, h, w, total * h * w, 0)
+            gy_pointer = d['gy'].data_ptr()
+        else:
+            desc = _lib.ConvDesc(n, c, h, w, k, 3, 3, 1, 1, 1, 1, h, w, 0, (k + 8) * h * w)
+            gy_pointer = d['gy_wide'].data_ptr() + 4 * 4 * h * w
         bn = _lib.BnRelu(d['mean'].data_ptr(), d['inv'].data_ptr(), d['gamma'].data_ptr(), d['beta'].data_ptr())
-        assert lib.srgan_conv2d_bnrelu_supported(desc, 1) == 1, (n, c, h, w, k)
+        assert lib.srgan_conv2d_bnrelu_supported(desc, 1) == 1, (n, c, h, w, k, r)
         old = torch.randn(n, total, h, w, generator=gen)
-        for accumulate in (0, 1):
+        for accumulate in ((0, 1) if r == 1 else (0,)):
             gx_wide = dev(old)
             g_gamma, g_beta = torch.full((c,), 0.25, device='cuda'), torch.full((c,), -0.5, device='cuda')
-            _lib.check(lib.srgan_conv2d_bwd_data_bnrelu(desc, d['gy'].data_ptr(), d['weight'].data_ptr(), bn,
+            _lib.check(lib.srgan_conv2d_bwd_data_bnrelu(desc, gy_pointer, d['weight'].data_ptr(), bn,
                                                         d['wide'].data_ptr(), gx_wide.data_ptr(), g_gamma.data_ptr(),
                                                         g_beta.data_ptr(), accumulate, stream), 'bwd_data_bnrelu')
-            what = f'fused bn backward {k}->{c} {h}x{w} accumulate={accumulate}'
+            what = f'fused bn backward {k}->{c} k{r} {h}x{w} accumulate={accumulate}'
             close(gx_wide[:, :c], gx_ref + (old[:, :c] if accumulate else 0.0), what=what + ' gx')
             if total > c:
                 close(gx_wide[:, c:], old[:, c:], 0.0, what + ' (channels beyond the view untouched)')
             close(g_gamma, ggamma_ref + 0.25, what=what + ' gamma gradient')
             close(g_beta, gbeta_ref - 0.5, what=what + ' beta gradient')
         gx_wide = dev(old)                          # input gradient only (frozen parameters)
-        _lib.check(lib.srgan_conv2d_bwd_data_bnrelu(desc, d['gy'].data_ptr(), d['weight'].data_ptr(), bn,
+        _lib.check(lib.srgan_conv2d_bwd_data_bnrelu(desc, gy_pointer, d['weight'].data_ptr(), bn,
                                                     d['wide'].data_ptr(), gx_wide.data_ptr(), None, None, 0, stream),
                    'bwd_data_bnrelu')
-        close(gx_wide[:, :c], gx_ref, what=f'fused bn backward {k}->{c} (no parameter gradients)')
+        close(gx_wide[:, :c], gx_ref, what=f'fused bn backward {k}->{c} k{r} (no parameter gradients)')
     odd = _lib.ConvDesc(2, 32, 9, 7, 16, 1, 1, 1, 1, 0, 0, 9, 7, 0, 0)
     assert lib.srgan_conv2d_bnrelu_supported(odd, 1) == 0
 
