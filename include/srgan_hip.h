@@ -152,8 +152,11 @@ int srgan_copy_channels(const float* src, int32_t src_channels, int32_t src_firs
  * reference crowd/models.py:371,1075,1151; age/vgg.py:76. */
 int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t planes, int32_t H, int32_t W, int32_t k,
                         int32_t s, int32_t p, int32_t OH, int32_t OW, void* stream);
+int srgan_maxpool2d_bwd(const float* g, const int32_t* argmax, float* gx, int32_t planes, int32_t H, int32_t W, int32_t k,
+                        int32_t s, int32_t p, int32_t OH, int32_t OW, void* stream);   /* max-pool backward, gather form */
 int srgan_pool_scatter(const float* g, const int32_t* argmax, float* out, int32_t planes, int64_t in_plane,
-                       int64_t out_plane, void* stream);      /* max-pool backward (out is zero-filled first) */
+                       int64_t out_plane, void* stream);      /* out[argmax] += g (out is zero-filled first): backward of
+                                                                 srgan_pool_gather */
 int srgan_pool_gather(const float* src, const int32_t* argmax, float* out, int32_t planes, int64_t in_plane,
                       int64_t out_plane, void* stream);       /* max-pool double-backward */
 int srgan_avgpool2d_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t k, int32_t s,

@@ -31,7 +31,6 @@ struct Conv3Params {
   int32_t tiles_x, tiles_y, tiles_m;
   int32_t ci_per_split;
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
-  int32_t debug;        // tuning experiments only (SRGAN_CONV3_DEBUG): 1 = no re-staging, 2 = no MFMA
   // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
   // EPI: the output goes through the backward of relu(batch_norm_eval(epi_x)) on its way out (bn_* then describe the
@@ -180,12 +179,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     stage(cbeg);
     __syncthreads();
     for (int c0 = cbeg; c0 < cend; c0 += CI_T) {
-      const bool more = (c0 + CI_T < cend) && !(p.debug & 1);
+      const bool more = c0 + CI_T < cend;
       if (more) fetch(c0 + CI_T);
       // (the channel-pair loop is kept rolled: full unrolling makes the scheduler hoist hundreds of LDS reads and
       // spill; the 9 taps x MI x NI MFMAs inside are plenty of straight-line work)
 #pragma unroll 1
-      for (int cp = 0; cp < ((p.debug & 2) ? 0 : CI_T / 2); ++cp) {
+      for (int cp = 0; cp < CI_T / 2; ++cp) {
         const float* a_cp = a_base + cp * (2 * 9 * LDW);
         const float* b_cp = b_base + cp * (2 * PHPW);
 #pragma unroll
@@ -396,7 +395,6 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   SRGAN_REQUIRE(bn == nullptr || CI <= CONV3_PRO_MAX_CI, SRGAN_EUNSUPPORTED, "conv3x3 fused batch-norm channel count");
   p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
   p.in_bs = in_bs; p.out_bs = out_bs;
-  p.debug = getenv("SRGAN_CONV3_DEBUG") ? atoi(getenv("SRGAN_CONV3_DEBUG")) : 0;
   p.w_so = w_so; p.w_si = w_si; p.w_skh = w_skh; p.w_skw = w_skw; p.w_base = w_base;
   const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W);
   const int bm = plan.bm, th = plan.th, tw = plan.tw, split = plan.split;

@@ -358,8 +358,7 @@ bool pointwise_enabled() {
 template <int MI, int BK, int NI>
 static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t stream) {
   if (p.epi_x) {
-    if constexpr (BK == 32 && NI == 1)
-      hipLaunchKernelGGL((pointwise_kernel<MI, 32, false, 1, true>), grid, dim3(256), 0, stream, p);
+    if constexpr (NI == 1) hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, 1, true>), grid, dim3(256), 0, stream, p);
     return;
   }
   if (p.bn_mean) hipLaunchKernelGGL((pointwise_kernel<MI, BK, true, NI>), grid, dim3(256), 0, stream, p);
@@ -401,7 +400,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
       if (mi > mi_cap) mi = mi_cap;
     }
   }
-  static const int min_wgs = getenv("SRGAN_PW_MIN_WGS") ? atoi(getenv("SRGAN_PW_MIN_WGS")) : 1024;
+  static const int min_wgs = getenv("SRGAN_PW_MIN_WGS") ? atoi(getenv("SRGAN_PW_MIN_WGS")) : 768;
   while (mi > 1 && col_blocks * ((CO + mi * 32 - 1) / (mi * 32)) < min_wgs) mi >>= 1;
   // Rows beyond the last full 128-row tile go to a second launch with a tile just tall enough for them (the data
   // gradients of the bottlenecks have 64 + 32*l rows: a padded 128-row tile would waste up to 3/8 of the matrix work).
@@ -443,20 +442,12 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     }
   }
   profile_bracket_begin(stream);
-  static const int bk_env = getenv("SRGAN_PW_BK") ? atoi(getenv("SRGAN_PW_BK")) : 32;
-  const int bk = epilogue ? 32 : bk_env;
+  // (K slices of 64 measured no faster and spill at 128 rows: the slice is 32 channels.)
   auto launch = [&](int mi_, dim3 grid) {
-    if (ni == 2) {
-      launch_pointwise<2, 32, 2>(p, grid, stream);
-    } else if (bk == 64) {
-      if (mi_ == 4) launch_pointwise<4, 64, 1>(p, grid, stream);
-      else if (mi_ == 2) launch_pointwise<2, 64, 1>(p, grid, stream);
-      else launch_pointwise<1, 64, 1>(p, grid, stream);
-    } else {
-      if (mi_ == 4) launch_pointwise<4, 32, 1>(p, grid, stream);
-      else if (mi_ == 2) launch_pointwise<2, 32, 1>(p, grid, stream);
-      else launch_pointwise<1, 32, 1>(p, grid, stream);
-    }
+    if (ni == 2) launch_pointwise<2, 32, 2>(p, grid, stream);
+    else if (mi_ == 4) launch_pointwise<4, 32, 1>(p, grid, stream);
+    else if (mi_ == 2) launch_pointwise<2, 32, 1>(p, grid, stream);
+    else launch_pointwise<1, 32, 1>(p, grid, stream);
   };
   static const bool no_xcd = getenv("SRGAN_NO_XCD_ORDER") != nullptr;
   p.xcd_remap = (!no_xcd && p.tiles_m > 1 && blocks % 8 == 0) ? 1 : 0;

@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void pool_scatter_kernel(const float* __restri
   }
 }
 
+// Max-pool backward in gather form: gx[h, w] = sum of g over the windows that contain (h, w) AND chose it.  Every input
+// element is written exactly once (no zero-fill, no atomics); the <= ceil(k/s)^2 window look-ups per element hit L2.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ gx, int H, int W, int k, int s, int p,
+                                                          int OH, int OW, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int64_t plane = i / ((int64_t)W * H);
+    const float* src = g + plane * OH * OW;
+    const int32_t* chosen = idx + plane * OH * OW;
+    int oh_lo = h + p - k + 1; oh_lo = oh_lo > 0 ? (oh_lo + s - 1) / s : 0;
+    int ow_lo = w + p - k + 1; ow_lo = ow_lo > 0 ? (ow_lo + s - 1) / s : 0;
+    int oh_hi = (h + p) / s; if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_hi = (w + p) / s; if (ow_hi > OW - 1) ow_hi = OW - 1;
+    const int32_t me = h * W + w;
+    float acc = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow)
+        if (chosen[oh * OW + ow] == me) acc += src[oh * OW + ow];
+    gx[i] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                           float* __restrict__ out, int64_t in_plane, int64_t out_plane,
                                                           int64_t n) {
@@ -106,6 +131,16 @@ int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t plane
   const int64_t n = (int64_t)planes * OH * OW;
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, H,
                      W, k, s, p, OH, OW, n);
+  return launch_status();
+}
+
+int srgan_maxpool2d_bwd(const float* g, const int32_t* argmax, float* gx, int32_t planes, int32_t H, int32_t W, int32_t k,
+                        int32_t s, int32_t p, int32_t OH, int32_t OW, void* stream) {
+  SRGAN_REQUIRE(g && argmax && gx && planes > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0 && OH > 0 && OW > 0,
+                SRGAN_EINVAL, "srgan_maxpool2d_bwd arguments");
+  const int64_t n = (int64_t)planes * H * W;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, argmax, gx, H, W,
+                     k, s, p, OH, OW, n);
   return launch_status();
 }
 

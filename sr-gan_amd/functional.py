@@ -608,7 +608,19 @@ def max_pool2d(x, kernel_size, stride, padding=0):
     _call('srgan_maxpool2d_fwd', _ptr(x), data.data_ptr(), argmax.data_ptr(), n * c, h, w, kernel_size, stride, padding,
           oh, ow, _stream())
     in_shape = x.shape
-    return _out(data, (x,), lambda g, needs: (_pool_scatter(g, argmax, in_shape),), 'max_pool2d')
+    geometry = (kernel_size, stride, padding, oh, ow)
+    return _out(data, (x,), lambda g, needs: (_max_pool2d_backward(g, argmax, in_shape, geometry),), 'max_pool2d')
+
+
+def _max_pool2d_backward(g, argmax, in_shape, geometry):
+    """Gather form (every input element written once: no zero-fill, no atomics); its own backward is the gather of
+    the incoming tensor at the forward's arg-max, as for the scatter form."""
+    n, c, h, w = in_shape
+    kernel_size, stride, padding, oh, ow = geometry
+    data = _empty(in_shape, g.data)
+    _call('srgan_maxpool2d_bwd', _ptr(g), argmax.data_ptr(), data.data_ptr(), n * c, h, w, kernel_size, stride, padding,
+          oh, ow, _stream())
+    return _out(data, (g,), lambda gg, needs: (_pool_gather(gg, argmax, g.shape),), 'max_pool2d_backward')
 
 
 def _pool_scatter(g, argmax, in_shape):

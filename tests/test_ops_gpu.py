@@ -282,6 +282,14 @@ def test_pooling_and_layout(F):
     out = F.max_pool2d(F.relu(xv), 3, 2, 1)
     backward(out, grad=F.leaf(dev(g)))
     close(xv.grad, xr.grad, 1e-6, 'maxpool backward with ties')
+    for (k, s, p, h, w) in [(2, 2, 0, 12, 10), (3, 1, 1, 9, 7), (3, 2, 1, 16, 16), (3, 3, 0, 10, 11), (2, 1, 0, 5, 6)]:
+        x3 = torch.randn(3, 4, h, w, generator=gen).requires_grad_()      # gather-form backward: every window overlap
+        ref = TF.max_pool2d(x3, k, s, p)
+        g = torch.randn(ref.shape, generator=gen)
+        ref.backward(g)
+        x3v = F.leaf(dev(x3.detach()), requires_grad=True)
+        backward(F.max_pool2d(x3v, k, s, p), grad=F.leaf(dev(g)))
+        close(x3v.grad, x3.grad, 1e-6, f'maxpool backward k{k} s{s} p{p}')
     for (k, s) in [(2, 2), (3, 1), (4, 4)]:
         x2 = torch.randn(2, 3, 12, 12, generator=gen).requires_grad_()
         ref = TF.avg_pool2d(x2, k, s)
