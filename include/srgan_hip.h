@@ -121,6 +121,14 @@ int srgan_chan_affine_act_strided(const float* x, const float* mean, const float
                                   const float* shift, const float* mask, int relu, float* y, int32_t N, int32_t C,
                                   int64_t HW, int64_t x_batch_stride, int64_t mask_batch_stride, int64_t y_batch_stride,
                                   int accumulate, void* stream);
+/* Per-weight-element part of the DOUBLE backward of norm -> relu -> conv (gradient penalty, reference
+ * srgan.py:360-375 through crowd/models.py:338-345), w and q shaped [CO][CI][taps], a = inv_std * gamma per input
+ * channel: w_scaled = w * a (optional); when q (the weight gradient taken with the masked, unscaled tangent) is
+ * given: w_grad += q * a and gamma_grad[ci] += inv_std[ci] * sum_{co,tap} w * q. */
+int srgan_bn_conv_tangent_weights(const float* w, const float* q, const float* inv_std, const float* gamma,
+                                  float* w_scaled, float* w_grad, float* gamma_grad, int32_t CO, int32_t CI, int32_t taps,
+                                  void* stream);
+
 /* Whole backward of frozen batch-norm (+ReLU when relu != 0) in one pass over (g, x): the activation mask is
  * recomputed from x (y = fma(x, a, b), a = inv_std*gamma, b = beta - mean*a, exactly the forward's arithmetic);
  * gx (=,+=) g*[y>0]*a (gx may be NULL; g / x / gx may be channel-slice views, batch stride 0 = dense; unscaled != 0

@@ -181,6 +181,43 @@ __global__ __launch_bounds__(256) void chan_reduce_cols_kernel(const float* __re
   out[c] = accumulate ? out[c] + acc : acc;
 }
 
+// Double backward of norm -> relu -> conv (fused.py, reference srgan.py:360-375 through crowd/models.py:338-345):
+// everything that is per weight element, in one launch over w[CO][inner] (inner = CI * taps, channel = j / taps):
+//   w_scaled = w * a[ci]                        (the linearised forward runs on the masked UNSCALED tangent)
+//   w_grad  += q * a[ci]                        (q = weight gradient w.r.t. the scaled weights)
+//   gamma_grad[ci] += inv_std[ci] * sum_{co, tap} w * q
+// Lanes along the contiguous inner index, four row-lanes over CO combined through LDS.
+__global__ __launch_bounds__(256) void tangent_weight_kernel(const float* __restrict__ w, const float* __restrict__ q,
+                                                             const float* __restrict__ inv_std,
+                                                             const float* __restrict__ gamma, float* __restrict__ w_scaled,
+                                                             float* __restrict__ w_grad, float* __restrict__ gamma_grad,
+                                                             int CO, int inner, int taps) {
+  __shared__ float scratch[4][64];
+  const int jl = (int)threadIdx.x & 63, cl = (int)threadIdx.x >> 6;
+  const int j = (int)blockIdx.x * 64 + jl;
+  const bool live = j < inner;
+  const int ci = live ? j / taps : 0;
+  const float a = __fmul_rn(inv_std[ci], gamma[ci]);
+  float dot = 0.f;
+  if (live)
+    for (int co = cl; co < CO; co += 4) {
+      const int64_t at = (int64_t)co * inner + j;
+      const float wv = w[at];
+      if (w_scaled) w_scaled[at] = wv * a;
+      if (q) {
+        const float qv = q[at];
+        w_grad[at] += qv * a;
+        dot = fmaf(wv, qv, dot);
+      }
+    }
+  if (q == nullptr) return;
+  scratch[cl][jl] = dot;
+  __syncthreads();
+  if (cl != 0 || !live) return;
+  dot = (scratch[0][jl] + scratch[1][jl]) + (scratch[2][jl] + scratch[3][jl]);
+  unsafeAtomicAdd(gamma_grad + ci, dot * inv_std[ci]);
+}
+
 // out[b] = max_f x[b, f]  (the stabiliser of logsumexp, reference utility.py:179); F is small (bins).
 __global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int F) {
   const int b = blockIdx.x * 256 + threadIdx.x;
@@ -262,6 +299,19 @@ int srgan_chan_reduce(const float* a, const float* b, const float* mean, const f
   if (!accumulate) SRGAN_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s));
   hipLaunchKernelGGL(chan_reduce_rows_kernel, dim3(C, N * segs), dim3(256), 0, s, a, b, mean, scale, out, C, HW,
                      segs);
+  return launch_status();
+}
+
+int srgan_bn_conv_tangent_weights(const float* w, const float* q, const float* inv_std, const float* gamma,
+                                  float* w_scaled, float* w_grad, float* gamma_grad, int32_t CO, int32_t CI, int32_t taps,
+                                  void* stream) {
+  SRGAN_REQUIRE(w && inv_std && gamma && CO > 0 && CI > 0 && taps > 0 && (w_scaled || q), SRGAN_EINVAL,
+                "srgan_bn_conv_tangent_weights arguments");
+  SRGAN_REQUIRE(q == nullptr || (w_grad && gamma_grad), SRGAN_EINVAL, "srgan_bn_conv_tangent_weights gradient outputs");
+  const int64_t inner = (int64_t)CI * taps;
+  SRGAN_REQUIRE(inner < ((int64_t)1 << 31), SRGAN_ERANGE, "srgan_bn_conv_tangent_weights size");
+  hipLaunchKernelGGL(tangent_weight_kernel, dim3((unsigned)((inner + 63) / 64)), dim3(256), 0, (hipStream_t)stream, w, q,
+                     inv_std, gamma, w_scaled, w_grad, gamma_grad, CO, (int)inner, taps);
   return launch_status();
 }
 

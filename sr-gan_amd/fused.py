@@ -219,17 +219,15 @@ def dense_block(x, layers):
             u1 = _empty((n, cin, h, w), device)
             F._call('srgan_bn_act_bwd', vbuf.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, u1.data_ptr(),
                     None, None, n, cin, hw, buffer_bs, buffer_bs, 0, 0, 1, stream)
+            q1 = None
             if want_params:
                 q1 = _empty(w1.shape, device)
                 F._call('srgan_conv2d_bwd_weight', desc1, u1.data_ptr(), g_b1.data_ptr(), q1.data_ptr(), 0, 0, stream)
-                # dL/dW1 += q1 * (inv_std * gamma)[ci];  dL/dgamma1 += inv_std * sum_co W1 * q1
-                F._call('srgan_chan_affine_act_strided', q1.data_ptr(), None, inv1, gamma1, None, None, 0,
-                        w1.grad.data_ptr(), width, cin, 1, 0, 0, 0, 1, stream)
-                F._call('srgan_chan_reduce', w1.data_ptr(), q1.data_ptr(), None, inv1, layer.norm1.weight.grad.data_ptr(),
-                        width, cin, 1, 1, stream)
+            # w1s = W1 * a;  dL/dW1 += q1 * a;  dL/dgamma1 += inv_std * sum_co W1 * q1   (a = inv_std * gamma per ci)
             w1s = _empty(w1.shape, device)
-            F._call('srgan_chan_affine_act', w1.data_ptr(), None, inv1, gamma1, None, None, 0, w1s.data_ptr(), width, cin, 1,
-                    stream)
+            F._call('srgan_bn_conv_tangent_weights', w1.data_ptr(), q1.data_ptr() if want_params else None, inv1, gamma1,
+                    w1s.data_ptr(), w1.grad.data_ptr() if want_params else None,
+                    layer.norm1.weight.grad.data_ptr() if want_params else None, width, cin, 1, stream)
             b1_tangent = _empty(b1.shape, device)
             F._call('srgan_conv2d_fwd', desc1, u1.data_ptr(), w1s.data_ptr(), None, b1_tangent.data_ptr(), 0, stream)
             del u1
@@ -237,16 +235,14 @@ def dense_block(x, layers):
             u2 = _empty(b1.shape, device)
             F._call('srgan_bn_act_bwd', b1_tangent.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1, u2.data_ptr(),
                     None, None, n, width, hw, 0, 0, 0, 0, 1, stream)
+            q2 = None
             if want_params:
                 q2 = _empty(w2.shape, device)
                 F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), q2.data_ptr(), 0, 0, stream)
-                F._call('srgan_chan_affine_act_strided', q2.data_ptr(), None, inv2, gamma2, None, None, 0,
-                        w2.grad.data_ptr(), growth, width, 9, 0, 0, 0, 1, stream)
-                F._call('srgan_chan_reduce', w2.data_ptr(), q2.data_ptr(), None, inv2, layer.norm2.weight.grad.data_ptr(),
-                        growth, width, 9, 1, stream)
             w2s = _empty(w2.shape, device)
-            F._call('srgan_chan_affine_act', w2.data_ptr(), None, inv2, gamma2, None, None, 0, w2s.data_ptr(), growth, width,
-                    9, stream)
+            F._call('srgan_bn_conv_tangent_weights', w2.data_ptr(), q2.data_ptr() if want_params else None, inv2, gamma2,
+                    w2s.data_ptr(), w2.grad.data_ptr() if want_params else None,
+                    layer.norm2.weight.grad.data_ptr() if want_params else None, growth, width, 9, stream)
             F._call('srgan_conv2d_fwd', desc2, u2.data_ptr(), w2s.data_ptr(), None, _ptr(vbuf, cin * hw), 0, stream)
             kept[index] = None
         return (Var(vbuf) if needs2[0] else None,) + (None,) * len(parameter_vars)
