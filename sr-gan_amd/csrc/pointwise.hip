@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
   static_assert(!EPI || (!PRO && NI == 1), "the batch-norm backward epilogue pairs with the plain single-group kernel");
   constexpr int BM = MI * 32, KP = BK / 2, LDA = BM + 1;
   constexpr int EA = BM * BK / 256;
-  __shared__ float lds[2 * BK * LDA];
+  constexpr int LDT = 128 + 4;                                     // EPI: row stride of the staged output tile
+  constexpr int LDS_MAIN = 2 * BK * LDA, LDS_EPI = EPI ? BM * LDT + BM * 4 : 0;
+  __shared__ float lds[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
   __shared__ float2 coef[2][PRO ? BK : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
@@ -204,20 +206,6 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     }
   };
 
-  // EPI state (declared here so that both phases see it)
-  const float* x_lane = p.epi_x + (int64_t)n * p.epi_x_bs + pix;
-  float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
-  const bool sums_wanted = p.epi_partial != nullptr;
-  float xs[2][16], olds[2][16];
-  auto fetch = [&](int mi, float (&x)[16], float (&old)[16], auto accumulate) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = min(m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, p.CO - 1);
-      x[r] = x_lane[(int64_t)o * p.HW];
-      if constexpr (decltype(accumulate)::value) old[r] = out_lane[(int64_t)o * p.HW];
-    }
-  };
-
   if (kbeg < kend) {
     fetch_a(kbeg);
     fetch_b(kbeg, b0);
@@ -230,15 +218,20 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
   }
 
   if (EPI) {
-    // Loads first, stores last: the compiler cannot prove that the stores do not alias x or the accumulated gradient,
-    // so a load issued after a store waits for it.  The loads of 32-row block mi + 1 are issued before block mi is
-    // written (two register sets); block 0's go out before the coefficient table is built.  (Requesting block 0
-    // before the K loop measured the same and costs 32 registers = one workgroup per CU of occupancy at 64 rows.)
-    if (p.mode == 0) fetch(0, xs[0], olds[0], std::false_type{});
-    else fetch(0, xs[0], olds[0], std::true_type{});
+    // The accumulator tile goes through LDS so that the epilogue works on float4s along the pixels: a half-wave owns
+    // one output row (512 contiguous bytes per global access instead of 128, a quarter of the instructions), every
+    // lane pre-sums its four pixels before the cross-lane reduction of the parameter gradients, and a row's sums are
+    // complete inside one half-wave -- no second combine.  Loads first, stores last (the compiler cannot prove that
+    // the stores do not alias x or the accumulated gradient, so a load issued after a store would wait for it).
+    static_assert(!EPI || MI <= 2, "the staged output tile of the epilogue fits the LDS up to 64 rows");
     __syncthreads();                               // every wave is done with the weight tiles: the LDS is reused
-    float* table = lds;                            // [BM][4]: a, b, mean of output row m0 + i
-    float* sums = lds + BM * 4;                    // [4 waves][2][BM]
+    float* tile = lds;                             // [BM][LDT]
+    float* table = lds + BM * LDT;                 // [BM][4]: a, b, mean of output row m0 + i
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDT + wave * 32 + l31] = acc[mi][0][r];
     if (tid < BM) {
       const int o = min(m0 + tid, p.CO - 1);
       const float mu = p.bn_mean[o];
@@ -247,49 +240,65 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
       table[tid * 4 + 0] = a; table[tid * 4 + 1] = b; table[tid * 4 + 2] = mu;
     }
     __syncthreads();
+    constexpr int RPT = BM / 8;                    // rows per thread: row = (tid >> 5) + 8 * e
+    const int half = tid >> 5, q4 = (tid & 31) * 4;
+    const int64_t my_pixel0 = ((int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5)) * 32;       // this lane's 32-pixel group
+    const bool my_live = my_pixel0 < total;
+    const int my_n = my_live ? (int)(my_pixel0 / p.HW) : 0;
+    const int my_pix = (my_live ? (int)(my_pixel0 - (int64_t)my_n * p.HW) : 0) + (q4 & 31);
+    const float* x_lane = p.epi_x + (int64_t)my_n * p.epi_x_bs + my_pix;
+    float* out_lane = p.out + (int64_t)my_n * p.out_bs + my_pix;
+    const bool sums_wanted = p.epi_partial != nullptr;
     auto emit = [&](auto accumulate) {
+      float4 xs[RPT], olds[RPT];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (mi + 1 < MI) fetch(mi + 1, xs[(mi + 1) & 1], olds[(mi + 1) & 1], accumulate);
+      for (int e = 0; e < RPT; ++e) {
+        const int o = min(m0 + half + 8 * e, p.CO - 1);
+        xs[e] = *reinterpret_cast<const float4*>(x_lane + (int64_t)o * p.HW);
+        if constexpr (decltype(accumulate)::value) olds[e] = *reinterpret_cast<const float4*>(out_lane + (int64_t)o * p.HW);
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          const int o = m0 + row;
-          const bool ok = live && o < p.CO;
-          const float4 t = *reinterpret_cast<const float4*>(table + row * 4);
-          const float xv = xs[mi & 1][r];
-          const float v = (ok && fmaf(xv, t.x, t.y) > 0.f) ? acc[mi][0][r] : 0.f;
-          if (ok) {
-            float* dst = out_lane + (int64_t)o * p.HW;
-            if constexpr (decltype(accumulate)::value) *dst = olds[mi & 1][r] + v * t.x;
-            else __builtin_nontemporal_store(v * t.x, dst);
+      for (int e = 0; e < RPT; ++e) {
+        const int row = half + 8 * e;
+        const int o = m0 + row;
+        const bool ok = my_live && o < p.CO;
+        const float4 t = *reinterpret_cast<const float4*>(table + row * 4);
+        float4 v = *reinterpret_cast<const float4*>(tile + row * LDT + q4);
+        const float4 x = xs[e];
+        v.x = (ok && fmaf(x.x, t.x, t.y) > 0.f) ? v.x : 0.f;
+        v.y = (ok && fmaf(x.y, t.x, t.y) > 0.f) ? v.y : 0.f;
+        v.z = (ok && fmaf(x.z, t.x, t.y) > 0.f) ? v.z : 0.f;
+        v.w = (ok && fmaf(x.w, t.x, t.y) > 0.f) ? v.w : 0.f;
+        if (ok) {
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          v4f result;
+          result.x = v.x * t.x; result.y = v.y * t.x; result.z = v.z * t.x; result.w = v.w * t.x;
+          v4f* dst = reinterpret_cast<v4f*>(out_lane + (int64_t)o * p.HW);
+          if constexpr (decltype(accumulate)::value) {
+            result.x += olds[e].x; result.y += olds[e].y; result.z += olds[e].z; result.w += olds[e].w;
+            *dst = result;
+          } else {
+            __builtin_nontemporal_store(result, dst);
           }
-          if (sums_wanted) {
-            const float plain = half_wave_sum(v), centred = half_wave_sum(v * (xv - t.z));
-            if (l31 == 31) {
-              sums[(wave * 2 + 0) * BM + row] = plain;
-              sums[(wave * 2 + 1) * BM + row] = centred;
-            }
+        }
+        if (sums_wanted) {
+          const float plain = half_wave_sum((v.x + v.y) + (v.z + v.w));
+          const float centred = half_wave_sum((v.x * (x.x - t.z) + v.y * (x.y - t.z)) + (v.z * (x.z - t.z) + v.w * (x.w - t.z)));
+          if (l31 == 31 && o < p.CO) {
+            float* partial = p.epi_partial + (int64_t)(bid / p.tiles_m) * p.CO + o;
+            partial[0] = plain;
+            partial[(int64_t)p.epi_cols * p.CO] = centred;
           }
         }
       }
     };
     if (p.mode == 0) emit(std::false_type{});
     else emit(std::true_type{});
-    if (sums_wanted) {
-      __syncthreads();
-      if (tid < 2 * BM) {
-        const int q = tid / BM, row = tid - q * BM;
-        const float total = (sums[(0 * 2 + q) * BM + row] + sums[(1 * 2 + q) * BM + row]) +
-                            (sums[(2 * 2 + q) * BM + row] + sums[(3 * 2 + q) * BM + row]);
-        const int o = m0 + row;
-        if (o < p.CO) p.epi_partial[((int64_t)q * p.epi_cols + bid / p.tiles_m) * p.CO + o] = total;
-      }
-    }
     return;
   }
   if (!live) return;
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+  float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
   // Three straight-line passes selected once (store / accumulate / atomic): with the mode tested per element the
   // 16 * MI stores of a lane are separated by branches and cannot be issued back to back.
   auto emit = [&](auto&& write) {
@@ -358,7 +367,8 @@ bool pointwise_enabled() {
 template <int MI, int BK, int NI>
 static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t stream) {
   if (p.epi_x) {
-    if constexpr (NI == 1) hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, 1, true>), grid, dim3(256), 0, stream, p);
+    if constexpr (NI == 1 && MI <= 2)
+      hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, 1, true>), grid, dim3(256), 0, stream, p);
     return;
   }
   if (p.bn_mean) hipLaunchKernelGGL((pointwise_kernel<MI, BK, true, NI>), grid, dim3(256), 0, stream, p);
@@ -389,6 +399,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   const int mi_cap = CI <= 128 ? mi_cap_short : mi_cap_long;
   int mi = CO > 64 ? 4 : (CO > 32 ? 2 : 1);
   if (mi > mi_cap) mi = mi_cap;
+  if (epilogue && mi > 2) mi = 2;
   // NI = 2 pairs with the 64-row tile (acc 64 + 2 x 32 operand registers; 128 rows x 64 pixels would spill)
   if (ni == 2) {
     if (mi > 2) mi = 2;
@@ -433,6 +444,9 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   }
   if (epilogue) {
     SRGAN_REQUIRE(!bn && !bias, SRGAN_EINVAL, "pointwise batch-norm backward epilogue: no prologue, no bias");
+    SRGAN_REQUIRE(mi <= 2 && rest == 0, SRGAN_EUNSUPPORTED, "pointwise batch-norm backward epilogue: at most 64-row tiles");
+    SRGAN_REQUIRE(((((uintptr_t)epilogue->x | (uintptr_t)out) & 15) | ((epilogue->x_bs | out_bs) & 3)) == 0, SRGAN_EINVAL,
+                  "pointwise batch-norm backward epilogue: 16-byte aligned x / gx rows");
     p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
     p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
     p.epi_cols = (int32_t)col_blocks;
