@@ -35,6 +35,7 @@ struct PointwiseParams {
   int32_t m_base;       // first output row of this launch (a second launch covers a shorter remainder tile)
   int32_t k_per_split;
   int32_t mode;         // 0 store, 1 accumulate, 2 atomic
+  int32_t wide_out;     // out rows / batch stride 16-byte aligned: modes 0 and 1 store float4 rows through LDS
   // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
   // EPI: the output rows go through the backward of relu(batch_norm_eval(epi_x)) on their way out (bn_* then describe
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
   constexpr int BM = MI * 32, KP = BK / 2, LDA = BM + 1;
   constexpr int EA = BM * BK / 256;
   constexpr int LDT = 128 + 4;                                     // EPI: row stride of the staged output tile
-  constexpr int LDS_MAIN = 2 * BK * LDA, LDS_EPI = EPI ? BM * LDT + BM * 4 : 0;
+  constexpr bool STAGED = MI <= 2 && NI == 1;                      // the output tile can go through LDS (<= 64 rows)
+  constexpr int LDS_MAIN = 2 * BK * LDA, LDS_EPI = STAGED ? BM * LDT + BM * 4 : 0;
   __shared__ float lds[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
   __shared__ float2 coef[2][PRO ? BK : 1];
 
@@ -296,6 +298,42 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     else emit(std::true_type{});
     return;
   }
+  if (STAGED && p.wide_out && p.mode != 2) {
+    // Store / accumulate through LDS as float4 rows (see the EPI epilogue: 512 contiguous bytes per access, a quarter
+    // of the instructions); rows and batch strides are 16-byte aligned (checked by the launcher).
+    __syncthreads();
+    float* tile = lds;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDT + wave * 32 + l31] = acc[mi][0][r];
+    __syncthreads();
+    constexpr int RPT = BM / 8;
+    const int half = tid >> 5, q4 = (tid & 31) * 4;
+    const int64_t my_pixel0 = ((int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5)) * 32;
+    if (my_pixel0 >= total) return;
+    const int my_n = (int)(my_pixel0 / p.HW);
+    float* out_lane = p.out + (int64_t)my_n * p.out_bs + (int)(my_pixel0 - (int64_t)my_n * p.HW) + (q4 & 31);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f olds[RPT];
+    if (p.mode == 1) {
+#pragma unroll
+      for (int e = 0; e < RPT; ++e)
+        olds[e] = *reinterpret_cast<const v4f*>(out_lane + (int64_t)min(m0 + half + 8 * e, p.CO - 1) * p.HW);
+    }
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+      const int row = half + 8 * e, o = m0 + row;
+      if (o >= p.CO) continue;
+      v4f v = *reinterpret_cast<const v4f*>(tile + row * LDT + q4);
+      if (p.bias) v += p.bias[o];
+      v4f* dst = reinterpret_cast<v4f*>(out_lane + (int64_t)o * p.HW);
+      if (p.mode == 1) *dst = olds[e] + v;
+      else __builtin_nontemporal_store(v, dst);                    // consumed by a later kernel
+    }
+    return;
+  }
   if (!live) return;
   const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
   float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
@@ -455,6 +493,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
       SRGAN_REQUIRE(p.epi_partial, (int)hipErrorOutOfMemory, "pointwise batch-norm backward workspace");
     }
   }
+  static const bool narrow = getenv("SRGAN_PW_NARROW_OUT") != nullptr;
+  p.wide_out = (!narrow && (((uintptr_t)out & 15) | (out_bs & 3)) == 0) ? 1 : 0;
   profile_bracket_begin(stream);
   // (K slices of 64 measured no faster and spill at 128 rows: the slice is 32 channels.)
   auto launch = [&](int mi_, dim3 grid) {
