@@ -45,6 +45,21 @@ __device__ __forceinline__ void bn_coefficients(float mean, float inv_std, float
   b = __fsub_rn(beta, __fmul_rn(mean, a));
 }
 
+// Sum over the 32 lanes of each half of the wave, valid in lanes 16-31 / 48-63: four rotations inside the rows of 16
+// (DPP row_ror) and one row broadcast (row_bcast:15 into rows 1 and 3) -- five VALU instructions, no LDS.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += dpp_move<0x128, 0xF>(v);
+  v += dpp_move<0x124, 0xF>(v);
+  v += dpp_move<0x122, 0xF>(v);
+  v += dpp_move<0x121, 0xF>(v);
+  v += dpp_move<0x142, 0xA>(v);
+  return v;
+}
+
 // Backward of relu(batch_norm_eval(x)) applied in the epilogue of a data-gradient kernel (pointwise.hip, conv3x3.hip):
 // x is the tensor the normalisation read (batch stride x_bs, same channels as the kernel's output), bn = {mean,
 // inv_std, gamma, beta}; g_gamma / g_beta (both or neither) are accumulated into.

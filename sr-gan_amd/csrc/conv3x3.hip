@@ -39,20 +39,6 @@ struct Conv3Params {
   float* epi_partial; int32_t epi_tiles;
 };
 
-// Sum over the 32 lanes of each half of the wave, valid in lanes 16-31 / 48-63 (DPP row rotations + row broadcast).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move3(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
-}
-__device__ __forceinline__ float half_wave_sum3(float v) {
-  v += dpp_move3<0x128, 0xF>(v);
-  v += dpp_move3<0x124, 0xF>(v);
-  v += dpp_move3<0x122, 0xF>(v);
-  v += dpp_move3<0x121, 0xF>(v);
-  v += dpp_move3<0x142, 0xA>(v);
-  return v;
-}
-
 constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range whose (a, b) fit the LDS table
 
 // PRO = frozen batch-norm + ReLU fused into the patch staging (reference crowd/models.py:342-345: norm2, relu2,
@@ -259,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
           centred += v * (xs[ni][r] - t.z);
         }
         if (sums_wanted) {
-          plain = half_wave_sum3(plain);
-          centred = half_wave_sum3(centred);
+          plain = half_wave_sum(plain);
+          centred = half_wave_sum(centred);
           if (l31 == 31) {
             sums[(wave * 2 + 0) * BM + row] = plain;
             sums[(wave * 2 + 1) * BM + row] = centred;
