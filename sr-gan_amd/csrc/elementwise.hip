@@ -164,14 +164,15 @@ __global__ __launch_bounds__(256) void chan_affine_flat_kernel(const float* __re
 }
 
 // dst[n, d0 + c, :] (=, +=) src[n, s0 + c, :] for c < count: a contiguous run of count*HW floats per image.
+template <typename I>      // element index type: 32-bit unless the tensor has > 2^31 elements (64-bit division is emulated)
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                             int64_t src_image, int64_t dst_image, int64_t src_off,
                                                             int64_t dst_off, int64_t run, int N, int accumulate) {
-  const int64_t total = run * N, stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-    const int64_t n = i / run, r = i - n * run;
-    const float v = src[n * src_image + src_off + r];
-    float* d = dst + n * dst_image + dst_off + r;
+  const I total = (I)(run * N), stride = (I)gridDim.x * 256, run_i = (I)run;
+  for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const I n = i / run_i, r = i - n * run_i;
+    const float v = src[(int64_t)n * src_image + src_off + r];
+    float* d = dst + (int64_t)n * dst_image + dst_off + r;
     *d = accumulate ? *d + v : v;
   }
 }
@@ -305,9 +306,14 @@ int srgan_copy_channels(const float* src, int32_t src_channels, int32_t src_firs
   SRGAN_REQUIRE(src_first >= 0 && dst_first >= 0 && src_first + count <= src_channels &&
                 dst_first + count <= dst_channels, SRGAN_EINVAL, "srgan_copy_channels channel ranges");
   const int64_t run = (int64_t)count * HW;
-  hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid(run * N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, src,
-                     dst, (int64_t)src_channels * HW, (int64_t)dst_channels * HW, (int64_t)src_first * HW,
-                     (int64_t)dst_first * HW, run, N, accumulate);
+  if (run * N < ((int64_t)1 << 31) - ((int64_t)2048 * 256))
+    hipLaunchKernelGGL(copy_channels_kernel<uint32_t>, dim3(stream_grid(run * N, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, (int64_t)src_channels * HW, (int64_t)dst_channels * HW, (int64_t)src_first * HW,
+                       (int64_t)dst_first * HW, run, N, accumulate);
+  else
+    hipLaunchKernelGGL(copy_channels_kernel<int64_t>, dim3(stream_grid(run * N, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, (int64_t)src_channels * HW, (int64_t)dst_channels * HW, (int64_t)src_first * HW,
+                       (int64_t)dst_first * HW, run, N, accumulate);
   return launch_status();
 }
 

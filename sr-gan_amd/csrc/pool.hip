@@ -7,15 +7,17 @@
 
 namespace srgan {
 
+// The geometric kernels are instantiated for 32-bit element indices (every tensor of the training step: 64-bit
+// division is emulated in ~100 instructions and made these kernels ALU-bound) and for 64-bit ones (> 2^31 elements).
+template <typename I>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           int32_t* __restrict__ idx, int H, int W, int k, int s, int p,
                                                           int OH, int OW, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
-    const int ow = (int)(o % OW);
-    const int oh = (int)((o / OW) % OH);
-    const int64_t plane = o / ((int64_t)OW * OH);
-    const float* src = x + plane * H * W;
+  const I stride = (I)gridDim.x * 256, count = (I)n, plane_out = (I)OW * OH;
+  for (I o = (I)blockIdx.x * 256 + threadIdx.x; o < count; o += stride) {
+    const I plane = o / plane_out, rest = o - plane * plane_out;
+    const int oh = (int)(rest / OW), ow = (int)(rest - (I)oh * OW);
+    const float* src = x + (int64_t)plane * H * W;
     const int h0 = oh * s - p, w0 = ow * s - p;
     float best = -INFINITY;
     int best_i = -1;
@@ -47,16 +49,16 @@ __global__ __launch_bounds__(256) void pool_scatter_kernel(const float* __restri
 
 // Max-pool backward in gather form: gx[h, w] = sum of g over the windows that contain (h, w) AND chose it.  Every input
 // element is written exactly once (no zero-fill, no atomics); the <= ceil(k/s)^2 window look-ups per element hit L2.
+template <typename I>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx,
                                                           float* __restrict__ gx, int H, int W, int k, int s, int p,
                                                           int OH, int OW, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int w = (int)(i % W);
-    const int h = (int)((i / W) % H);
-    const int64_t plane = i / ((int64_t)W * H);
-    const float* src = g + plane * OH * OW;
-    const int32_t* chosen = idx + plane * OH * OW;
+  const I stride = (I)gridDim.x * 256, count = (I)n, plane_in = (I)W * H;
+  for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const I plane = i / plane_in, rest = i - plane * plane_in;
+    const int h = (int)(rest / W), w = (int)(rest - (I)h * W);
+    const float* src = g + (int64_t)plane * OH * OW;
+    const int32_t* chosen = idx + (int64_t)plane * OH * OW;
     int oh_lo = h + p - k + 1; oh_lo = oh_lo > 0 ? (oh_lo + s - 1) / s : 0;
     int ow_lo = w + p - k + 1; ow_lo = ow_lo > 0 ? (ow_lo + s - 1) / s : 0;
     int oh_hi = (h + p) / s; if (oh_hi > OH - 1) oh_hi = OH - 1;
@@ -80,15 +82,15 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restric
   }
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
                                                           int W, int k, int s, int OH, int OW, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const I stride = (I)gridDim.x * 256, count = (I)n, plane_out = (I)OW * OH;
   const float inv = 1.f / (float)(k * k);
-  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
-    const int ow = (int)(o % OW);
-    const int oh = (int)((o / OW) % OH);
-    const int64_t plane = o / ((int64_t)OW * OH);
-    const float* src = x + plane * H * W + (int64_t)(oh * s) * W + ow * s;
+  for (I o = (I)blockIdx.x * 256 + threadIdx.x; o < count; o += stride) {
+    const I plane = o / plane_out, rest = o - plane * plane_out;
+    const int oh = (int)(rest / OW), ow = (int)(rest - (I)oh * OW);
+    const float* src = x + (int64_t)plane * H * W + (int64_t)(oh * s) * W + ow * s;
     float acc = 0.f;
     for (int r = 0; r < k; ++r)
       for (int c = 0; c < k; ++c) acc += src[r * W + c];
@@ -97,15 +99,15 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
 }
 
 // gx[h, w] = (1 / k^2) * sum of g over the output windows that contain (h, w)
+template <typename I>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int H,
                                                           int W, int k, int s, int OH, int OW, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const I stride = (I)gridDim.x * 256, count = (I)n, plane_in = (I)W * H;
   const float inv = 1.f / (float)(k * k);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int w = (int)(i % W);
-    const int h = (int)((i / W) % H);
-    const int64_t plane = i / ((int64_t)W * H);
-    const float* src = g + plane * OH * OW;
+  for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const I plane = i / plane_in, rest = i - plane * plane_in;
+    const int h = (int)(rest / W), w = (int)(rest - (I)h * W);
+    const float* src = g + (int64_t)plane * OH * OW;
     int oh_lo = h - k + 1; oh_lo = oh_lo > 0 ? (oh_lo + s - 1) / s : 0;
     int ow_lo = w - k + 1; ow_lo = ow_lo > 0 ? (ow_lo + s - 1) / s : 0;
     int oh_hi = h / s; if (oh_hi > OH - 1) oh_hi = OH - 1;
@@ -129,8 +131,12 @@ int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t plane
                 SRGAN_EINVAL, "srgan_maxpool2d_fwd arguments");
   SRGAN_REQUIRE((OH - 1) * s - p < H && (OW - 1) * s - p < W && p < k, SRGAN_EINVAL, "srgan_maxpool2d_fwd geometry");
   const int64_t n = (int64_t)planes * OH * OW;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, H,
-                     W, k, s, p, OH, OW, n);
+  if (n < ((int64_t)1 << 31) - ((int64_t)2048 * 256))      // (the grid-stride loop adds at most grid * 256 to a valid index)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<uint32_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       argmax, H, W, k, s, p, OH, OW, n);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<int64_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       argmax, H, W, k, s, p, OH, OW, n);
   return launch_status();
 }
 
@@ -139,8 +145,12 @@ int srgan_maxpool2d_bwd(const float* g, const int32_t* argmax, float* gx, int32_
   SRGAN_REQUIRE(g && argmax && gx && planes > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0 && OH > 0 && OW > 0,
                 SRGAN_EINVAL, "srgan_maxpool2d_bwd arguments");
   const int64_t n = (int64_t)planes * H * W;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, argmax, gx, H, W,
-                     k, s, p, OH, OW, n);
+  if (n < ((int64_t)1 << 31) - ((int64_t)2048 * 256))
+    hipLaunchKernelGGL(maxpool_bwd_kernel<uint32_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       argmax, gx, H, W, k, s, p, OH, OW, n);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<int64_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, argmax,
+                       gx, H, W, k, s, p, OH, OW, n);
   return launch_status();
 }
 
@@ -172,8 +182,12 @@ int srgan_avgpool2d_fwd(const float* x, float* y, int32_t planes, int32_t H, int
                 "srgan_avgpool2d_fwd arguments");
   SRGAN_REQUIRE((OH - 1) * s + k <= H && (OW - 1) * s + k <= W, SRGAN_EINVAL, "srgan_avgpool2d_fwd geometry");
   const int64_t n = (int64_t)planes * OH * OW;
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, k, s,
-                     OH, OW, n);
+  if (n < ((int64_t)1 << 31) - ((int64_t)2048 * 256))
+    hipLaunchKernelGGL(avgpool_fwd_kernel<uint32_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H,
+                       W, k, s, OH, OW, n);
+  else
+    hipLaunchKernelGGL(avgpool_fwd_kernel<int64_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W,
+                       k, s, OH, OW, n);
   return launch_status();
 }
 
@@ -183,8 +197,12 @@ int srgan_avgpool2d_bwd(const float* g, float* gx, int32_t planes, int32_t H, in
                 "srgan_avgpool2d_bwd arguments");
   SRGAN_REQUIRE((OH - 1) * s + k <= H && (OW - 1) * s + k <= W, SRGAN_EINVAL, "srgan_avgpool2d_bwd geometry");
   const int64_t n = (int64_t)planes * H * W;
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, H, W, k, s,
-                     OH, OW, n);
+  if (n < ((int64_t)1 << 31) - ((int64_t)2048 * 256))
+    hipLaunchKernelGGL(avgpool_bwd_kernel<uint32_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, H,
+                       W, k, s, OH, OW, n);
+  else
+    hipLaunchKernelGGL(avgpool_bwd_kernel<int64_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, gx, H, W,
+                       k, s, OH, OW, n);
   return launch_status();
 }
 

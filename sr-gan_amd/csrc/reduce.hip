@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void chan_reduce_cols_kernel(const float* __re
 //   w_scaled = w * a[ci]                        (the linearised forward runs on the masked UNSCALED tangent)
 //   w_grad  += q * a[ci]                        (q = weight gradient w.r.t. the scaled weights)
 //   gamma_grad[ci] += inv_std[ci] * sum_{co, tap} w * q
-// Lanes along the contiguous inner index, four row-lanes over CO combined through LDS.
+// Lanes along the contiguous inner index; a workgroup covers 64 inner indices x 16 rows of CO (four row-lanes x four
+// independent iterations: the chain of dependent loads, not bandwidth, bounds this tiny kernel), combined through LDS.
+constexpr int TW_ROWS = 16;
 __global__ __launch_bounds__(256) void tangent_weight_kernel(const float* __restrict__ w, const float* __restrict__ q,
                                                              const float* __restrict__ inv_std,
                                                              const float* __restrict__ gamma, float* __restrict__ w_scaled,
@@ -198,18 +200,29 @@ __global__ __launch_bounds__(256) void tangent_weight_kernel(const float* __rest
   const bool live = j < inner;
   const int ci = live ? j / taps : 0;
   const float a = __fmul_rn(inv_std[ci], gamma[ci]);
+  const int co0 = (int)blockIdx.y * TW_ROWS + cl;
+  float wv[TW_ROWS / 4], qv[TW_ROWS / 4], gv[TW_ROWS / 4];
+#pragma unroll
+  for (int e = 0; e < TW_ROWS / 4; ++e) {                     // all loads first
+    const int co = co0 + 4 * e;
+    const bool ok = live && co < CO;
+    const int64_t at = ok ? (int64_t)co * inner + j : 0;
+    wv[e] = ok ? w[at] : 0.f;
+    qv[e] = (ok && q) ? q[at] : 0.f;
+    gv[e] = (ok && q) ? w_grad[at] : 0.f;
+  }
   float dot = 0.f;
-  if (live)
-    for (int co = cl; co < CO; co += 4) {
-      const int64_t at = (int64_t)co * inner + j;
-      const float wv = w[at];
-      if (w_scaled) w_scaled[at] = wv * a;
-      if (q) {
-        const float qv = q[at];
-        w_grad[at] += qv * a;
-        dot = fmaf(wv, qv, dot);
-      }
+#pragma unroll
+  for (int e = 0; e < TW_ROWS / 4; ++e) {
+    const int co = co0 + 4 * e;
+    if (!live || co >= CO) continue;
+    const int64_t at = (int64_t)co * inner + j;
+    if (w_scaled) w_scaled[at] = wv[e] * a;
+    if (q) {
+      w_grad[at] = gv[e] + qv[e] * a;
+      dot = fmaf(wv[e], qv[e], dot);
     }
+  }
   if (q == nullptr) return;
   scratch[cl][jl] = dot;
   __syncthreads();
@@ -310,8 +323,9 @@ int srgan_bn_conv_tangent_weights(const float* w, const float* q, const float* i
   SRGAN_REQUIRE(q == nullptr || (w_grad && gamma_grad), SRGAN_EINVAL, "srgan_bn_conv_tangent_weights gradient outputs");
   const int64_t inner = (int64_t)CI * taps;
   SRGAN_REQUIRE(inner < ((int64_t)1 << 31), SRGAN_ERANGE, "srgan_bn_conv_tangent_weights size");
-  hipLaunchKernelGGL(tangent_weight_kernel, dim3((unsigned)((inner + 63) / 64)), dim3(256), 0, (hipStream_t)stream, w, q,
-                     inv_std, gamma, w_scaled, w_grad, gamma_grad, CO, (int)inner, taps);
+  hipLaunchKernelGGL(tangent_weight_kernel, dim3((unsigned)((inner + 63) / 64), (unsigned)((CO + TW_ROWS - 1) / TW_ROWS)),
+                     dim3(256), 0, (hipStream_t)stream, w, q, inv_std, gamma, w_scaled, w_grad, gamma_grad, CO, (int)inner,
+                     taps);
   return launch_status();
 }
 
