@@ -453,7 +453,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   const int64_t blocks = col_blocks * p.tiles_m;
   const int slices = (CI + 63) / 64;
   int split = 1;
-  if (blocks < (min_wgs * 3) / 4 && slices >= 2 && !epilogue) {   // (the fused epilogue needs whole sums per workgroup)
+  static const int split_below = getenv("SRGAN_PW_SPLIT_BELOW") ? atoi(getenv("SRGAN_PW_SPLIT_BELOW")) : (min_wgs * 3) / 4;
+  if (blocks < split_below && slices >= 2 && !epilogue) {   // (the fused epilogue needs whole sums per workgroup)
     split = (int)((min_wgs + blocks - 1) / blocks);
     if (split > slices) split = slices;
     if (split < 1) split = 1;

@@ -206,6 +206,11 @@ def dense_block(x, layers):
         want_params = any(needs2[1:])
         vbuf = _empty((n, total, h, w), device)
         F._call('srgan_copy_channels', v.data.data_ptr(), c0, 0, vbuf.data_ptr(), total, 0, c0, n, hw, 0, stream)
+        # the weight gradients w.r.t. the scaled weights (q1, q2 of every layer) land in ONE pre-zeroed buffer, so the
+        # weight-gradient kernels accumulate into it without a zero-fill launch of their own (2 per layer otherwise)
+        q_sizes = [(layer.conv1.weight.numel(), layer.conv2.weight.numel()) for layer in layers]
+        q_all = torch.zeros(sum(a + b for a, b in q_sizes), dtype=torch.float32, device=device) if want_params else None
+        q_at = 0
         for index, layer in enumerate(layers):
             g_b1, b1 = kept[index]
             cin = c0 + index * growth
@@ -219,13 +224,14 @@ def dense_block(x, layers):
             u1 = _empty((n, cin, h, w), device)
             F._call('srgan_bn_act_bwd', vbuf.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, u1.data_ptr(),
                     None, None, n, cin, hw, buffer_bs, buffer_bs, 0, 0, 1, stream)
-            q1 = None
+            q1 = q2 = None
             if want_params:
-                q1 = _empty(w1.shape, device)
-                F._call('srgan_conv2d_bwd_weight', desc1, u1.data_ptr(), g_b1.data_ptr(), q1.data_ptr(), 0, 0, stream)
+                q1, q2 = _ptr(q_all, q_at), _ptr(q_all, q_at + q_sizes[index][0])
+                q_at += sum(q_sizes[index])
+                F._call('srgan_conv2d_bwd_weight', desc1, u1.data_ptr(), g_b1.data_ptr(), q1, 1, 0, stream)
             # w1s = W1 * a;  dL/dW1 += q1 * a;  dL/dgamma1 += inv_std * sum_co W1 * q1   (a = inv_std * gamma per ci)
             w1s = _empty(w1.shape, device)
-            F._call('srgan_bn_conv_tangent_weights', w1.data_ptr(), q1.data_ptr() if want_params else None, inv1, gamma1,
+            F._call('srgan_bn_conv_tangent_weights', w1.data_ptr(), q1, inv1, gamma1,
                     w1s.data_ptr(), w1.grad.data_ptr() if want_params else None,
                     layer.norm1.weight.grad.data_ptr() if want_params else None, width, cin, 1, stream)
             b1_tangent = _empty(b1.shape, device)
@@ -235,12 +241,10 @@ def dense_block(x, layers):
             u2 = _empty(b1.shape, device)
             F._call('srgan_bn_act_bwd', b1_tangent.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1, u2.data_ptr(),
                     None, None, n, width, hw, 0, 0, 0, 0, 1, stream)
-            q2 = None
             if want_params:
-                q2 = _empty(w2.shape, device)
-                F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), q2.data_ptr(), 0, 0, stream)
+                F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), q2, 1, 0, stream)
             w2s = _empty(w2.shape, device)
-            F._call('srgan_bn_conv_tangent_weights', w2.data_ptr(), q2.data_ptr() if want_params else None, inv2, gamma2,
+            F._call('srgan_bn_conv_tangent_weights', w2.data_ptr(), q2, inv2, gamma2,
                     w2s.data_ptr(), w2.grad.data_ptr() if want_params else None,
                     layer.norm2.weight.grad.data_ptr() if want_params else None, growth, width, 9, stream)
             F._call('srgan_conv2d_fwd', desc2, u2.data_ptr(), w2s.data_ptr(), None, _ptr(vbuf, cin * hw), 0, stream)
