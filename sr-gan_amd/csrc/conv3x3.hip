@@ -349,7 +349,8 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
   plan.blocks = count(bm, th);
   const int chunks = (CI + plan.ci_t - 1) / plan.ci_t;
   int split = 1;
-  if (plan.blocks < 384 && chunks >= 4) {
+  static const int split_below = getenv("SRGAN_CONV3_SPLIT_BELOW") ? atoi(getenv("SRGAN_CONV3_SPLIT_BELOW")) : 384;
+  if (plan.blocks < split_below && chunks >= 4) {
     split = (int)((512 + plan.blocks - 1) / plan.blocks);
     if (split > chunks / 2) split = chunks / 2;
   }
