@@ -23,6 +23,8 @@ and no concatenation, slicing or mask tensors are materialised.  Only the input 
 recorded backward (exactly the penalty's use); parameter gradients of a recorded backward need the primitive path
 (``fused.ENABLED = False``).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -34,6 +36,17 @@ from .nn import parameter_var
 ENABLED = True      # tests flip this to compare the fused block with the primitive path
 PROLOGUE = True     # batch-norm + ReLU evaluated inside the convolution kernels (tests flip this too)
 EPILOGUE = True     # batch-norm + ReLU backward evaluated in the epilogue of the data-gradient kernels
+# Experiment (off by default): the weight-gradient kernels of a block's backward only feed the optimizer, so they can
+# run on a second stream next to the data-gradient chain.  Throughput rises, but kernels then overlap and the
+# per-kernel timings behind bench.py's roofline no longer describe one kernel at a time.
+WGRAD_STREAM = os.environ.get('SRGAN_WGRAD_STREAM', '0') == '1'
+_side_streams = {}
+
+
+def _side_stream(device):
+    if device not in _side_streams:
+        _side_streams[device] = torch.cuda.Stream(device=device)
+    return _side_streams[device]
 
 
 def _ptr(tensor, offset_elements=0):
@@ -127,6 +140,13 @@ def dense_block(x, layers):
         gbuf = _empty(g.shape, device)            # private copy: the incoming gradient may be shared
         F._call('srgan_ew_unary', F.U_COPY, g.data.data_ptr(), gbuf.data_ptr(), gbuf.numel(), 0.0, 0.0, stream)
         kept = [None] * len(layers)               # per layer, for the double backward: (gradient at conv1's output, b1)
+        overlap = WGRAD_STREAM and want_params and prologue and not recorded
+        if overlap:
+            main, side = torch.cuda.current_stream(device), _side_stream(device)
+            wstream = side.cuda_stream
+            alive = []                            # tensors the side stream still reads
+        else:
+            wstream = stream
         for index in range(len(layers) - 1, -1, -1):
             layer = layers[index]
             t1, b1, t2 = saved[index]
@@ -136,9 +156,11 @@ def dense_block(x, layers):
             mean2, inv2, gamma2, beta2 = norm_pointers(layer.norm2)
             g_new = _ptr(gbuf, cin * hw)                                  # [N, growth, H, W] view, batch stride buffer_bs
             desc2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
+            if overlap:
+                side.wait_stream(main)            # this layer's slice of the gradient buffer is final
             if want_params and prologue:
                 F._call('srgan_conv2d_bwd_weight_bnrelu', desc2, b1.data_ptr(), bn_struct(layer.norm2), g_new,
-                        layer.conv2.weight.grad.data_ptr(), 1, stream)
+                        layer.conv2.weight.grad.data_ptr(), 1, wstream)
             elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc2, t2.data_ptr(), g_new, layer.conv2.weight.grad.data_ptr(), 1, 0,
                         stream)
@@ -157,10 +179,13 @@ def dense_block(x, layers):
                         layer.norm2.bias.grad.data_ptr() if want_params else None, n, width, hw, 0, 0, 0, 0, 0, stream)
                 del g_t2
             desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
+            if overlap:
+                side.wait_stream(main)            # g_b1 is complete
+                alive.extend((g_b1, b1))
             if want_params and prologue:
                 F._call('srgan_conv2d_bwd_weight_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0),
                         buffer.data_ptr(), bn_struct(layer.norm1), g_b1.data_ptr(), layer.conv1.weight.grad.data_ptr(), 1,
-                        stream)
+                        wstream)
             elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc1, t1.data_ptr(), g_b1.data_ptr(),
                         layer.conv1.weight.grad.data_ptr(), 1, 0, stream)
@@ -186,6 +211,9 @@ def dense_block(x, layers):
                 kept[index] = (g_b1, b1)
             else:
                 saved[index] = None
+        if overlap:
+            main.wait_stream(side)                # the weight gradients are in the arena before anything consumes it
+            del alive
         gx = None
         if needs[0]:
             gx_data = _empty((n, c0, h, w), device)
