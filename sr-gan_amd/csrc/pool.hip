@@ -72,6 +72,43 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// The same for compile-time window geometry and four consecutive pixels per thread (W % 4 == 0, 16-byte aligned rows):
+// the windows of neighbouring pixels overlap, so the four pixels share their (arg-max, g) look-ups, the window bounds
+// are shifts instead of divisions, and the result leaves as one float4.
+template <int K, int S, int P>
+__global__ __launch_bounds__(256) void maxpool_bwd_quad_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx,
+                                                               float* __restrict__ gx, int H, int W, int OH, int OW,
+                                                               uint32_t quads) {
+  constexpr int SPAN = (3 + P) / S - (P - K + 1 > 0 ? (P - K + 1 + S - 1) / S : 0) + 2;   // upper bound of windows per quad row
+  const uint32_t stride = gridDim.x * 256u, w4 = (uint32_t)W >> 2;
+  for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < quads; q += stride) {
+    const uint32_t row = q / w4;                       // plane * H + h
+    const int w0 = (int)(q - row * w4) * 4;
+    const uint32_t plane = row / (uint32_t)H;
+    const int h = (int)(row - plane * (uint32_t)H);
+    const float* src = g + (int64_t)plane * OH * OW;
+    const int32_t* chosen = idx + (int64_t)plane * OH * OW;
+    int oh_lo = h + P - K + 1; oh_lo = oh_lo > 0 ? (oh_lo + S - 1) / S : 0;
+    int oh_hi = (h + P) / S; if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_lo = w0 + P - K + 1; ow_lo = ow_lo > 0 ? (ow_lo + S - 1) / S : 0;
+    int ow_hi = (w0 + 3 + P) / S; if (ow_hi > OW - 1) ow_hi = OW - 1;
+    const int32_t me = h * W + w0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+#pragma unroll
+      for (int j = 0; j < SPAN; ++j) {
+        const int ow = ow_lo + j;
+        if (ow > ow_hi) break;
+        const int32_t d = chosen[oh * OW + ow] - me;   // 0 .. 3 when the window chose one of this thread's pixels
+        if ((uint32_t)d < 4u) {
+          const float v = src[oh * OW + ow];
+          acc[0] += d == 0 ? v : 0.f; acc[1] += d == 1 ? v : 0.f; acc[2] += d == 2 ? v : 0.f; acc[3] += d == 3 ? v : 0.f;
+        }
+      }
+    *reinterpret_cast<float4*>(gx + (int64_t)row * W + w0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                           float* __restrict__ out, int64_t in_plane, int64_t out_plane,
                                                           int64_t n) {
@@ -145,6 +182,20 @@ int srgan_maxpool2d_bwd(const float* g, const int32_t* argmax, float* gx, int32_
   SRGAN_REQUIRE(g && argmax && gx && planes > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0 && OH > 0 && OW > 0,
                 SRGAN_EINVAL, "srgan_maxpool2d_bwd arguments");
   const int64_t n = (int64_t)planes * H * W;
+  if (W % 4 == 0 && ((uintptr_t)gx & 15) == 0 && n < ((int64_t)1 << 31)) {
+    const uint32_t quads = (uint32_t)(n / 4);
+    const dim3 grid(stream_grid(quads, 256));
+    if (k == 3 && s == 2 && p == 1) {
+      hipLaunchKernelGGL((maxpool_bwd_quad_kernel<3, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, g, argmax, gx, H, W, OH,
+                         OW, quads);
+      return launch_status();
+    }
+    if (k == 2 && s == 2 && p == 0) {
+      hipLaunchKernelGGL((maxpool_bwd_quad_kernel<2, 2, 0>), grid, dim3(256), 0, (hipStream_t)stream, g, argmax, gx, H, W, OH,
+                         OW, quads);
+      return launch_status();
+    }
+  }
   if (n < ((int64_t)1 << 31) - ((int64_t)2048 * 256))
     hipLaunchKernelGGL(maxpool_bwd_kernel<uint32_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g,
                        argmax, gx, H, W, k, s, p, OH, OW, n);

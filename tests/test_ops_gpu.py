@@ -282,7 +282,8 @@ def test_pooling_and_layout(F):
     out = F.max_pool2d(F.relu(xv), 3, 2, 1)
     backward(out, grad=F.leaf(dev(g)))
     close(xv.grad, xr.grad, 1e-6, 'maxpool backward with ties')
-    for (k, s, p, h, w) in [(2, 2, 0, 12, 10), (3, 1, 1, 9, 7), (3, 2, 1, 16, 16), (3, 3, 0, 10, 11), (2, 1, 0, 5, 6)]:
+    for (k, s, p, h, w) in [(2, 2, 0, 12, 10), (3, 1, 1, 9, 7), (3, 2, 1, 16, 16), (3, 3, 0, 10, 11), (2, 1, 0, 5, 6),
+                            (2, 2, 0, 12, 8), (3, 2, 1, 15, 20), (3, 2, 1, 8, 4)]:     # four-pixels-per-thread forms
         x3 = torch.randn(3, 4, h, w, generator=gen).requires_grad_()      # gather-form backward: every window overlap
         ref = TF.max_pool2d(x3, k, s, p)
         g = torch.randn(ref.shape, generator=gen)
