@@ -75,7 +75,7 @@ class MapModule(nn.Module):
     """Transposed conv to the label size, then conv k2 s2 x3, a whole-map "linear" conv and a count layer,
     leaky_relu 0.01 throughout (reference crowd/models.py:763-786)."""
 
-    def __init__(self, in_features, input_size, label_size):
+    def __init__(self, in_features, input_size, label_size, count_outputs=1):
         super().__init__()
         kernel_size = label_size // input_size
         self.map_transposed_conv_layer = nn.ConvTranspose2d(in_channels=in_features, out_channels=1,
@@ -84,7 +84,7 @@ class MapModule(nn.Module):
         self.conv2 = nn.Conv2d(in_channels=8, out_channels=16, kernel_size=2, stride=2)
         self.conv3 = nn.Conv2d(in_channels=16, out_channels=32, kernel_size=2, stride=2)
         self.linear1 = nn.Conv2d(in_channels=32, out_channels=20, kernel_size=label_size // (2 ** 3))
-        self.count_layer = nn.Conv2d(in_channels=20, out_channels=1, kernel_size=1)
+        self.count_layer = nn.Conv2d(in_channels=20, out_channels=count_outputs, kernel_size=1)
 
     def forward(self, x):
         map_ = F.leaky_relu(self.map_transposed_conv_layer(x))
@@ -101,6 +101,8 @@ class KnnDenseNetCat(nn.Module):
 
     Returns ``(density, count, maps)`` like the reference; ``density`` is the reference's all-zero
     (B, S, S) placeholder, produced once per shape and reused (Appendix A.11)."""
+
+    COUNT_OUTPUTS = 1      # 2 in the dual-goal variant: (count, real/fake score)
 
     def __init__(self, growth_rate=32, block_config=(6, 12, 48, 32), num_init_features=64, bn_size=4, drop_rate=0,
                  pretrained=False, label_patch_size=224, image_size=None):
@@ -137,11 +139,12 @@ class KnnDenseNetCat(nn.Module):
                 m.bias.data.zero_()
         if pretrained:      # the trunk only, before the heads exist -- as in the reference (crowd/models.py:1103-1129)
             self.load_torchvision_densenet201(pretrained)
-        self.map_module1 = MapModule(in_features=widths[0], input_size=image_size // 8, label_size=image_size)
-        self.map_module2 = MapModule(in_features=widths[1], input_size=image_size // 16, label_size=image_size)
-        self.map_module3 = MapModule(in_features=widths[2], input_size=image_size // 32, label_size=image_size)
+        outputs = self.COUNT_OUTPUTS
+        self.map_module1 = MapModule(widths[0], image_size // 8, image_size, count_outputs=outputs)
+        self.map_module2 = MapModule(widths[1], image_size // 16, image_size, count_outputs=outputs)
+        self.map_module3 = MapModule(widths[2], image_size // 32, image_size, count_outputs=outputs)
         self.final_count_feature_layer = nn.Conv2d(in_channels=num_features, out_channels=20, kernel_size=1)
-        self.count_layer = nn.Conv2d(in_channels=20, out_channels=1, kernel_size=1)
+        self.count_layer = nn.Conv2d(in_channels=20, out_channels=outputs, kernel_size=1)
         self.final_pool_size = image_size // 32
         self.features = None
         self._density_cache = None
@@ -194,6 +197,14 @@ class KnnDenseNetCat(nn.Module):
         return cache
 
     def forward(self, x):
+        count, map_, hidden = self._heads(x)
+        batch_size = x.shape[0]
+        self.features = F.cat_channels([F.view(t, (batch_size, -1, 1, 1)) for t in hidden])
+        return self._density(batch_size, x), F.view(count, (batch_size,)), map_
+
+    def _heads(self, x):
+        """Summed count-layer outputs (B, COUNT_OUTPUTS, 1, 1), the three maps (B, 3, S, S) and the four 20-d hidden
+        vectors."""
         batch_size = x.shape[0]
         stem = self.conv_layer1
         out = stem.pool0(stem.norm0(stem.conv0(x), relu=True))
@@ -208,9 +219,21 @@ class KnnDenseNetCat(nn.Module):
         map1, count1, h1 = self.map_module1(t1_out)
         map2, count2, h2 = self.map_module2(t2_out)
         map3, count3, h3 = self.map_module3(t3_out)
-        self.features = F.cat_channels([F.view(t, (batch_size, -1, 1, 1))
-                                        for t in (h1, h2, h3, final_count_features)])
         count = F.add(F.add(F.add(count1, count2), count3), final_count)
-        count = F.view(count, (batch_size,))
-        map_ = F.cat_channels([map1, map2, map3])
-        return self._density(batch_size, x), count, map_
+        return count, F.cat_channels([map1, map2, map3]), (h1, h2, h3, final_count_features)
+
+
+class KnnDenseNetCatDggan(KnnDenseNetCat):
+    """The dual-goal variant (reference crowd/models.py:903-1046): every count layer has two outputs, the second one is
+    the real/fake score, kept in ``real_label`` (B); ``features`` is not produced (the reference never sets it)."""
+    COUNT_OUTPUTS = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.real_label = None
+
+    def forward(self, x):
+        outputs, map_, _ = self._heads(x)
+        batch_size = x.shape[0]
+        self.real_label = F.view(F.slice_channels(outputs, 1, 2), (batch_size,))
+        return self._density(batch_size, x), F.view(F.slice_channels(outputs, 0, 1), (batch_size,)), map_

@@ -10,6 +10,7 @@ import os
 from .age.sgan import AgeSganExperiment
 from .age.srgan import AgeExperiment
 from .coefficient.dggan import CoefficientDgganExperiment
+from .crowd.dggan import CrowdDgganExperiment
 from .coefficient.sgan import CoefficientSganExperiment
 from .coefficient.srgan import CoefficientExperiment
 from .crowd.dnn import CrowdDnnExperiment
@@ -49,7 +50,8 @@ def build_settings(application_name, method_name):
         settings_.labeled_dataset_size = [500]
         settings_.gradient_penalty_multiplier = 1e1
     elif application_name == ApplicationName.crowd:
-        experiment_class = {MethodName.srgan: CrowdExperiment, MethodName.dnn: CrowdDnnExperiment}[method_name]
+        experiment_class = {MethodName.srgan: CrowdExperiment, MethodName.dnn: CrowdDnnExperiment,
+                            MethodName.dggan: CrowdDgganExperiment}[method_name]
         settings_.matching_loss_multiplier = [1e3]
         settings_.contrasting_loss_multiplier = [1e2]
         settings_.batch_size = 15

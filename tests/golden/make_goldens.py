@@ -629,9 +629,81 @@ def g9_crowd_sliding_window():
     save('g9_crowd_sliding_window', **out)
 
 
+def g10_crowd_dggan():
+    """the dual-goal GAN on the crowd task (crowd/dggan.py:9-49 on KnnDenseNetCatDggan,
+    crowd/models.py:903-1046) at 64x64 -- the network is size-generalised exactly like the SRGAN crowd oracle above, the
+    loss methods are the reference's own, bound onto the three-hook experiment.  Discriminator scaled so that the
+    gradient penalty (on the per-example real/fake scores) is active."""
+    import crowd.models as cm
+    from crowd.dggan import CrowdDgganExperiment
+    from crowd.srgan import CrowdExperiment
+    from torch.nn.functional import avg_pool2d
+    size, batch, steps, d_scale = 64, 2, 2, 1.26
+
+    class SizedKnnDenseNetCatDggan(cm.KnnDenseNetCatDggan):
+        def __init__(self):
+            original = cm.MapModuleDggan
+            remap = {28: size // 8, 14: size // 16, 7: size // 32}
+            cm.MapModuleDggan = lambda in_features, input_size, label_size: original(
+                in_features=in_features, input_size=remap[input_size], label_size=label_size)
+            try:
+                super().__init__(pretrained=False, label_patch_size=size)
+            finally:
+                cm.MapModuleDggan = original
+
+        def forward(self, x):
+            original = cm.avg_pool2d
+            cm.avg_pool2d = lambda t, kernel_size, stride: avg_pool2d(t, kernel_size=size // 32, stride=stride)
+            try:
+                return super().forward(x)
+            finally:
+                cm.avg_pool2d = original
+
+    def builders():
+        return cm.DCGenerator(image_size=size), SizedKnnDenseNetCatDggan(), SizedKnnDenseNetCatDggan()
+
+    settings = Settings()
+    settings.batch_size = batch
+    for key, value in CROWD_MULTIPLIERS.items():
+        setattr(settings, key, value)
+    experiment = _ImageExperiment(settings)
+    experiment.builders = builders
+    experiment.labeled_loss_function = CrowdExperiment.labeled_loss_function.__get__(experiment)
+    for method in ('unlabeled_loss_calculation', 'fake_loss_calculation', 'interpolate_loss_calculation',
+                   'generator_loss_calculation'):
+        setattr(experiment, method, getattr(CrowdDgganExperiment, method).__get__(experiment))
+    ref_utility.seed_all(0)
+    experiment.model_setup()
+    experiment.prepare_optimizers()
+    experiment.train_mode()
+    attach_writers(experiment)
+    out = {'batch_size': np.array(batch), 'image_size': np.array(size), 'input_seed': np.array(170 + size),
+           'd_scale': np.array(d_scale), 'dggan_loss_multiplier': np.array(settings.dggan_loss_multiplier)}
+    with torch.no_grad():
+        for module in experiment.D.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                module.weight.mul_(d_scale)
+    out.update(checksum_arrays('init_ck/D', experiment.D))
+    out.update(checksum_arrays('init_ck/DNN', experiment.DNN))
+    out.update(checksum_arrays('init_ck/G', experiment.G))
+    generator = torch.Generator().manual_seed(170 + size)
+    batches = [_crowd_inputs(generator, batch, size) for _ in range(steps)]
+    experiment.D.apply(ref_srgan.disable_batch_norm_updates)
+    with torch.no_grad():
+        _, count, maps = experiment.D(batches[0][0])
+    out['fwd/count'] = np32(count)
+    out['fwd/real_label'] = np32(experiment.D.real_label)
+    out['fwd/maps_ck'] = np.array([maps.double().sum().item(), maps.double().abs().sum().item()])
+    run_recorded_steps(experiment, batches, out, with_grads_on_step0=False, features=False)
+    out.update(checksum_arrays('final_ck/D', experiment.D))
+    out.update(checksum_arrays('final_ck/DNN', experiment.DNN))
+    out.update(checksum_arrays('final_ck/G', experiment.G))
+    save('g10_crowd_dggan64_gp_active', **out)
+
+
 ALL = {'g0': g0_toydata, 'g1': g1_distance, 'g2': g2_sgan_math, 'g3': g3_coefficient_srgan,
        'g4': g4_coefficient_sgan, 'g4b': g4b_coefficient_dggan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
-       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window}
+       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan}
 
 if __name__ == '__main__':
     wanted = sys.argv[1:] or ['all']

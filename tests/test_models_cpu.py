@@ -1,0 +1,28 @@
+"""CPU: the product's network definitions reproduce the reference's parameter initialisation (same construction order,
+same random stream) -- checked against the checksums stored in the reference-generated fixtures."""
+import torch
+
+from helpers import load_golden, checksum, assert_close
+
+
+def test_crowd_dggan_networks_initialise_like_the_reference():
+    """KnnDenseNetCatDggan / DCGenerator at 64x64 (reference crowd/models.py:903-1046,127-147):
+    seed_all(0), then G, D, DNN in the order of the reference's model_setup."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCatDggan
+    from srgan_amd.utility import seed_all
+    g = load_golden('g10_crowd_dggan64_gp_active')
+    size = int(g['image_size'])
+    seed_all(0)
+    generator = DCGenerator(image_size=size)
+    discriminator, dnn = KnnDenseNetCatDggan(image_size=size), KnnDenseNetCatDggan(image_size=size)
+    with torch.no_grad():
+        for m in discriminator.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                m.weight.mul_(float(g['d_scale']))
+    for module, prefix in ((discriminator, 'init_ck/D'), (dnn, 'init_ck/DNN'), (generator, 'init_ck/G')):
+        names = [name for name, _ in module.named_parameters()]
+        assert sorted(names) == sorted(k[len(prefix) + 1:] for k in g.files if k.startswith(prefix + '/'))
+        for name, parameter in module.named_parameters():
+            assert_close(checksum(parameter), g[f'{prefix}/{name}'], rtol=1e-9, atol=1e-12, what=f'{prefix} {name}')
+    assert discriminator.count_layer.weight.shape[0] == 2 and discriminator.map_module1.count_layer.weight.shape[0] == 2

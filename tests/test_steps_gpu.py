@@ -18,7 +18,7 @@ def pkg():
     return srgan_amd
 
 
-def make_experiment(builders, settings_overrides, sgan_bins=None, crowd=False):
+def make_experiment(builders, settings_overrides, sgan_bins=None, crowd=False, base_class=None):
     from srgan_amd.settings import Settings
     from srgan_amd.srgan import Experiment
     from srgan_amd.sgan import SganExperiment
@@ -27,6 +27,8 @@ def make_experiment(builders, settings_overrides, sgan_bins=None, crowd=False):
     if crowd:
         from srgan_amd.crowd.srgan import CrowdExperiment
         base = CrowdExperiment
+    if base_class is not None:
+        base = base_class
 
     class _Experiment(base):
         def dataset_setup(self):
@@ -274,6 +276,60 @@ def test_crowd_steps(pkg, name, size, steps, reference_schedule, overlap=False):
                 # Adam's first step moves every element by ~lr * sign(g): elements whose gradient is ~0 are
                 # ill-conditioned, so allow a couple of lr-sized element differences on top of 1e-3 relative.
                 assert_close(checksum(p)[1], expected[1], rtol=RTOL, atol=4e-4, what=f'{prefix} {pname} abs-sum')
+
+
+def test_crowd_dggan(pkg):
+    """the dual-goal GAN on the crowd task (reference crowd/dggan.py on KnnDenseNetCatDggan) against
+    the fixture generated from the unmodified reference losses; discriminator scaled so that the gradient penalty on the
+    real/fake scores is active."""
+    from srgan_amd.crowd.dggan import CrowdDgganExperiment
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCatDggan
+    from srgan_amd.srgan import as_var
+    from srgan_amd.tape import no_grad
+    g = load_golden('g10_crowd_dggan64_gp_active')
+    batch, size = int(g['batch_size']), int(g['image_size'])
+    experiment = make_experiment(
+        lambda: (DCGenerator(image_size=size), KnnDenseNetCatDggan(image_size=size), KnnDenseNetCatDggan(image_size=size)),
+        dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
+             gradient_penalty_multiplier=1e2, map_multiplier=1e-3), base_class=CrowdDgganExperiment)
+    assert experiment.settings.dggan_loss_multiplier == float(g['dggan_loss_multiplier'])
+    with torch.no_grad():
+        for m in experiment.D.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                m.weight.mul_(float(g['d_scale']))
+    for module, prefix in ((experiment.D, 'init_ck/D'), (experiment.DNN, 'init_ck/DNN'), (experiment.G, 'init_ck/G')):
+        for pname, p in module.named_parameters():
+            assert_close(checksum(p), g[f'{prefix}/{pname}'], rtol=1e-9, atol=1e-12, what=f'{prefix} {pname}')
+    finish_setup(experiment)
+    generator = torch.Generator().manual_seed(int(g['input_seed']))
+    batches = [crowd_inputs(generator, batch, size) for _ in range(2)]
+    with no_grad():
+        _, count, maps = experiment.D(as_var(batches[0][0]))
+    assert_close(count.cpu().numpy(), g['fwd/count'], rtol=RTOL, what='count')
+    assert_close(experiment.D.real_label.cpu().numpy(), g['fwd/real_label'], rtol=RTOL, what='real/fake score')
+    assert_close(checksum(maps.data)[:2], g['fwd/maps_ck'], rtol=RTOL, what='density-map checksums')
+    for step, (x, y, u) in enumerate(batches):
+        result = run_step(experiment, x.cuda(), tuple(t.cuda() for t in y), u.cuda(), step, g)
+        expected = golden_scalars(g, step)
+        if step == 0:
+            check(result, expected, 'crowd dggan step 0')
+            assert_close(experiment.gradient_norm.cpu().numpy(), g['s0/gradient_norm'], rtol=RTOL, what='gn')
+        else:
+            # The second step starts from weights that went through one Adam update: every element moved by
+            # ~lr * sign(gradient), which is ill-conditioned where the gradient is ~0, and this fixture's discriminator
+            # is scaled by 1.26 per layer to make the penalty active, so that difference is amplified: the real/fake
+            # scores still agree to 4e-4, the penalty (100 * (norm - 1)^2 at norm 1.5: 6x the norm's error) and the
+            # cross-entropy of a score near -9 (= exp(score): relative error = absolute error of the score) less so.
+            for key, value in expected.items():
+                if key == 'unlabeled_loss':
+                    assert abs(np.log(result[key]) - np.log(value)) < 1e-3 * abs(np.log(value / 1e4)), key
+                elif key in result:
+                    assert_close(result[key], value, rtol=1e-2, atol=0.0, what=f'crowd dggan step 1 {key}')
+            assert_close(experiment.gradient_norm.cpu().numpy(), g['s1/gradient_norm'], rtol=2e-3, what='gn')
+        assert result['gradient_penalty'] > 10.0
+    for prefix, module in (('final_ck/D', experiment.D), ('final_ck/G', experiment.G)):
+        for pname, p in module.named_parameters():
+            assert_close(checksum(p)[1], g[f'{prefix}/{pname}'][1], rtol=RTOL, atol=8e-4, what=f'{prefix} {pname} abs-sum')
 
 
 def test_age_dcgan128(pkg):
