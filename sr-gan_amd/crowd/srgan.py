@@ -8,7 +8,7 @@ import torch
 from .. import functional as F
 from ..srgan import Experiment, as_var
 from ..tape import no_grad
-from .data import ImageSlidingWindowDataset
+from .data import CrowdExample, ImageSlidingWindowDataset
 from .models import DCGenerator, KnnDenseNetCat
 from ..synthetic import SyntheticLoader
 
@@ -34,7 +34,96 @@ class CrowdExperiment(Experiment):
         self.DNN = KnnDenseNetCat(image_size=size)
 
     def validation_summaries(self, step):
-        pass
+        """The scalar summaries of reference crowd/srgan.py:98-147 when evaluation datasets are attached
+        (``train_dataset`` / ``validation_dataset``: indexable, items ``(image, label, map)``; ``dataset_class`` for the
+        full-image test summaries); the image grids of the reference are out of scope."""
+        train_dataset = getattr(self, 'train_dataset', None)
+        validation_dataset = getattr(self, 'validation_dataset', None)
+        if train_dataset is not None and validation_dataset is not None:
+            settings = self.settings
+            self.evaluation_epoch(settings, self.DNN, train_dataset, self.dnn_summary_writer, '2 Train Error', shuffle=False)
+            dnn_validation_count_mae = self.evaluation_epoch(settings, self.DNN, validation_dataset,
+                                                             self.dnn_summary_writer, '1 Validation Error', shuffle=False)
+            self.evaluation_epoch(settings, self.D, train_dataset, self.gan_summary_writer, '2 Train Error', shuffle=False)
+            self.evaluation_epoch(settings, self.D, validation_dataset, self.gan_summary_writer, '1 Validation Error',
+                                  comparison_value=dnn_validation_count_mae, shuffle=False)
+        if getattr(self, 'dataset_class', None) is not None:
+            self.test_summaries()
+
+    def images_to_predicted_labels(self, network, images):
+        """reference crowd/srgan.py:256-259"""
+        predicted_densities, predicted_counts, predicted_maps = network(images)
+        return predicted_densities, predicted_counts, predicted_maps
+
+    def evaluation_epoch(self, settings, network, dataset, summary_writer, summary_name, comparison_value=None,
+                         shuffle=True):
+        """Count ME / MAE / MSE and kNN-map MAE / MSE of ``network`` over batches of ``dataset`` (reference
+        crowd/srgan.py:149-191), stopping once more than 100 examples have been seen.  As in the reference, the map
+        errors cover the FIRST batch only (its concatenation of the maps sits inside the "still empty" branch)."""
+        self.join_dnn_stream()
+        order = np.random.permutation(len(dataset)) if shuffle else np.arange(len(dataset))
+        predicted_counts, label_counts = [], []
+        maps = predicted_maps = None
+        for index, start in enumerate(range(0, len(order), settings.batch_size)):
+            items = [dataset[int(i)] for i in order[start:start + settings.batch_size]]
+            images = torch.stack([torch.as_tensor(item[0]) for item in items])
+            labels = torch.stack([torch.as_tensor(item[1]) for item in items])
+            with no_grad():
+                _, batch_predicted_counts, batch_predicted_maps = self.images_to_predicted_labels(network, as_var(images))
+            predicted_counts.append(batch_predicted_counts.cpu().numpy().reshape(-1).astype(np.float64))
+            label_counts.append(labels.cpu().numpy().astype(np.float64).sum(axis=(1, 2)))
+            if maps is None:
+                maps = np.stack([np.asarray(torch.as_tensor(item[2]).cpu(), dtype=np.float64) for item in items])
+                predicted_maps = batch_predicted_maps.cpu().numpy().astype(np.float64)
+            if index * settings.batch_size >= 100:
+                break
+        predicted_counts, label_counts = np.concatenate(predicted_counts), np.concatenate(label_counts)
+        maps = np.expand_dims(maps, axis=1)
+        count_mae = np.abs(predicted_counts - label_counts).mean()
+        summary_writer.add_scalar('{}/ME'.format(summary_name), (predicted_counts - label_counts).mean())
+        summary_writer.add_scalar('{}/MAE'.format(summary_name), count_mae)
+        summary_writer.add_scalar('{}/kNN MAE'.format(summary_name), np.abs(predicted_maps - maps).mean())
+        summary_writer.add_scalar('{}/MSE'.format(summary_name), (np.abs(predicted_counts - label_counts) ** 2).mean())
+        summary_writer.add_scalar('{}/kNN MSE'.format(summary_name), (np.abs(predicted_maps - maps) ** 2).mean())
+        if comparison_value is not None:
+            summary_writer.add_scalar('{}/Ratio MAE GAN DNN'.format(summary_name), count_mae / comparison_value)
+        return count_mae
+
+    def test_summaries(self):
+        """Full-image test errors of both networks through ``predict_full_example`` (reference crowd/srgan.py:261-300):
+        NAE / MAE / RMSE of the count, MAE / RMSE of the density sum, and the GAN-to-DNN ratios."""
+        import random
+        test_dataset = self.dataset_class(dataset='test', map_directory_name=self.settings.map_directory_name)
+        if self.settings.test_summary_size is not None:
+            indexes = random.sample(range(test_dataset.length), self.settings.test_summary_size)
+        else:
+            indexes = range(test_dataset.length)
+        dnn_mae_count = dnn_rmse_count = None
+        for network in (self.DNN, self.D):
+            totals = dict.fromkeys(('Count error', 'NAE', 'Density sum error', 'SE count', 'SE density'), 0.0)
+            for index in indexes:
+                full_image, full_label, _ = test_dataset[index]
+                full_example = CrowdExample(image=full_image, label=full_label)
+                predicted_count, predicted_label = self.predict_full_example(full_example, network)
+                true_count = full_example.label.sum()
+                totals['Count error'] += np.abs(predicted_count - true_count)
+                totals['NAE'] += np.abs(predicted_count - true_count) / true_count
+                totals['Density sum error'] += np.abs(predicted_label.sum() - true_count)
+                totals['SE count'] += (predicted_count - true_count) ** 2
+                totals['SE density'] += (predicted_label.sum() - true_count) ** 2
+            summary_writer = self.dnn_summary_writer if network is self.DNN else self.gan_summary_writer
+            mae_count = totals['Count error'] / len(indexes)
+            rmse_count = (totals['SE count'] / len(indexes)) ** 0.5
+            summary_writer.add_scalar('0 Test Error/NAE count', totals['NAE'] / len(indexes))
+            summary_writer.add_scalar('0 Test Error/MAE count', mae_count)
+            summary_writer.add_scalar('0 Test Error/MAE density', totals['Density sum error'] / len(indexes))
+            summary_writer.add_scalar('0 Test Error/RMSE count', rmse_count)
+            summary_writer.add_scalar('0 Test Error/RMSE density', (totals['SE density'] / len(indexes)) ** 0.5)
+            if network is self.DNN:
+                dnn_mae_count, dnn_rmse_count = mae_count, rmse_count
+            else:
+                summary_writer.add_scalar('0 Test Error/Ratio MAE GAN DNN', mae_count / dnn_mae_count)
+                summary_writer.add_scalar('0 Test Error/Ratio RMSE GAN DNN', rmse_count / dnn_rmse_count)
 
     def labeled_loss_function(self, predicted_labels, labels, order=2):
         """count loss + map_multiplier * map loss (reference crowd/srgan.py:247-254)."""

@@ -701,9 +701,73 @@ def g10_crowd_dggan():
     save('g10_crowd_dggan64_gp_active', **out)
 
 
+def g11_crowd_evaluation():
+    """the crowd evaluation summaries -- ``CrowdExperiment.evaluation_epoch`` over patch batches
+    (crowd/srgan.py:149-191: count ME / MAE / MSE over all batches, the kNN-map errors over the FIRST batch only, as the
+    reference's indentation has it) and ``test_summaries`` over full images through ``predict_full_example``
+    (crowd/srgan.py:261-300), both run from the unmodified reference on a 64x64 discriminator pair."""
+    import scipy.misc
+    from torch.utils.data import TensorDataset
+    from crowd.srgan import CrowdExperiment
+
+    def imresize_identity(array, size, mode=None):
+        assert tuple(array.shape) == tuple(size) and mode == 'F'
+        return np.asarray(array, dtype=np.float32)
+    scipy.misc.imresize = imresize_identity
+    size, batch = 64, 4
+    experiment = _image_experiment(_crowd_builders(size), batch, CROWD_MULTIPLIERS, crowd=True)
+    experiment.settings.image_patch_size = size
+    experiment.settings.test_sliding_window_size = 32
+    experiment.settings.number_of_data_workers = 0
+    experiment.settings.pin_memory = False
+    experiment.settings.test_summary_size = None
+    experiment.settings.map_directory_name = 'unused'
+    for module in (experiment.D, experiment.DNN, experiment.G):
+        module.eval()
+    for method in ('evaluation_epoch', 'images_to_predicted_labels', 'test_summaries', 'predict_full_example'):
+        setattr(experiment, method, getattr(CrowdExperiment, method).__get__(experiment))
+    out = {'image_size': np.array(size), 'batch_size': np.array(batch), 'window_step': np.array(32)}
+    out.update(checksum_arrays('init_ck/D', experiment.D))
+    out.update(checksum_arrays('init_ck/DNN', experiment.DNN))
+    generator = torch.Generator().manual_seed(211)
+    images = torch.rand(10, 3, size, size, generator=generator) * 2 - 1
+    labels = (torch.rand(10, size, size, generator=generator) < 0.004).float()
+    maps = torch.rand(10, size, size, generator=generator)
+    out['patches/images'], out['patches/labels'], out['patches/maps'] = np32(images), np32(labels), np32(maps)
+    dataset = TensorDataset(images, labels, maps)
+    with torch.no_grad():
+        dnn_mae = experiment.evaluation_epoch(experiment.settings, experiment.DNN, dataset, experiment.dnn_summary_writer,
+                                              '1 Validation Error', shuffle=False)
+        experiment.evaluation_epoch(experiment.settings, experiment.D, dataset, experiment.gan_summary_writer,
+                                    '1 Validation Error', comparison_value=dnn_mae, shuffle=False)
+    random_state = np.random.RandomState(7)
+    scenes = []
+    for index, shape in enumerate([(80, 120), (64, 64), (50, 100)]):
+        image = random_state.randint(0, 256, size=shape + (3,)).astype(np.uint8)
+        label = (random_state.rand(*shape) < 0.004).astype(np.float32)
+        scenes.append((image, label, np.zeros(shape, dtype=np.float32)))
+        out[f'scene{index}/image'], out[f'scene{index}/label'] = image, label
+
+    class TestDataset:
+        length = len(scenes)
+
+        def __init__(self, dataset, map_directory_name):
+            assert dataset == 'test'
+
+        def __getitem__(self, index):
+            return scenes[index]
+    experiment.dataset_class = TestDataset
+    with torch.no_grad():
+        experiment.test_summaries()
+    for prefix, writer in (('dnn', experiment.dnn_summary_writer), ('gan', experiment.gan_summary_writer)):
+        for tag, value in last_scalars(writer).items():
+            out[f'{prefix}/{tag}'] = np.array(value, dtype=np.float64)
+    save('g11_crowd_evaluation', **out)
+
+
 ALL = {'g0': g0_toydata, 'g1': g1_distance, 'g2': g2_sgan_math, 'g3': g3_coefficient_srgan,
        'g4': g4_coefficient_sgan, 'g4b': g4b_coefficient_dggan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
-       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan}
+       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan, 'g11': g11_crowd_evaluation}
 
 if __name__ == '__main__':
     wanted = sys.argv[1:] or ['all']

@@ -564,6 +564,52 @@ def test_crowd_sliding_window_inference(pkg):
     assert tuple(patch.shape) == (3, size, size) and float(patch.min()) >= -1.0 and float(patch.max()) <= 1.0
 
 
+def test_crowd_evaluation_summaries(pkg):
+    """the crowd evaluation summaries against the reference's own functions (golden g11):
+    ``evaluation_epoch`` over patch batches (count ME / MAE / MSE over all batches, kNN-map errors over the first batch
+    only, as the reference computes them) for DNN and D, and ``test_summaries`` over three full images through the
+    sliding-window prediction; every logged scalar is compared."""
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
+    g = load_golden('g11_crowd_evaluation')
+    size = int(g['image_size'])
+    experiment = make_experiment(
+        lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
+        dict(batch_size=int(g['batch_size']), image_patch_size=size, test_sliding_window_size=int(g['window_step']),
+             test_summary_size=None, map_directory_name='unused'), crowd=True)
+    for module, prefix in ((experiment.D, 'init_ck/D'), (experiment.DNN, 'init_ck/DNN')):
+        for pname, p in module.named_parameters():
+            assert_close(checksum(p), g[f'{prefix}/{pname}'], rtol=1e-9, atol=1e-12, what=f'{prefix} {pname}')
+    finish_setup(experiment)
+    experiment.eval_mode()
+    patches = list(zip(torch.from_numpy(g['patches/images']), torch.from_numpy(g['patches/labels']),
+                       torch.from_numpy(g['patches/maps'])))
+    dnn_mae = experiment.evaluation_epoch(experiment.settings, experiment.DNN, patches, experiment.dnn_summary_writer,
+                                          '1 Validation Error', shuffle=False)
+    experiment.evaluation_epoch(experiment.settings, experiment.D, patches, experiment.gan_summary_writer,
+                                '1 Validation Error', comparison_value=dnn_mae, shuffle=False)
+    scenes = [(g[f'scene{i}/image'], g[f'scene{i}/label'], None) for i in range(3)]
+
+    class TestDataset:
+        length = len(scenes)
+
+        def __init__(self, dataset, map_directory_name):
+            assert dataset == 'test'
+
+        def __getitem__(self, index):
+            return scenes[index]
+    experiment.dataset_class = TestDataset
+    experiment.test_summaries()
+    compared = 0
+    for prefix, writer in (('dnn', experiment.dnn_summary_writer), ('gan', experiment.gan_summary_writer)):
+        logged = {tag: values[-1][1] for tag, values in writer.scalars.items()}
+        for key in g.files:
+            if key.startswith(prefix + '/'):
+                tag = key[len(prefix) + 1:]
+                assert_close(float(logged[tag]), float(g[key]), rtol=RTOL, atol=1e-6, what=f'{prefix} {tag}')
+                compared += 1
+    assert compared == 23
+
+
 def test_dnn_only_experiment(pkg, tmp_path):
     """SURVEY.md 8(f) N3, the DNN method (reference dnn.py:15-100, crowd/dnn.py:20): the DNN-only loop end to end on the
     coefficient task (checkpoint with the reference's three keys), and the crowd mix-in's step equal to the DNN step of
