@@ -64,6 +64,39 @@ class ImageSlidingWindowDataset:
         return torch.from_numpy(np.ascontiguousarray(patch.transpose((2, 0, 1)))), x, y
 
 
+class PreprocessedCrowdDataset:
+    """Full-image examples of a crowd database in the on-disk layout the reference's preprocessors write and its
+    ``ShanghaiTechFullImageDataset`` / ``UcfQnrfFullImageDataset`` read (crowd/shanghai_tech_data.py:18-44,
+    crowd/ucf_qnrf_data.py): ``<database_directory>/[<part>/]<dataset>_data/{images,labels,<map_directory_name>}/*.npy``
+    (image u8[H, W, 3], head-count label f32[H, W], ikNN map f32[H, W]).  ``__getitem__`` returns ``(image, label,
+    map)`` like the reference; ``examples()`` gives the ``CrowdExample``s that ``DeviceCrowdPatchLoader`` keeps resident
+    (training) and ``CrowdExperiment.test_summaries`` walks (evaluation).  The database directory is passed in (the
+    reference takes it from its preprocessor object)."""
+
+    def __init__(self, database_directory, dataset='train', part=None, number_of_examples=None,
+                 map_directory_name='knn_maps'):
+        import os
+        pieces = [database_directory] + ([part] if part else []) + ['{}_data'.format(dataset)]
+        self.dataset_directory = os.path.join(*pieces)
+        names = [name for name in os.listdir(os.path.join(self.dataset_directory, 'labels')) if name.endswith('.npy')]
+        self.file_names = sorted(names)[:number_of_examples]       # (the reference keeps the directory's own order)
+        self.length = len(self.file_names)
+        self.map_directory_name = map_directory_name
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        import os
+        file_name = self.file_names[index]
+        return tuple(np.load(os.path.join(self.dataset_directory, directory, file_name))
+                     for directory in ('images', 'labels', self.map_directory_name))
+
+    def examples(self):
+        return [CrowdExample(image=image, label=label, map_=map_) for image, label, map_ in
+                (self[index] for index in range(self.length))]
+
+
 class DeviceCrowdPatchLoader:
     """Endless training batches cut ON THE DEVICE from full crowd scenes that stay resident in HBM:
     the reference's ``ShanghaiTechTransformedDataset`` + ``DataLoader(num_workers=4)`` pipeline (random position

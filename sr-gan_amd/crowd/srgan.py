@@ -16,11 +16,33 @@ from ..synthetic import SyntheticLoader
 class CrowdExperiment(Experiment):
     """The crowd application."""
 
+    DATABASE_ENV = 'SRGAN_CROWD_DATABASE'       # e.g. .../ShanghaiTech ; SRGAN_CROWD_DATABASE_PART e.g. part_A
+
     def dataset_setup(self):
-        """Synthetic (image, head-count label, ikNN map) batches of the reference's batch contract
-        (crowd/shanghai_tech_data.py:99-104): image f32[3,S,S] in [-1,1], label f32[S,S], map f32[S,S]."""
+        """Without a database on disk: synthetic (image, head-count label, ikNN map) batches of the reference's batch
+        contract (crowd/shanghai_tech_data.py:99-104): image f32[3,S,S] in [-1,1], label f32[S,S], map f32[S,S].
+        With ``SRGAN_CROWD_DATABASE`` pointing at a database preprocessed by the reference: the
+        ShanghaiTech branch of reference crowd/srgan.py:54-69 -- labeled / unlabeled scenes resident in HBM and cut into
+        random patches on the device, the test split behind ``dataset_class`` for the full-image summaries."""
+        import os
         settings = self.settings
         size = settings.image_patch_size
+        directory = os.environ.get(self.DATABASE_ENV)
+        if directory:
+            from .data import DeviceCrowdPatchLoader, PreprocessedCrowdDataset
+            part = os.environ.get(self.DATABASE_ENV + '_PART') or None
+            maps = settings.map_directory_name
+
+            def scenes(count):
+                return PreprocessedCrowdDataset(directory, 'train', part, number_of_examples=count,
+                                                map_directory_name=maps).examples()
+            self.train_dataset_loader = DeviceCrowdPatchLoader(scenes(settings.labeled_dataset_size), settings.batch_size,
+                                                               size, seed=settings.labeled_dataset_seed)
+            self.unlabeled_dataset_loader = DeviceCrowdPatchLoader(scenes(settings.unlabeled_dataset_size),
+                                                                   settings.batch_size, size, seed=100)
+            self.dataset_class = lambda dataset, map_directory_name: PreprocessedCrowdDataset(
+                directory, dataset, part, map_directory_name=map_directory_name)
+            return
         self.train_dataset_loader = SyntheticLoader.crowd(settings.batch_size, size, seed=settings.labeled_dataset_seed,
                                                           dp=self.dp)
         self.unlabeled_dataset_loader = SyntheticLoader.crowd(settings.batch_size, size, seed=100, dp=self.dp)

@@ -21,3 +21,32 @@ def test_sliding_window_positions_and_padding():
     assert padded.shape == (64, 64, 3)
     assert (padded[:24] == 0).all() and (padded[24:] == 200).all()        # 32 - 8 rows of padding on top
     assert float(negative_one_to_one(np.array([[[0, 255, 127]]], dtype=np.uint8)).min()) == -1.0
+
+
+def test_preprocessed_database_reader(tmp_path):
+    """The on-disk layout of the reference's preprocessed crowd databases (crowd/shanghai_tech_data.py:18-44):
+    <database>/<part>/<dataset>_data/{images,labels,<maps>}/<name>.npy -> (image, label, map) / CrowdExamples."""
+    import os
+    import srgan_amd  # noqa: F401
+    from srgan_amd.crowd.data import PreprocessedCrowdDataset
+    generator = np.random.RandomState(3)
+    root = tmp_path / 'ShanghaiTech' / 'part_B' / 'test_data'
+    scenes = {}
+    for name, shape in (('IMG_2.npy', (30, 40)), ('IMG_1.npy', (25, 35)), ('IMG_3.npy', (20, 20))):
+        scenes[name] = (generator.randint(0, 256, size=shape + (3,)).astype(np.uint8),
+                        generator.rand(*shape).astype(np.float32), generator.rand(*shape).astype(np.float32))
+        for directory, array in zip(('images', 'labels', 'density3e-1'), scenes[name]):
+            os.makedirs(root / directory, exist_ok=True)
+            np.save(root / directory / name, array)
+    (root / 'labels' / 'notes.txt').write_text('ignored')
+    dataset = PreprocessedCrowdDataset(str(tmp_path / 'ShanghaiTech'), dataset='test', part='part_B',
+                                       map_directory_name='density3e-1')
+    assert len(dataset) == dataset.length == 3 and dataset.file_names == ['IMG_1.npy', 'IMG_2.npy', 'IMG_3.npy']
+    image, label, map_ = dataset[1]
+    for got, expected in zip((image, label, map_), scenes['IMG_2.npy']):
+        np.testing.assert_array_equal(got, expected)
+    examples = dataset.examples()
+    assert [e.image.shape[:2] for e in examples] == [(25, 35), (30, 40), (20, 20)]
+    np.testing.assert_array_equal(examples[2].map, scenes['IMG_3.npy'][2])
+    assert len(PreprocessedCrowdDataset(str(tmp_path / 'ShanghaiTech'), dataset='test', part='part_B',
+                                        number_of_examples=2, map_directory_name='density3e-1')) == 2

@@ -749,3 +749,48 @@ def test_crowd_step_fed_by_the_device_patch_loader(pkg):
     experiment.gan_training_step(x, (heads, knn), u, 0)
     values = [v[-1][1] for v in experiment.gan_summary_writer.scalars.values()]
     assert len(values) >= 6 and all(np.isfinite(values))
+
+
+def test_crowd_experiment_on_a_preprocessed_database(pkg, tmp_path, monkeypatch):
+    """SURVEY.md 8(f) N4 + N2 end to end: with ``SRGAN_CROWD_DATABASE`` pointing at a database in the reference's
+    preprocessed layout, ``CrowdExperiment.dataset_setup`` keeps the training scenes resident and cuts batches on the
+    device; one iteration runs on them and the full-image test summaries walk the test split."""
+    import os
+    from srgan_amd.settings import Settings
+    from srgan_amd.crowd.srgan import CrowdExperiment
+    from srgan_amd.utility import SummaryWriter, seed_all
+    generator = np.random.RandomState(4)
+    for split, count in (('train', 3), ('test', 2)):
+        for index in range(count):
+            shape = (80 + 8 * index, 100)
+            arrays = {'images': generator.randint(0, 256, size=shape + (3,)).astype(np.uint8),
+                      'labels': (generator.rand(*shape) < 0.004).astype(np.float32),
+                      'i1nn_maps': generator.rand(*shape).astype(np.float32)}
+            for directory, array in arrays.items():
+                os.makedirs(tmp_path / 'part_A' / f'{split}_data' / directory, exist_ok=True)
+                np.save(tmp_path / 'part_A' / f'{split}_data' / directory / f'IMG_{index}.npy', array)
+    monkeypatch.setenv('SRGAN_CROWD_DATABASE', str(tmp_path))
+    monkeypatch.setenv('SRGAN_CROWD_DATABASE_PART', 'part_A')
+    settings = Settings()
+    settings.batch_size, settings.image_patch_size, settings.test_sliding_window_size = 2, 64, 32
+    settings.labeled_dataset_size, settings.unlabeled_dataset_size, settings.test_summary_size = 2, 3, None
+    settings.matching_loss_multiplier, settings.contrasting_loss_multiplier = 1e3, 1e2
+    settings.gradient_penalty_multiplier, settings.map_multiplier = 1e2, 1e-3
+    experiment = CrowdExperiment(settings)
+    experiment.dataset_setup()
+    assert len(experiment.train_dataset_loader.images) == 2 and len(experiment.unlabeled_dataset_loader.images) == 3
+    seed_all(0)
+    experiment.model_setup()
+    experiment.dnn_summary_writer, experiment.gan_summary_writer = SummaryWriter(), SummaryWriter()
+    finish_setup(experiment)
+    x, heads, knn = next(iter(experiment.train_dataset_loader))
+    u = next(iter(experiment.unlabeled_dataset_loader))[0]
+    assert tuple(x.shape) == (2, 3, 64, 64) and tuple(heads.shape) == (2, 64, 64) == tuple(knn.shape)
+    experiment.dnn_training_step(x, (heads, knn), 0)
+    experiment.gan_training_step(x, (heads, knn), u, 0)
+    experiment.eval_mode()
+    experiment.validation_summaries(0)
+    logged = {tag: values[-1][1] for tag, values in experiment.gan_summary_writer.scalars.items()}
+    for tag in ('0 Test Error/MAE count', '0 Test Error/RMSE count', '0 Test Error/Ratio MAE GAN DNN',
+                'Discriminator/Gradient Penalty'):
+        assert np.isfinite(logged[tag]), tag
