@@ -192,6 +192,12 @@ int srgan_crowd_extract_patches(const void* const* images_u8, const float* const
                                 const int32_t* flips, int32_t B, int32_t P, float* out_images, float* out_labels,
                                 float* out_maps, void* stream);
 
+/* Offline ikNN label of a crowd scene (reference crowd/database_preprocessor.py:93-101,266-290: generate_knn_map +
+ * 1 / (map + epsilon)): out[y, x] = 1 / (mean over the k nearest heads of the Euclidean distance from (y, x), each
+ * clipped at upper_bound when upper_bound > 0, + epsilon).  heads_yx: M (y, x) pairs, float; k <= 8 and k = min(k, M) as in the reference. */
+int srgan_crowd_iknn_map(const float* heads_yx, int32_t M, int32_t H, int32_t W, int32_t k, float epsilon, float upper_bound,
+                         float* out, void* stream);
+
 /* Adam on a flat arena, torch.optim.Adam defaults and operation order (reference srgan.py:131-138,266,297,305);
  * `step` is the 1-based update count. */
 int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

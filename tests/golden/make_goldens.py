@@ -765,9 +765,30 @@ def g11_crowd_evaluation():
     save('g11_crowd_evaluation', **out)
 
 
+def g12_crowd_labels():
+    """the offline labels of the reference's database preprocessor (crowd/database_preprocessor.py:
+    253-290): the point map of the annotated heads and the ikNN maps 1 / (generate_knn_map(k) + 1) for k = 1..5, on two
+    small scenes (one with fewer heads than neighbours)."""
+    from crowd.database_preprocessor import generate_knn_map, generate_point_density_map
+    random_state = np.random.RandomState(12)
+    out = {}
+    for index, (shape, heads) in enumerate((((40, 56), 30), ((24, 33), 3))):
+        positions = random_state.rand(heads, 2) * (np.array(shape) - 1)          # (y, x) order, as the preprocessors pass
+        out[f'scene{index}/shape'] = np.array(shape)
+        out[f'scene{index}/heads_yx'] = positions
+        density, outside = generate_point_density_map(positions, shape)
+        out[f'scene{index}/point_map'] = density
+        assert outside == 0
+        for k in (1, 2, 3, 4, 5):
+            out[f'scene{index}/i{k}nn_map'] = 1 / (generate_knn_map(positions, shape, number_of_neighbors=k) + 1)
+        out[f'scene{index}/i3nn_map_bounded'] = 1 / (generate_knn_map(positions, shape, number_of_neighbors=3,
+                                                                          upper_bound=6.0) + 1)
+    save('g12_crowd_labels', **out)
+
+
 ALL = {'g0': g0_toydata, 'g1': g1_distance, 'g2': g2_sgan_math, 'g3': g3_coefficient_srgan,
        'g4': g4_coefficient_sgan, 'g4b': g4b_coefficient_dggan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
-       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan, 'g11': g11_crowd_evaluation}
+       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan, 'g11': g11_crowd_evaluation, 'g12': g12_crowd_labels}
 
 if __name__ == '__main__':
     wanted = sys.argv[1:] or ['all']

@@ -50,3 +50,17 @@ def test_preprocessed_database_reader(tmp_path):
     np.testing.assert_array_equal(examples[2].map, scenes['IMG_3.npy'][2])
     assert len(PreprocessedCrowdDataset(str(tmp_path / 'ShanghaiTech'), dataset='test', part='part_B',
                                         number_of_examples=2, map_directory_name='density3e-1')) == 2
+
+
+def test_point_density_map_matches_the_reference():
+    """generate_point_density_map against the reference's output (golden g12): host-side, runs without a GPU."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd.crowd.labels import generate_point_density_map
+    from helpers import load_golden
+    g = load_golden('g12_crowd_labels')
+    for index in range(2):
+        density, outside = generate_point_density_map(g[f'scene{index}/heads_yx'], tuple(g[f'scene{index}/shape']))
+        assert outside == 0
+        np.testing.assert_array_equal(density, g[f'scene{index}/point_map'])
+    _, outside = generate_point_density_map(np.array([[3.0, 99.0], [1.0, 1.0]]), (10, 10))
+    assert outside == 1

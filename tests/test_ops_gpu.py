@@ -646,3 +646,27 @@ def test_device_side_crowd_patch_batches(F):
     for scene, y, x, flip in loader.draw_positions():
         height, width = loader.shapes[scene]
         assert 32 <= y <= height - 32 and 32 <= x <= width - 32 and flip in (0, 1)
+
+
+@gpu
+def test_crowd_iknn_labels(F):
+    """srgan_crowd_iknn_map / crowd.labels.generate_iknn_map against the reference preprocessor's own output (golden
+    g12: generate_knn_map through scikit-learn's ball tree, k = 1..5, a scene with fewer heads than neighbours, and
+    the clipped variant); float32 on the device against float64 on the host."""
+    from helpers import load_golden
+    from srgan_amd.crowd.labels import generate_iknn_map
+    g = load_golden('g12_crowd_labels')
+    for index in range(2):
+        heads, shape = g[f'scene{index}/heads_yx'], tuple(int(v) for v in g[f'scene{index}/shape'])
+        for k in (1, 2, 3, 4, 5):
+            close(generate_iknn_map(heads, shape, number_of_neighbors=k), torch.from_numpy(g[f'scene{index}/i{k}nn_map']),
+                  1e-5, f'scene {index} i{k}nn map')
+        close(generate_iknn_map(heads, shape, number_of_neighbors=3, upper_bound=6.0),
+              torch.from_numpy(g[f'scene{index}/i3nn_map_bounded']), 1e-5, f'scene {index} bounded i3nn map')
+    # a scene larger than one chunk of the head list, against a brute-force torch reference
+    generator = torch.Generator().manual_seed(5)
+    heads = torch.rand(2500, 2, generator=generator) * torch.tensor([95.0, 127.0])
+    ys, xs = torch.meshgrid(torch.arange(96.0), torch.arange(128.0), indexing='ij')
+    distances = torch.cdist(torch.stack([ys.reshape(-1), xs.reshape(-1)], 1).double(), heads.double())
+    expected = 1 / (distances.topk(4, dim=1, largest=False).values.mean(1).reshape(96, 128) + 1)
+    close(generate_iknn_map(heads.numpy(), (96, 128), number_of_neighbors=4), expected, 1e-5, 'large scene i4nn map')
