@@ -197,6 +197,12 @@ int srgan_crowd_extract_patches(const void* const* images_u8, const float* const
  * clipped at upper_bound when upper_bound > 0, + epsilon).  heads_yx: M (y, x) pairs, float; k <= 8 and k = min(k, M) as in the reference. */
 int srgan_crowd_iknn_map(const float* heads_yx, int32_t M, int32_t H, int32_t W, int32_t k, float epsilon, float upper_bound,
                          float* out, void* stream);
+/* Gaussian density label before its final rescaling (reference generate_density_label with perspective = None,
+ * crowd/database_preprocessor.py:110-236: sigma_h = beta * mean distance of head h to its <= 11 nearest heads including
+ * itself, window half-size int(2 sigma_h), each window normalised by its unclipped sum): out[y, x] = sum over heads.
+ * workspace: 20 * M bytes of device memory.  The caller multiplies by head_count / sum(out) as the reference does. */
+int srgan_crowd_density_label(const float* heads_yx, int32_t M, int32_t H, int32_t W, float beta, void* workspace, float* out,
+                              void* stream);
 
 /* Adam on a flat arena, torch.optim.Adam defaults and operation order (reference srgan.py:131-138,266,297,305);
  * `step` is the 1-based update count. */

@@ -63,6 +63,7 @@ SIGNATURES = {
     'srgan_profile_end': ([ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     'srgan_profile_report': ([ctypes.c_char_p, ctypes.c_int64], ctypes.c_int64),
+    'srgan_crowd_density_label': ([vp, i32, i32, i32, f32, vp, vp, vp], ctypes.c_int),
     'srgan_crowd_iknn_map': ([vp, i32, i32, i32, i32, f32, f32, vp, vp], ctypes.c_int),
     'srgan_crowd_extract_patches': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     'srgan_adam_step': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp], ctypes.c_int),

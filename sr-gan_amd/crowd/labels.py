@@ -36,3 +36,24 @@ def generate_iknn_map(head_positions, label_size, number_of_neighbors=1, epsilon
                                                    float(upper_bound) if upper_bound is not None else 0.0, out.data_ptr(),
                                                    torch.cuda.current_stream(device).cuda_stream), 'srgan_crowd_iknn_map')
     return out
+
+
+def generate_density_label(head_positions, label_size, neighbor_deviation_beta=0.15, device=None):
+    """The Gaussian density label of the reference's preprocessor for databases without a perspective map
+    (``generate_density_label(positions, size, perspective_resizing=True, yx_order=True, neighbor_deviation_beta=beta)``,
+    crowd/database_preprocessor.py:82-91,110-236): every head a Gaussian of sigma = beta x its mean distance to its 11
+    nearest heads (itself included), windowed at int(2 sigma), normalised, and the whole label rescaled to the head
+    count.  float32 device tensor [H, W]."""
+    device = device or current_device()
+    heads = torch.as_tensor(np.ascontiguousarray(head_positions, dtype=np.float32)).to(device)
+    if heads.ndim != 2 or heads.shape[1] != 2 or heads.shape[0] < 2:
+        raise ValueError('head_positions must be an (M >= 2, 2) array of (y, x) pairs')
+    height, width = int(label_size[0]), int(label_size[1])
+    out = torch.empty((height, width), dtype=torch.float32, device=device)
+    workspace = torch.empty((heads.shape[0], 5), dtype=torch.float32, device=device)
+    _lib.check(_lib.library().srgan_crowd_density_label(heads.data_ptr(), heads.shape[0], height, width,
+                                                        float(neighbor_deviation_beta), workspace.data_ptr(), out.data_ptr(),
+                                                        torch.cuda.current_stream(device).cuda_stream),
+               'srgan_crowd_density_label')
+    counted = (workspace[:, 4] > 0).sum()             # heads whose window reaches the image
+    return out * (counted / out.sum())

@@ -769,10 +769,10 @@ def g12_crowd_labels():
     """the offline labels of the reference's database preprocessor (crowd/database_preprocessor.py:
     253-290): the point map of the annotated heads and the ikNN maps 1 / (generate_knn_map(k) + 1) for k = 1..5, on two
     small scenes (one with fewer heads than neighbours)."""
-    from crowd.database_preprocessor import generate_knn_map, generate_point_density_map
+    from crowd.database_preprocessor import generate_density_label, generate_knn_map, generate_point_density_map
     random_state = np.random.RandomState(12)
     out = {}
-    for index, (shape, heads) in enumerate((((40, 56), 30), ((24, 33), 3))):
+    for index, (shape, heads) in enumerate((((40, 56), 30), ((24, 33), 3), ((72, 90), 400))):
         positions = random_state.rand(heads, 2) * (np.array(shape) - 1)          # (y, x) order, as the preprocessors pass
         out[f'scene{index}/shape'] = np.array(shape)
         out[f'scene{index}/heads_yx'] = positions
@@ -783,6 +783,16 @@ def g12_crowd_labels():
             out[f'scene{index}/i{k}nn_map'] = 1 / (generate_knn_map(positions, shape, number_of_neighbors=k) + 1)
         out[f'scene{index}/i3nn_map_bounded'] = 1 / (generate_knn_map(positions, shape, number_of_neighbors=3,
                                                                           upper_bound=6.0) + 1)
+    # The "density{beta}" labels (crowd/database_preprocessor.py:82-91).  Under NumPy 2 the reference's window clipping
+    # at the TOP / LEFT border wraps around (uint32 head coordinate minus a Python int), so these scenes keep their
+    # heads a window away from those two borders; clipping at the bottom / right border is exercised.
+    for index, (shape, heads, margin) in enumerate((((90, 110), 40, 34), ((72, 90), 400, 10))):
+        positions = margin + random_state.rand(heads, 2) * (np.array(shape) - 1 - margin)
+        out[f'dscene{index}/shape'] = np.array(shape)
+        out[f'dscene{index}/heads_yx'] = positions
+        for beta in (0.1, 0.3, 0.5):
+            out[f'dscene{index}/density_beta{beta}'] = generate_density_label(
+                positions, shape, perspective_resizing=True, yx_order=True, neighbor_deviation_beta=beta)
     save('g12_crowd_labels', **out)
 
 

@@ -58,7 +58,7 @@ def test_point_density_map_matches_the_reference():
     from srgan_amd.crowd.labels import generate_point_density_map
     from helpers import load_golden
     g = load_golden('g12_crowd_labels')
-    for index in range(2):
+    for index in range(3):
         density, outside = generate_point_density_map(g[f'scene{index}/heads_yx'], tuple(g[f'scene{index}/shape']))
         assert outside == 0
         np.testing.assert_array_equal(density, g[f'scene{index}/point_map'])

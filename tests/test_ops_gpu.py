@@ -649,20 +649,29 @@ def test_device_side_crowd_patch_batches(F):
 
 
 @gpu
-def test_crowd_iknn_labels(F):
+def test_crowd_offline_labels(F):
     """srgan_crowd_iknn_map / crowd.labels.generate_iknn_map against the reference preprocessor's own output (golden
     g12: generate_knn_map through scikit-learn's ball tree, k = 1..5, a scene with fewer heads than neighbours, and
-    the clipped variant); float32 on the device against float64 on the host."""
+    the clipped variant) and srgan_crowd_density_label / generate_density_label against its generate_density_label
+    (beta 0.1 / 0.3 / 0.5; 40 and 400 heads); float32 on the device against float64 on the host."""
     from helpers import load_golden
     from srgan_amd.crowd.labels import generate_iknn_map
     g = load_golden('g12_crowd_labels')
-    for index in range(2):
+    for index in range(3):
         heads, shape = g[f'scene{index}/heads_yx'], tuple(int(v) for v in g[f'scene{index}/shape'])
         for k in (1, 2, 3, 4, 5):
             close(generate_iknn_map(heads, shape, number_of_neighbors=k), torch.from_numpy(g[f'scene{index}/i{k}nn_map']),
                   1e-5, f'scene {index} i{k}nn map')
         close(generate_iknn_map(heads, shape, number_of_neighbors=3, upper_bound=6.0),
               torch.from_numpy(g[f'scene{index}/i3nn_map_bounded']), 1e-5, f'scene {index} bounded i3nn map')
+    from srgan_amd.crowd.labels import generate_density_label
+    for index in range(2):                      # Gaussian density labels: 40 and 400 heads, windows clipped at the bottom / right
+        heads, shape = g[f'dscene{index}/heads_yx'], tuple(int(v) for v in g[f'dscene{index}/shape'])
+        for beta in (0.1, 0.3, 0.5):
+            expected = torch.from_numpy(g[f'dscene{index}/density_beta{beta}'])
+            label = generate_density_label(heads, shape, neighbor_deviation_beta=beta)
+            close(label, expected, 1e-4, f'scene {index} density label beta {beta}')
+            assert abs(float(label.sum()) - float(expected.sum())) < 1e-3 * float(expected.sum())
     # a scene larger than one chunk of the head list, against a brute-force torch reference
     generator = torch.Generator().manual_seed(5)
     heads = torch.rand(2500, 2, generator=generator) * torch.tensor([95.0, 127.0])
