@@ -75,6 +75,13 @@ typedef struct srgan_bn_relu { const float* mean; const float* inv_std; const fl
 int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass);
 int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
                             const float* bias, float* y, void* stream);
+/* Small problems split K over the grid and add their partial results with fp32 atomics into a zeroed y: one extra
+ * zero-fill launch per convolution.  srgan_conv2d_fwd_bnrelu_splits(desc) tells how many K splits the forward of this
+ * geometry uses (1: plain stores; -1: no fused form); a caller that hands over y ALREADY ZERO (one fill for the outputs
+ * of a whole dense block) calls srgan_conv2d_fwd_bnrelu_into_zeros, which skips the per-call zero-fill. */
+int srgan_conv2d_fwd_bnrelu_splits(const srgan_conv_desc* desc);
+int srgan_conv2d_fwd_bnrelu_into_zeros(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
+                                       const float* bias, float* y, void* stream);
 int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
                                  const float* x, float* gx, float* g_gamma, float* g_beta, int accumulate, void* stream);
 int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,

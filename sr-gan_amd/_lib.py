@@ -29,6 +29,9 @@ SIGNATURES = {
     'srgan_conv2d_bwd_weight': ([ctypes.POINTER(ConvDesc), vp, vp, vp, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),
     'srgan_conv2d_bnrelu_supported': ([ctypes.POINTER(ConvDesc), ctypes.c_int], ctypes.c_int),
     'srgan_conv2d_fwd_bnrelu': ([ctypes.POINTER(ConvDesc), vp, ctypes.POINTER(BnRelu), vp, vp, vp, vp], ctypes.c_int),
+    'srgan_conv2d_fwd_bnrelu_into_zeros': ([ctypes.POINTER(ConvDesc), vp, ctypes.POINTER(BnRelu), vp, vp, vp, vp],
+                                           ctypes.c_int),
+    'srgan_conv2d_fwd_bnrelu_splits': ([ctypes.POINTER(ConvDesc)], ctypes.c_int),
     'srgan_bn_conv_tangent_weights': ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], ctypes.c_int),
     'srgan_conv2d_bwd_data_bnrelu': ([ctypes.POINTER(ConvDesc), vp, vp, ctypes.POINTER(BnRelu), vp, vp, vp, vp,
                                       ctypes.c_int, vp], ctypes.c_int),

@@ -359,6 +359,8 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
   return plan;
 }
 
+int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) { return conv3x3_plan(N, CI, CO, H, W).split; }
+
 // The batch-norm backward epilogue needs whole sums in one workgroup (no split) and a 32- or 64-row tile.
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) {
   const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W);
@@ -389,13 +391,13 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   p.ci_per_split = plan.chunks_per * plan.ci_t;
   const int64_t blocks = plan.blocks;
   SRGAN_REQUIRE(blocks < (int64_t)1 << 31 && split <= 65535, SRGAN_ERANGE, "conv3x3 grid");
-  if (split > 1) {
-    if (!accumulate)
+  if (split > 1) {                       // accumulate: 0 store, 1 add to out, 2 out is already zero
+    if (accumulate == 0)
       SRGAN_HIP(hipMemset2DAsync(out, (size_t)out_bs * sizeof(float), 0, (size_t)CO * H * W * sizeof(float), (size_t)N,
                                  stream));
     p.mode = 2;
   } else {
-    p.mode = accumulate ? 1 : 0;
+    p.mode = accumulate == 1 ? 1 : 0;
   }
   if (epilogue) {
     SRGAN_REQUIRE(!bn && !bias && !accumulate && split == 1 && bm <= 64, SRGAN_EUNSUPPORTED,

@@ -604,7 +604,9 @@ bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, in
 bool pointwise_enabled();
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
                   int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream,
-                  const float* const* bn = nullptr, const BnBackwardEpilogue* epilogue = nullptr);
+                  const float* const* bn = nullptr, const BnBackwardEpilogue* epilogue = nullptr,
+                  int* plan_only_split = nullptr);
+int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 
 // 1x1 / stride 1 / unpadded on images whose pixel count is a multiple of 32: the register-streamed pointwise kernel.
 static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
@@ -840,21 +842,43 @@ int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
   return 0;
 }
 
-int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
-                            const float* bias, float* y, void* stream) {
+// y_state: 0 = y holds anything (stored over), 2 = y is already zero where the convolution writes (a kernel that splits
+// K over the grid then skips its own zero-fill launch; see srgan_conv2d_fwd_bnrelu_splits).
+static int fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w, const float* bias,
+                      float* y, int y_state, int* plan_only_split, void* stream) {
   ConvGeom g;
   SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu geometry");
-  SRGAN_REQUIRE(x && w && y && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu pointers");
+  SRGAN_REQUIRE(plan_only_split || (x && w && y && bn_ok(bn)), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu pointers");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 0), SRGAN_EUNSUPPORTED, "srgan_conv2d_fwd_bnrelu geometry support");
-  const float* const coefficients[4] = {bn->mean, bn->inv_std, bn->gamma, bn->beta};
-  if (pointwise(g) && ((uintptr_t)w & 15) == 0 && pointwise_ksplit_wanted(g.N, g.C, g.K, g.H * g.W, true))
+  const float* const coefficients[4] = {bn ? bn->mean : nullptr, bn ? bn->inv_std : nullptr, bn ? bn->gamma : nullptr,
+                                        bn ? bn->beta : nullptr};
+  if (pointwise(g) && (plan_only_split || ((uintptr_t)w & 15) == 0) &&
+      pointwise_ksplit_wanted(g.N, g.C, g.K, g.H * g.W, true)) {
+    if (plan_only_split) { *plan_only_split = 1; return SRGAN_OK; }
     return pointwise_ksplit_run(x, g.x_bs, w, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream,
                                 coefficients);
+  }
   if (pointwise(g))
-    return pointwise_run(x, g.x_bs, w, g.C, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream,
-                         coefficients);
-  return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, 0, (hipStream_t)stream,
-                     coefficients);
+    return pointwise_run(x, g.x_bs, w, g.C, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, y_state, (hipStream_t)stream,
+                         coefficients, nullptr, plan_only_split);
+  if (plan_only_split) { *plan_only_split = conv3x3_splits(g.N, g.C, g.K, g.H, g.W); return SRGAN_OK; }
+  return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, y_state,
+                     (hipStream_t)stream, coefficients);
+}
+
+int srgan_conv2d_fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
+                            const float* bias, float* y, void* stream) {
+  return fwd_bnrelu(desc, x, bn, w, bias, y, 0, nullptr, stream);
+}
+
+int srgan_conv2d_fwd_bnrelu_into_zeros(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w,
+                                       const float* bias, float* y, void* stream) {
+  return fwd_bnrelu(desc, x, bn, w, bias, y, 2, nullptr, stream);
+}
+
+int srgan_conv2d_fwd_bnrelu_splits(const srgan_conv_desc* desc) {
+  int split = 0;
+  return fwd_bnrelu(desc, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &split, nullptr) == SRGAN_OK ? split : -1;
 }
 
 int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,

@@ -405,7 +405,9 @@ static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t st
 // bn (4 pointers: mean, inv_std, gamma, beta; NULL = none): the input is relu(batch_norm_eval(in)) on the fly.
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
                   int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream,
-                  const float* const* bn, const BnBackwardEpilogue* epilogue) {
+                  const float* const* bn, const BnBackwardEpilogue* epilogue, int* plan_only_split) {
+  // accumulate: 0 store, 1 add to out, 2 out is already zero (a K split then skips its zero-fill; otherwise a store).
+  // plan_only_split: when given, nothing is launched and the number of K splits this call would use is returned there.
   PointwiseParams p;
   p.epi_x = nullptr; p.epi_x_bs = 0; p.epi_partial = nullptr; p.epi_cols = 0;
   p.in = in; p.w = w; p.out = out; p.bias = bias;
@@ -463,12 +465,16 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   p.k_per_split = per * 64;
   split = (slices + per - 1) / per;
   SRGAN_REQUIRE(blocks < ((int64_t)1 << 31) && split <= 65535, SRGAN_ERANGE, "pointwise grid");
+  if (plan_only_split) {
+    *plan_only_split = split;
+    return SRGAN_OK;
+  }
   if (split > 1) {
-    if (!accumulate)
+    if (accumulate == 0)
       SRGAN_HIP(hipMemset2DAsync(out, (size_t)out_bs * sizeof(float), 0, (size_t)CO * HW * sizeof(float), (size_t)N, stream));
     p.mode = 2;
   } else {
-    p.mode = accumulate ? 1 : 0;
+    p.mode = accumulate == 1 ? 1 : 0;
   }
   if (epilogue) {
     SRGAN_REQUIRE(!bn && !bias, SRGAN_EINVAL, "pointwise batch-norm backward epilogue: no prologue, no bias");

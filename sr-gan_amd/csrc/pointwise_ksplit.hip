@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
     if (o >= p.M) continue;
     if (p.bias) v += p.bias[o];
     float* dst = out_n + (int64_t)o * p.HW + col;
-    if (p.accumulate) *dst += v;
+    if (p.accumulate == 1) *dst += v;
     else __builtin_nontemporal_store(v, dst);
   }
 }

@@ -72,7 +72,6 @@ def dense_block(x, layers):
     stream = F._stream()
     buffer = _empty((n, total, h, w), device)
     buffer_bs = total * hw
-    F._call('srgan_copy_channels', x.data.data_ptr(), c0, 0, buffer.data_ptr(), total, 0, c0, n, hw, 0, stream)
     saved = []
     parameter_vars = [parameter_var(p) for layer in layers for p in layer.parameters()]
     requires = grad_enabled() and (x.requires_grad or any(v.requires_grad for v in parameter_vars))
@@ -94,13 +93,27 @@ def dense_block(x, layers):
         inv, mean = norm._inverse_std()
         return _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
 
+    # Small planes make the convolutions split K over the grid (fp32 atomics into a zeroed output): one zero-fill for
+    # ALL the layers' outputs instead of one fill launch per convolution.
+    zero_b1 = zero_new = False
+    if prologue:
+        last_cin = c0 + (len(layers) - 1) * growth
+        zero_b1 = lib.srgan_conv2d_fwd_bnrelu_splits(_desc(n, last_cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0)) > 1
+        zero_new = lib.srgan_conv2d_fwd_bnrelu_splits(probe2) > 1
+        if zero_new:
+            F._call('srgan_fill', buffer.data_ptr(), buffer.numel(), 0.0, stream)
+        if zero_b1:
+            b1_all = torch.zeros((len(layers), n, width, h, w), dtype=torch.float32, device=device)
+    F._call('srgan_copy_channels', x.data.data_ptr(), c0, 0, buffer.data_ptr(), total, 0, c0, n, hw, 0, stream)
+    forward1 = 'srgan_conv2d_fwd_bnrelu_into_zeros' if zero_b1 else 'srgan_conv2d_fwd_bnrelu'
+    forward2 = 'srgan_conv2d_fwd_bnrelu_into_zeros' if zero_new else 'srgan_conv2d_fwd_bnrelu'
     for index, layer in enumerate(layers):
         cin = c0 + index * growth
-        b1 = _empty((n, width, h, w), device)
+        b1 = b1_all[index] if zero_b1 else _empty((n, width, h, w), device)
         if prologue:
-            F._call('srgan_conv2d_fwd_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), buffer.data_ptr(),
+            F._call(forward1, _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), buffer.data_ptr(),
                     bn_struct(layer.norm1), layer.conv1.weight.data_ptr(), None, b1.data_ptr(), stream)
-            F._call('srgan_conv2d_fwd_bnrelu', _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs), b1.data_ptr(),
+            F._call(forward2, _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs), b1.data_ptr(),
                     bn_struct(layer.norm2), layer.conv2.weight.data_ptr(), None, _ptr(buffer, cin * hw), stream)
             if requires:
                 saved.append([None, b1, None])
