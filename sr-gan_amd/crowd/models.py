@@ -68,7 +68,10 @@ class _Transition(nn.Sequential):
         self.add_module('pool', nn.AvgPool2d(kernel_size=2, stride=2))
 
     def forward(self, x):
-        return self.pool(self.conv(self.norm(x, relu=True)))
+        y = fused.bn_relu_conv(x, self.norm, self.conv) if fused.ENABLED else None
+        if y is None:
+            y = self.conv(self.norm(x, relu=True))
+        return self.pool(y)
 
 
 class MapModule(nn.Module):

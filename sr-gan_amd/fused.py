@@ -294,3 +294,87 @@ def dense_block(x, layers):
 
     out.node = Node((x,) + tuple(parameter_vars), backward, 'dense_block')
     return out
+
+
+def bn_relu_conv(x, norm, conv):
+    """``conv(relu(norm(x)))`` for a 1x1 convolution as ONE tape node on the fused kernels of the dense layers (the
+    DenseNet transitions, reference crowd/models.py:364-371): the activated tensor is never materialised in either
+    direction -- forward with the normalisation in the operand stream, weight gradient likewise, data gradient with the
+    batch-norm backward in its epilogue.  First order, recorded backward (input gradient only) and its double backward
+    (linearised forward on the masked tangent) follow the dense block above.  Returns None when the geometry has no fused
+    form (the caller then composes the primitive ops)."""
+    n, cin, h, w = x.shape
+    if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.bias is not None:
+        return None
+    cout, hw = conv.out_channels, h * w
+    lib = _lib.library()
+    desc = _desc(n, cin, h, w, cout, 1, 1, 1, 0)
+    if not (PROLOGUE and EPILOGUE and all(lib.srgan_conv2d_bnrelu_supported(desc, kind) for kind in (0, 1, 2))):
+        return None
+    device = x.data.device
+    parameter_vars = [parameter_var(p) for p in (norm.weight, norm.bias, conv.weight)]
+    requires = grad_enabled() and (x.requires_grad or any(v.requires_grad for v in parameter_vars))
+
+    def bn_struct():
+        inv, mean = norm._inverse_std()
+        return _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
+
+    y = _empty((n, cout, h, w), device)
+    F._call('srgan_conv2d_fwd_bnrelu', desc, x.data.data_ptr(), bn_struct(), conv.weight.data_ptr(), None, y.data_ptr(),
+            F._stream())
+    out = Var(y, requires_grad=requires)
+    if not requires:
+        return out
+
+    def backward(g, needs):
+        recorded = grad_enabled()
+        want_params = any(needs[1:])
+        if recorded and want_params:
+            raise NotImplementedError('a recorded backward of the fused norm -> relu -> conv yields the input gradient only')
+        stream = F._stream()
+        if want_params:
+            F._call('srgan_conv2d_bwd_weight_bnrelu', desc, x.data.data_ptr(), bn_struct(), g.data.data_ptr(),
+                    conv.weight.grad.data_ptr(), 1, stream)
+        gx = None
+        if needs[0] or want_params:
+            gx_data = _empty((n, cin, h, w), device)
+            F._call('srgan_conv2d_bwd_data_bnrelu', desc, g.data.data_ptr(), conv.weight.data_ptr(), bn_struct(),
+                    x.data.data_ptr(), gx_data.data_ptr(), norm.weight.grad.data_ptr() if want_params else None,
+                    norm.bias.grad.data_ptr() if want_params else None, 0, stream)
+            if needs[0]:
+                gx = Var(gx_data)
+                if recorded:
+                    gx.requires_grad = True
+                    gx.node = Node((g,) + tuple(parameter_vars), lambda v, needs2: double_backward(v, needs2, g),
+                                   'bn_relu_conv_backward')
+        return (gx,) + (None,) * len(parameter_vars)
+
+    def double_backward(v, needs2, g):
+        """v = dL/d(input gradient): dL/dg = conv(mask * v, W * a); dL/dW += wgrad(mask * v, g) * a; dL/dgamma +=
+        inv_std * sum_co W * wgrad(mask * v, g)."""
+        if grad_enabled():
+            raise NotImplementedError('third-order differentiation of the fused norm -> relu -> conv')
+        stream = F._stream()
+        want_params = any(needs2[1:])
+        inv, mean = norm._inverse_std()
+        u = _empty((n, cin, h, w), device)
+        F._call('srgan_bn_act_bwd', v.data.data_ptr(), x.data.data_ptr(), mean.data.data_ptr(), inv.data.data_ptr(),
+                norm.weight.data_ptr(), norm.bias.data_ptr(), 1, u.data_ptr(), None, None, n, cin, hw, 0, 0, 0, 0, 1, stream)
+        q = None
+        if want_params:
+            q = torch.zeros(conv.weight.shape, dtype=torch.float32, device=device)
+            F._call('srgan_conv2d_bwd_weight', desc, u.data_ptr(), g.data.data_ptr(), q.data_ptr(), 1, 0, stream)
+        scaled = _empty(conv.weight.shape, device)
+        F._call('srgan_bn_conv_tangent_weights', conv.weight.data_ptr(), q.data_ptr() if want_params else None,
+                inv.data.data_ptr(), norm.weight.data_ptr(), scaled.data_ptr(),
+                conv.weight.grad.data_ptr() if want_params else None,
+                norm.weight.grad.data_ptr() if want_params else None, cout, cin, 1, stream)
+        tangent = None
+        if needs2[0]:
+            tangent = _empty((n, cout, h, w), device)
+            F._call('srgan_conv2d_fwd', desc, u.data_ptr(), scaled.data_ptr(), None, tangent.data_ptr(), 0, stream)
+            tangent = Var(tangent)
+        return (tangent,) + (None,) * len(parameter_vars)
+
+    out.node = Node((x,) + tuple(parameter_vars), backward, 'bn_relu_conv')
+    return out

@@ -613,6 +613,54 @@ def test_fused_dense_block_with_in_kernel_batch_norm(F):
 
 
 @gpu
+def test_fused_transition_matches_primitive_path(F):
+    """The DenseNet transition's norm -> relu -> conv as one fused node (fused.bn_relu_conv) against the primitive ops:
+    forward, first-order gradients (trainable and frozen parameters) and the gradient-penalty second order."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd import fused, nn
+    from srgan_amd.crowd.models import _Transition
+    from srgan_amd.tape import backward
+    torch.manual_seed(7)
+    transition = _Transition(64, 32)
+    gen = torch.Generator().manual_seed(8)
+    norm = transition.norm
+    norm.weight.data = torch.rand(norm.weight.shape, generator=gen) + 0.5
+    norm.bias.data = torch.randn(norm.bias.shape, generator=gen) * 0.2
+    norm.running_mean.data = torch.randn(norm.running_mean.shape, generator=gen) * 0.2
+    norm.running_var.data = torch.rand(norm.running_var.shape, generator=gen) + 0.5
+    arena = nn.flatten_parameters(transition, torch.device('cuda', 0))
+    x_host = torch.randn(3, 64, 16, 16, generator=gen)
+    cotangent = torch.randn(3, 32, 8, 8, generator=gen)
+    results = {}
+    for enabled in (False, True):
+        fused.ENABLED = enabled
+        try:
+            arena.zero_grad()
+            x = F.leaf(dev(x_host), requires_grad=True)
+            y = transition(x)
+            backward(y, grad=F.leaf(dev(cotangent)))
+            first = (y.cpu(), x.grad.cpu(), arena.grad.detach().cpu().clone())
+            with nn.frozen_parameters(transition):
+                arena.zero_grad()
+                x = F.leaf(dev(x_host), requires_grad=True)
+                backward(transition(x), grad=F.leaf(dev(cotangent)))
+                frozen = (x.grad.cpu(), float(arena.grad.abs().max()))
+            arena.zero_grad()
+            x = F.leaf(dev(x_host), requires_grad=True)
+            scalar = F.sum_all(F.mul(transition(x), F.leaf(dev(cotangent))))
+            (gx,) = backward(scalar, inputs=[x], create_graph=True)
+            penalty = F.mean_all(F.square(F.add_scalar(F.row_norm(F.flatten2d(gx)), -1.0)))
+            backward(penalty)
+            results[enabled] = first + (gx.cpu(), arena.grad.detach().cpu().clone()) + frozen
+        finally:
+            fused.ENABLED = True
+    for i, what in enumerate(('output', 'input gradient', 'parameter gradients', 'recorded input gradient',
+                              'penalty parameter gradients', 'input gradient with frozen parameters')):
+        close(results[True][i], results[False][i], 1e-4, 'fused transition: ' + what)
+    assert results[True][6] == 0.0 and float(results[True][4].abs().max()) > 0.0
+
+
+@gpu
 def test_device_side_crowd_patch_batches(F):
     """srgan_crowd_extract_patches / DeviceCrowdPatchLoader against the host-side NumPy transforms
     of the reference pipeline (patch around a centre with zero padding, left-right flip, [-1, 1] normalisation, CHW)."""
