@@ -1,12 +1,16 @@
-"""Concat-free DenseNet block: ONE tape node per ``_DenseBlock`` (reference crowd/models.py:335-361).
+"""Concat-free DenseNet block: ONE tape node per ``_DenseBlock`` (reference crowd/models.py:335-361), and the
+transition's ``norm -> relu -> conv`` as one node on the same kernels (``bn_relu_conv``, crowd/models.py:364-371).
 
 The reference concatenates ``[x, new_features]`` after every layer (quadratic copy traffic) and autograd slices
 the gradient back apart.  Here the block owns one ``[N, C0 + L*k, H, W]`` buffer: every layer's 3x3 convolution
 writes its ``k`` channels straight into its slice (the conv kernel takes an output batch stride), and the
 batch-norm of the next layer reads a channel-slice *view* of the same buffer.  The backward keeps one gradient
 buffer of the same shape and walks the layers last-to-first: each layer reads its slice of it, and the gradient
-w.r.t. its (view) input is ACCUMULATED into the leading channels by the batch-norm backward kernel; weight and
-batch-norm parameter gradients are accumulated straight into the network's flat gradient arena.
+w.r.t. its (view) input is ACCUMULATED into the leading channels by the batch-norm backward epilogue of the
+data-gradient kernel (``srgan_conv2d_bwd_data_bnrelu``); weight and batch-norm parameter gradients are accumulated
+straight into the network's flat gradient arena.  Neither the normalised / activated tensors nor the gradients
+w.r.t. them exist in HBM: the convolution kernels evaluate batch-norm + ReLU in their operand streams (``PROLOGUE``)
+and its backward on their way out (``EPILOGUE``).
 
 Second order (the gradient penalty, reference srgan.py:360-375: ``autograd.grad(..., create_graph=True)`` w.r.t.
 the block input, then ``.backward()`` of a function of that gradient).  With frozen batch-norm and ReLU the block is
