@@ -25,6 +25,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails in the legacy mode)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import torch  # noqa: E402
 
