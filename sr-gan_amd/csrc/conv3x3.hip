@@ -324,7 +324,7 @@ bool conv3x3_enabled() {
 // into a pre-zeroed output) only as the last resort and never below two chunks per workgroup.
 struct Conv3Plan { int bm, th, tw, ci_t, tiles_x, tiles_y, tiles_m, split, chunks_per; int64_t blocks; };
 
-static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) {
+static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W, bool allow_split = true) {
   Conv3Plan plan;
   const int tw = W <= 16 ? 16 : 32;      // 16-wide images: a 32-lane column block = two image rows (no dead columns)
   plan.tw = tw;
@@ -343,14 +343,15 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
     else break;
   }
   plan.bm = bm; plan.th = th;
-  plan.ci_t = bm == 128 ? 4 : (bm == 64 ? 8 : 16);     // keeps the staged registers + accumulators <= 256
+  static const int ci_t32 = getenv("SRGAN_CONV3_CIT32") ? atoi(getenv("SRGAN_CONV3_CIT32")) : 8;
+  plan.ci_t = bm == 128 ? 4 : (bm == 64 ? 8 : ci_t32);     // keeps the staged registers + accumulators <= 256
   plan.tiles_m = (CO + bm - 1) / bm;
   plan.tiles_y = (H + rows(th) - 1) / rows(th);
   plan.blocks = count(bm, th);
   const int chunks = (CI + plan.ci_t - 1) / plan.ci_t;
   int split = 1;
   static const int split_below = getenv("SRGAN_CONV3_SPLIT_BELOW") ? atoi(getenv("SRGAN_CONV3_SPLIT_BELOW")) : 384;
-  if (plan.blocks < split_below && chunks >= 4) {
+  if (allow_split && plan.blocks < split_below && chunks >= 4) {
     split = (int)((512 + plan.blocks - 1) / plan.blocks);
     if (split > chunks / 2) split = chunks / 2;
   }
@@ -361,10 +362,9 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
 
 int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) { return conv3x3_plan(N, CI, CO, H, W).split; }
 
-// The batch-norm backward epilogue needs whole sums in one workgroup (no split) and a 32- or 64-row tile.
+// The batch-norm backward epilogue needs a 32- or 64-row tile (and whole sums in one workgroup: its plan never splits K).
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) {
-  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W);
-  return plan.split == 1 && plan.bm <= 64;
+  return conv3x3_plan(N, CI, CO, H, W, false).bm <= 64;      // (with the epilogue the plan does not split K)
 }
 
 void bn_partial_reduce_run(const float* partial, int tiles, int CO, const float* inv_std, float* g_gamma, float* g_beta,
@@ -385,7 +385,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
   p.in_bs = in_bs; p.out_bs = out_bs;
   p.w_so = w_so; p.w_si = w_si; p.w_skh = w_skh; p.w_skw = w_skw; p.w_base = w_base;
-  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W);
+  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W, epilogue == nullptr);   // the epilogue needs whole sums per workgroup
   const int bm = plan.bm, th = plan.th, tw = plan.tw, split = plan.split;
   p.tiles_x = plan.tiles_x; p.tiles_y = plan.tiles_y; p.tiles_m = plan.tiles_m;
   p.ci_per_split = plan.chunks_per * plan.ci_t;
@@ -412,7 +412,8 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);
   profile_bracket_begin(stream);
-  if (bm == 32) launch_conv3<32, 16>(p, th, tw, grid, stream);
+  if (bm == 32 && plan.ci_t == 16) launch_conv3<32, 16>(p, th, tw, grid, stream);
+  else if (bm == 32) launch_conv3<32, 8>(p, th, tw, grid, stream);
   else if (bm == 64) launch_conv3<64, 8>(p, th, tw, grid, stream);
   else launch_conv3<128, 4>(p, 4, tw, grid, stream);
   if (p.epi_partial)
