@@ -332,7 +332,8 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
   static const int bm_cap = getenv("SRGAN_CONV3_BM") ? atoi(getenv("SRGAN_CONV3_BM")) : 64;   // 64 rows: +0.4 % in-step over 128
   int bm = CO > 64 ? 128 : (CO > 32 ? 64 : 32);
   if (bm > bm_cap) bm = bm_cap;
-  int th = (bm == 128 || tw == 16) ? 4 : 8;   // 128 rows / 16-wide tiles always use 4 column blocks per workgroup
+  static const int th_cap = getenv("SRGAN_CONV3_TH") ? atoi(getenv("SRGAN_CONV3_TH")) : 8;
+  int th = (bm == 128 || tw == 16 || th_cap < 8) ? 4 : 8;   // 128 rows / 16-wide tiles always use 4 column blocks per workgroup
   auto rows = [&](int th_) { return th_ * (32 / tw); };
   auto count = [&](int bm_, int th_) {
     return (int64_t)N * ((H + rows(th_) - 1) / rows(th_)) * plan.tiles_x * ((CO + bm_ - 1) / bm_);
@@ -344,7 +345,8 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
   }
   plan.bm = bm; plan.th = th;
   static const int ci_t32 = getenv("SRGAN_CONV3_CIT32") ? atoi(getenv("SRGAN_CONV3_CIT32")) : 8;
-  plan.ci_t = bm == 128 ? 4 : (bm == 64 ? 8 : ci_t32);     // keeps the staged registers + accumulators <= 256
+  static const int ci_t64 = getenv("SRGAN_CONV3_CIT64") ? atoi(getenv("SRGAN_CONV3_CIT64")) : 4;
+  plan.ci_t = bm == 128 ? 4 : (bm == 64 ? ci_t64 : ci_t32);     // keeps the staged registers + accumulators <= 256
   plan.tiles_m = (CO + bm - 1) / bm;
   plan.tiles_y = (H + rows(th) - 1) / rows(th);
   plan.blocks = count(bm, th);
@@ -414,7 +416,8 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   profile_bracket_begin(stream);
   if (bm == 32 && plan.ci_t == 16) launch_conv3<32, 16>(p, th, tw, grid, stream);
   else if (bm == 32) launch_conv3<32, 8>(p, th, tw, grid, stream);
-  else if (bm == 64) launch_conv3<64, 8>(p, th, tw, grid, stream);
+  else if (bm == 64 && plan.ci_t == 8) launch_conv3<64, 8>(p, th, tw, grid, stream);
+  else if (bm == 64) launch_conv3<64, 4>(p, th, tw, grid, stream);
   else launch_conv3<128, 4>(p, 4, tw, grid, stream);
   if (p.epi_partial)
     bn_partial_reduce_run(p.epi_partial, p.epi_tiles, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
