@@ -42,8 +42,9 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
   constexpr int GT = TH * WG3_TW;           // gy tile of one channel
   constexpr int GS = GT | 1;
   static_assert(PH * 32 <= WG3_THREADS, "one (patch row, channel) pair per thread");
-  constexpr int OUT_ROW = WG3_CI * 9 + 1;   // epilogue transpose buffer: [co][ci*9 + tap], odd row stride
-  constexpr int SMEM = WG3_CI * PS + WG3_CO * GS > WG3_CO * OUT_ROW ? WG3_CI * PS + WG3_CO * GS : WG3_CO * OUT_ROW;
+  constexpr int OUT_ROW = WG3_CI * 9 + 1;   // epilogue transpose buffer: [co][ci*9 + tap], odd row stride; the 32 output
+  constexpr int OUT_HALF = WG3_CO / 2;      // rows go through it in two halves so that it fits under the staging tiles
+  constexpr int SMEM = WG3_CI * PS + WG3_CO * GS > OUT_HALF * OUT_ROW ? WG3_CI * PS + WG3_CO * GS : OUT_HALF * OUT_ROW;
   __shared__ float smem[SMEM];
   float* xs = smem;
   float* gs = smem + WG3_CI * PS;
@@ -172,19 +173,23 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
   // lane: measured 630 us per launch), so the 32 x 288 block is transposed through LDS and the atomics go out with
   // lanes along the contiguous (ci, tap) run of each output-channel row.
   if (p.debug & 1) return;
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) smem[co * OUT_ROW + l31 * 9 + kh * 3 + kw] = acc[kw][r];
-  }
-  __syncthreads();
   const int run = min(WG3_CI, p.CI - ci0) * 9;       // valid floats of each row
-  for (int idx = tid; idx < WG3_CO * WG3_CI * 9; idx += WG3_THREADS) {
-    const int co = idx / (WG3_CI * 9), within = idx - co * (WG3_CI * 9);
-    if (co0 + co < p.CO && within < run)
-      unsafeAtomicAdd(p.gw + ((int64_t)(co0 + co) * p.CI + ci0) * 9 + within, smem[co * OUT_ROW + within]);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {             // rows 16 * half ... : accumulator registers 8 * half ...
+    __syncthreads();
+#pragma unroll
+    for (int r = 8 * half; r < 8 * half + 8; ++r) {
+      const int co = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;          // row within the half
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) smem[co * OUT_ROW + l31 * 9 + kh * 3 + kw] = acc[kw][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < OUT_HALF * WG3_CI * 9; idx += WG3_THREADS) {
+      const int co = idx / (WG3_CI * 9), within = idx - co * (WG3_CI * 9);
+      const int row = co0 + OUT_HALF * half + co;
+      if (row < p.CO && within < run)
+        unsafeAtomicAdd(p.gw + ((int64_t)row * p.CI + ci0) * 9 + within, smem[co * OUT_ROW + within]);
+    }
   }
 }
 
@@ -216,9 +221,9 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
                 "conv3x3 wgrad 16-byte rows");
   SRGAN_REQUIRE(tiles < (int64_t)1 << 31 && ci_chunks <= 65535 && co_chunks <= 65535, SRGAN_ERANGE, "conv3x3 wgrad grid");
   p.tiles = (int)tiles;
-  // Walkers: four resident 3-wave workgroups per CU (LDS-bound) over the whole grid, and at least `depth` tiles per
+  // Walkers: five resident 3-wave workgroups per CU (120 VGPRs, 22 KB of LDS) over the whole grid, and at least `depth` tiles per
   // walker so that the atomic pass (32 x 288 floats per workgroup) is amortised.
-  static const int resident = getenv("SRGAN_WGRAD3_WGS") ? atoi(getenv("SRGAN_WGRAD3_WGS")) : 1024;
+  static const int resident = getenv("SRGAN_WGRAD3_WGS") ? atoi(getenv("SRGAN_WGRAD3_WGS")) : 1280;
   static const int depth_override = getenv("SRGAN_WGRAD3_DEPTH") ? atoi(getenv("SRGAN_WGRAD3_DEPTH")) : 0;
   // measured on 128 -> 32 channels, batch 16: 64x64 images best at 8 tiles per walker, 32x32 at 4, 16x16 at 1 (batch
   // 48 at 16x16 = 192 tiles: 48 us at depth 1 -- 768 workgroups x 9216 atomics -- so 4 from 128 tiles up)
