@@ -469,7 +469,8 @@ static GGConfig choose_config(const GatherGemm& p, int force) {
     c.tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     return c;
   }
-  for (int i = 0; i < 3; ++i) {
+  static const int first = getenv("SRGAN_GG_FIRST_TILE") ? atoi(getenv("SRGAN_GG_FIRST_TILE")) : 0;
+  for (int i = first; i < 3; ++i) {
     c.bm = candidates[cls][i][0];
     c.bn = candidates[cls][i][1];
     c.tiles = ((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
