@@ -1,75 +1,75 @@
 """DCGAN generator / discriminator on HIP kernels (surface of reference age/models.py:32-80, identical to
-driving/models.py and, for the generator, crowd/models.py:127-147).  ``image_size`` may be an (H, W) pair
-for the rectangular driving frames; a square int is the reference graph."""
+driving/models.py and, for the generator, crowd/models.py:127-147): same module names, construction order (hence the same
+initial weights from ``seed_all(0)``) and ``state_dict`` keys.  ``image_size`` may be an (H, W) pair for the rectangular
+driving frames; a square int is the reference graph."""
 from .. import functional as F
 from .. import nn
 from ..utility import seed_all
 
-batch_norm = False
+batch_norm = False            # the reference's module-level switch (age/models.py:13): no batch-norm anywhere
+LEAK = 0.05
 
 
 def _pair(value):
     return (value, value) if isinstance(value, int) else tuple(value)
 
 
+def _stage(layer_class, c_in, c_out, k_size, stride, pad, bn):
+    """``Sequential(layer[, BatchNorm2d])`` -- the reference wraps every layer like this, so keys read ``layerN.0.weight``."""
+    return nn.Sequential(*([layer_class(c_in, c_out, k_size, stride, pad)] + ([nn.BatchNorm2d(c_out)] if bn else [])))
+
+
 def transpose_convolution(c_in, c_out, k_size, stride=2, pad=1, bn=batch_norm):
-    layers = [nn.ConvTranspose2d(c_in, c_out, k_size, stride, pad)]
-    if bn:
-        layers.append(nn.BatchNorm2d(c_out))
-    return nn.Sequential(*layers)
+    return _stage(nn.ConvTranspose2d, c_in, c_out, k_size, stride, pad, bn)
 
 
 def convolution(c_in, c_out, k_size, stride=2, pad=1, bn=batch_norm):
-    layers = [nn.Conv2d(c_in, c_out, k_size, stride, pad)]
-    if bn:
-        layers.append(nn.BatchNorm2d(c_out))
-    return nn.Sequential(*layers)
+    return _stage(nn.Conv2d, c_in, c_out, k_size, stride, pad, bn)
+
+
+def _seed_kernel(image_size):
+    height, width = _pair(image_size)
+    return int(height / 16), int(width / 16)      # four stride-2 stages between the 1x1 code and the image
 
 
 class Generator(nn.Module):
-    """z -> convT(k = S/16) -> 3x [convT k4 s2 p1, leaky 0.05] -> convT k4 s2 p1 -> tanh."""
+    """z -> ``fc``: convT(k = S/16) -> ``layer1..3``: convT k4 s2 p1 + leaky 0.05 -> ``layer4``: convT k4 s2 p1 -> tanh."""
 
     def __init__(self, z_dim=256, image_size=128, conv_dim=64):
         seed_all(0)
         super().__init__()
-        height, width = _pair(image_size)
-        self.fc = transpose_convolution(z_dim, conv_dim * 8, (int(height / 16), int(width / 16)), 1, 0, bn=False)
-        self.layer1 = transpose_convolution(conv_dim * 8, conv_dim * 4, 4)
-        self.layer2 = transpose_convolution(conv_dim * 4, conv_dim * 2, 4)
-        self.layer3 = transpose_convolution(conv_dim * 2, conv_dim, 4)
-        self.layer4 = transpose_convolution(conv_dim, 3, 4, bn=False)
+        widths = (conv_dim * 8, conv_dim * 4, conv_dim * 2, conv_dim, 3)
+        self.fc = transpose_convolution(z_dim, widths[0], _seed_kernel(image_size), 1, 0, bn=False)
+        for index in range(1, 5):
+            setattr(self, f'layer{index}', transpose_convolution(widths[index - 1], widths[index], 4,
+                                                                 **({'bn': False} if index == 4 else {})))
         self.input_size = z_dim
 
     def forward(self, z):
         out = self.fc(F.view(z, (z.shape[0], z.shape[1], 1, 1)))
-        out = F.leaky_relu(self.layer1(out), 0.05)
-        out = F.leaky_relu(self.layer2(out), 0.05)
-        out = F.leaky_relu(self.layer3(out), 0.05)
+        for stage in (self.layer1, self.layer2, self.layer3):
+            out = F.leaky_relu(stage(out), LEAK)
         return F.tanh(self.layer4(out))
 
 
 class Discriminator(nn.Module):
-    """4x [conv k4 s2 p1, leaky 0.05]; ``features`` = flattened activations; conv k = S/16 -> outputs."""
+    """``layer1..4``: conv k4 s2 p1 + leaky 0.05; ``features`` = the flattened result; ``layer5``: conv k = S/16 -> outputs."""
 
     def __init__(self, image_size=128, conv_dim=64, number_of_outputs=1):
         seed_all(0)
         super().__init__()
-        height, width = _pair(image_size)
         self.number_of_outputs = number_of_outputs
-        self.layer1 = convolution(3, conv_dim, 4, bn=False)
-        self.layer2 = convolution(conv_dim, conv_dim * 2, 4)
-        self.layer3 = convolution(conv_dim * 2, conv_dim * 4, 4)
-        self.layer4 = convolution(conv_dim * 4, conv_dim * 8, 4)
-        self.layer5 = convolution(conv_dim * 8, number_of_outputs, (int(height / 16), int(width / 16)), 1, 0, False)
+        widths = (3, conv_dim, conv_dim * 2, conv_dim * 4, conv_dim * 8)
+        for index in range(1, 5):
+            setattr(self, f'layer{index}', convolution(widths[index - 1], widths[index], 4,
+                                                       **({'bn': False} if index == 1 else {})))
+        self.layer5 = convolution(widths[4], number_of_outputs, _seed_kernel(image_size), 1, 0, False)
         self.features = None
 
     def forward(self, x):
-        out = F.leaky_relu(self.layer1(x), 0.05)
-        out = F.leaky_relu(self.layer2(out), 0.05)
-        out = F.leaky_relu(self.layer3(out), 0.05)
-        out = F.leaky_relu(self.layer4(out), 0.05)
+        out = x
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            out = F.leaky_relu(stage(out), LEAK)
         self.features = F.flatten2d(out)
-        out = self.layer5(out)
-        if self.number_of_outputs == 1:
-            return F.view(out, (-1,))
-        return F.view(out, (-1, self.number_of_outputs))
+        scores = self.layer5(out)
+        return F.view(scores, (-1,) if self.number_of_outputs == 1 else (-1, self.number_of_outputs))

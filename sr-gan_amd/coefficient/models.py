@@ -1,48 +1,53 @@
-"""Coefficient-task networks on HIP kernels (surface of reference coefficient/models.py:12-93)."""
+"""Coefficient-task networks on HIP kernels (surface of reference coefficient/models.py:12-93): four-layer perceptrons
+whose module names (``linear1`` .. ``linear4``), construction order and ``state_dict`` keys are the reference's."""
 from .. import functional as F
 from .. import nn
 from ..utility import seed_all
 
 observation_count = 10
 irrelevant_data_multiplier = 5
+EXAMPLE_WIDTH = observation_count * irrelevant_data_multiplier          # 50 numbers per example
 
 
-class Generator(nn.Module):
-    """10 -> h -> h -> h -> 50, leaky_relu 0.01 (reference coefficient/models.py:12-28; no reseed)."""
+class _Perceptron(nn.Module):
+    """width_in -> h -> h -> h -> width_out with leaky_relu(0.01) between; ``hidden(x)`` is the third hidden layer."""
+
+    def _build(self, width_in, hidden_size, width_out):
+        widths = (width_in, hidden_size, hidden_size, hidden_size, width_out)
+        for index in range(4):
+            setattr(self, f'linear{index + 1}', nn.Linear(widths[index], widths[index + 1]))
+
+    def hidden(self, x):
+        for layer in (self.linear1, self.linear2, self.linear3):
+            x = F.leaky_relu(layer(x))
+        return x
+
+
+class Generator(_Perceptron):
+    """z[10] -> example[50] (reference coefficient/models.py:12-28; the only network that does not reseed)."""
 
     def __init__(self, hidden_size=10):
         super().__init__()
         self.input_size = 10
-        self.linear1 = nn.Linear(self.input_size, hidden_size)
-        self.linear2 = nn.Linear(hidden_size, hidden_size)
-        self.linear3 = nn.Linear(hidden_size, hidden_size)
-        self.linear4 = nn.Linear(hidden_size, observation_count * irrelevant_data_multiplier)
+        self._build(self.input_size, hidden_size, EXAMPLE_WIDTH)
 
     def forward(self, z, add_noise=False):
-        h = F.leaky_relu(self.linear1(z))
-        h = F.leaky_relu(self.linear2(h))
-        h = F.leaky_relu(self.linear3(h))
-        return self.linear4(h)
+        return self.linear4(self.hidden(z))
 
 
-class MLP(nn.Module):
-    """50 -> h -> h -> h -> 1; ``features`` is the third hidden activation (reference
-    coefficient/models.py:31-50)."""
+class MLP(_Perceptron):
+    """example[50] -> value; ``features`` = the third hidden activation (reference coefficient/models.py:31-50).
+    A single output is squeezed to shape (B)."""
 
     def __init__(self, hidden_size=10, outputs=1, tap_features=True):
         super().__init__()
         seed_all(0)
-        self.linear1 = nn.Linear(observation_count * irrelevant_data_multiplier, hidden_size)
-        self.linear2 = nn.Linear(hidden_size, hidden_size)
-        self.linear3 = nn.Linear(hidden_size, hidden_size)
-        self.linear4 = nn.Linear(hidden_size, outputs)
+        self._build(EXAMPLE_WIDTH, hidden_size, outputs)
         self.tap_features = tap_features
         self.features = None
 
     def forward(self, x):
-        h = F.leaky_relu(self.linear1(x))
-        h = F.leaky_relu(self.linear2(h))
-        h = F.leaky_relu(self.linear3(h))
+        h = self.hidden(x)
         if self.tap_features:
             self.features = h
         out = self.linear4(h)
@@ -50,20 +55,20 @@ class MLP(nn.Module):
 
 
 class DgganMLP(MLP):
-    """50 -> h -> h -> h -> 2: (predicted value, real/fake score) per example (reference coefficient/models.py:53-72)."""
+    """example[50] -> (value, real/fake score), each of shape (B) (reference coefficient/models.py:53-72)."""
 
     def __init__(self, hidden_size=10):
         super().__init__(hidden_size, outputs=2)
 
     def forward(self, x):
         out = super().forward(x)                                   # [B, 2]
-        columns = F.view(out, (out.shape[0], 2, 1, 1))
-        return (F.view(F.slice_channels(columns, 0, 1), (out.shape[0],)),
-                F.view(F.slice_channels(columns, 1, 2), (out.shape[0],)))
+        batch = out.shape[0]
+        columns = F.view(out, (batch, 2, 1, 1))
+        return tuple(F.view(F.slice_channels(columns, column, column + 1), (batch,)) for column in (0, 1))
 
 
 class SganMLP(MLP):
-    """50 -> 100 -> 100 -> 100 -> bins, no feature tap (reference coefficient/models.py:75-93)."""
+    """example[50] -> bin logits through 100-wide layers, no feature tap (reference coefficient/models.py:75-93)."""
 
     def __init__(self, number_of_bins=10):
         super().__init__(hidden_size=100, outputs=number_of_bins, tap_features=False)

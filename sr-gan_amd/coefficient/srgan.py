@@ -15,17 +15,20 @@ class CoefficientExperiment(Experiment):
     """The coefficient application."""
 
     def dataset_setup(self):
+        """Labeled / unlabeled / validation toy datasets with the reference's seeds (labeled: the settings' seed, unlabeled
+        100, validation 101; reference coefficient/srgan.py:20-33); the two training sets are shuffled each epoch."""
         settings = self.settings
-        self.train_dataset = ToyDataset(dataset_size=settings.labeled_dataset_size, observation_count=observation_count,
-                                        settings=settings, seed=settings.labeled_dataset_seed)
-        self.train_dataset_loader = DataLoader(self.train_dataset, batch_size=settings.batch_size, shuffle=True,
-                                               pin_memory=settings.pin_memory)
-        self.unlabeled_dataset = ToyDataset(dataset_size=settings.unlabeled_dataset_size,
-                                            observation_count=observation_count, settings=settings, seed=100)
-        self.unlabeled_dataset_loader = DataLoader(self.unlabeled_dataset, batch_size=settings.batch_size,
-                                                   shuffle=True, pin_memory=settings.pin_memory)
-        self.validation_dataset = ToyDataset(settings.validation_dataset_size, observation_count, seed=101,
-                                             settings=settings)
+
+        def toy(size, seed):
+            return ToyDataset(dataset_size=size, observation_count=observation_count, settings=settings, seed=seed)
+
+        def shuffled(dataset):
+            return DataLoader(dataset, batch_size=settings.batch_size, shuffle=True, pin_memory=settings.pin_memory)
+        self.train_dataset = toy(settings.labeled_dataset_size, settings.labeled_dataset_seed)
+        self.train_dataset_loader = shuffled(self.train_dataset)
+        self.unlabeled_dataset = toy(settings.unlabeled_dataset_size, 100)
+        self.unlabeled_dataset_loader = shuffled(self.unlabeled_dataset)
+        self.validation_dataset = toy(settings.validation_dataset_size, 101)
 
     def model_setup(self):
         self.DNN = MLP(self.settings.hidden_size)
@@ -46,14 +49,15 @@ class CoefficientExperiment(Experiment):
     def evaluation_epoch(self, network, dataset, summary_writer, summary_name, comparison_values=None):
         with no_grad():
             predicted = network(as_var(torch.from_numpy(dataset.examples.astype(np.float32)))).cpu().numpy()
-        mae = float(np.mean(np.abs(predicted - dataset.labels)))
-        mse = float(np.mean(np.power(predicted - dataset.labels, 2)))
-        rmse = mse ** 0.5
-        summary_writer.add_scalar(f'{summary_name}/MAE', mae)
-        summary_writer.add_scalar(f'{summary_name}/MSE', mse)
-        summary_writer.add_scalar(f'{summary_name}/RMSE', rmse)
+        errors = predicted - dataset.labels
+        values = dict(mae=float(np.mean(np.abs(errors))), mse=float(np.mean(np.power(errors, 2))))
+        values['rmse'] = values['mse'] ** 0.5
+        for key, value in values.items():
+            summary_writer.add_scalar(f'{summary_name}/{key.upper()}', value)
         if comparison_values:
-            summary_writer.add_scalar(f'{summary_name}/Ratio MAE GAN DNN', mae / comparison_values['mae'])
-            summary_writer.add_scalar(f'{summary_name}/Ratio MSE GAN DNN', mae / comparison_values['mse'])
-            summary_writer.add_scalar(f'{summary_name}/Ratio RMSE GAN DNN', rmse / comparison_values['rmse'])
-        return dict(mae=mae, mse=mse, rmse=rmse, predicted_labels=predicted)
+            # (the reference's "Ratio MSE" divides the MAE by the DNN's MSE, coefficient/srgan.py:96; kept as it logs it)
+            for key, numerator in (('mae', 'mae'), ('mse', 'mae'), ('rmse', 'rmse')):
+                summary_writer.add_scalar(f'{summary_name}/Ratio {key.upper()} GAN DNN',
+                                          values[numerator] / comparison_values[key])
+        values['predicted_labels'] = predicted
+        return values

@@ -20,57 +20,48 @@ from .settings import Settings, convert_to_settings_list, ApplicationName, Metho
 from .utility import seed_all, clean_scientific_notation, abs_plus_one_sqrt_mean_neg, abs_mean
 
 
+# Which experiment class runs an (application, method) pair, and the hyper-parameters each application overrides
+# (reference run.py:28-70).  List values are grid axes (see settings.convert_to_settings_list).
+EXPERIMENTS = {
+    ApplicationName.age: {MethodName.srgan: AgeExperiment, MethodName.sgan: AgeSganExperiment},
+    ApplicationName.driving: {method: DrivingExperiment for method in MethodName},
+    ApplicationName.coefficient: {MethodName.srgan: CoefficientExperiment, MethodName.sgan: CoefficientSganExperiment,
+                                  MethodName.dggan: CoefficientDgganExperiment},
+    ApplicationName.crowd: {MethodName.srgan: CrowdExperiment, MethodName.dnn: CrowdDnnExperiment,
+                            MethodName.dggan: CrowdDgganExperiment},
+}
+APPLICATION_SETTINGS = {
+    ApplicationName.age: dict(matching_loss_multiplier=[1e2], contrasting_loss_multiplier=[1e1], batch_size=600,
+                              unlabeled_dataset_size=50000, labeled_dataset_size=[5000],
+                              gradient_penalty_multiplier=1e2),
+    ApplicationName.driving: dict(matching_loss_multiplier=[1e2], contrasting_loss_multiplier=[1e1], batch_size=600,
+                                  unlabeled_dataset_size=None, labeled_dataset_size=[100], validation_dataset_size=9000,
+                                  gradient_penalty_multiplier=1e2),
+    ApplicationName.coefficient: dict(matching_loss_multiplier=[1e-1, 1e0, 1e1],
+                                      contrasting_loss_multiplier=[1e-1, 1e0, 1e1], batch_size=5000,
+                                      unlabeled_dataset_size=50000, labeled_dataset_size=[500],
+                                      gradient_penalty_multiplier=1e1),
+    ApplicationName.crowd: dict(matching_loss_multiplier=[1e3], contrasting_loss_multiplier=[1e2], batch_size=15,
+                                labeled_loss_order=2, unlabeled_dataset_size=None, labeled_dataset_size=50,
+                                gradient_penalty_multiplier=1e2, map_directory_name=['density3e-1'],
+                                map_multiplier=1e-3),
+}
+COMMON_SETTINGS = dict(summary_step_period=5000, labeled_dataset_seed=0, learning_rate=[1e-4],
+                       contrasting_distance_function=abs_plus_one_sqrt_mean_neg, matching_distance_function=abs_mean,
+                       continue_existing_experiments=False, save_step_period=20000)
+
+
 def build_settings(application_name, method_name):
-    settings_ = Settings()
-    if application_name == ApplicationName.age:
-        experiment_class = {MethodName.srgan: AgeExperiment, MethodName.sgan: AgeSganExperiment}[method_name]
-        settings_.matching_loss_multiplier = [1e2]
-        settings_.contrasting_loss_multiplier = [1e1]
-        settings_.batch_size = 600
-        settings_.unlabeled_dataset_size = 50000
-        settings_.labeled_dataset_size = [5000]
-        settings_.gradient_penalty_multiplier = 1e2
-    elif application_name == ApplicationName.driving:
-        experiment_class = DrivingExperiment
-        settings_.matching_loss_multiplier = [1e2]
-        settings_.contrasting_loss_multiplier = [1e1]
-        settings_.batch_size = 600
-        settings_.unlabeled_dataset_size = None
-        settings_.labeled_dataset_size = [100]
-        settings_.validation_dataset_size = 9000
-        settings_.gradient_penalty_multiplier = 1e2
-    elif application_name == ApplicationName.coefficient:
-        experiment_class = {MethodName.srgan: CoefficientExperiment,
-                            MethodName.sgan: CoefficientSganExperiment,
-                            MethodName.dggan: CoefficientDgganExperiment}[method_name]
-        settings_.matching_loss_multiplier = [1e-1, 1e0, 1e1]
-        settings_.contrasting_loss_multiplier = [1e-1, 1e0, 1e1]
-        settings_.batch_size = 5000
-        settings_.unlabeled_dataset_size = 50000
-        settings_.labeled_dataset_size = [500]
-        settings_.gradient_penalty_multiplier = 1e1
-    elif application_name == ApplicationName.crowd:
-        experiment_class = {MethodName.srgan: CrowdExperiment, MethodName.dnn: CrowdDnnExperiment,
-                            MethodName.dggan: CrowdDgganExperiment}[method_name]
-        settings_.matching_loss_multiplier = [1e3]
-        settings_.contrasting_loss_multiplier = [1e2]
-        settings_.batch_size = 15
-        settings_.labeled_loss_order = 2
-        settings_.unlabeled_dataset_size = None
-        settings_.labeled_dataset_size = 50
-        settings_.gradient_penalty_multiplier = 1e2
-        settings_.map_directory_name = ['density3e-1']
-        settings_.map_multiplier = 1e-3
-    else:
+    """(experiment class, Settings) of one application / method pair; application values first, then the common ones,
+    as in the reference (a later assignment wins)."""
+    if application_name not in APPLICATION_SETTINGS:
         raise ValueError(f'{application_name} is not an available application.')
-    settings_.summary_step_period = 5000
-    settings_.labeled_dataset_seed = 0
-    settings_.steps_to_run = int(os.environ.get('SRGAN_STEPS', 100000))
-    settings_.learning_rate = [1e-4]
-    settings_.contrasting_distance_function = abs_plus_one_sqrt_mean_neg
-    settings_.matching_distance_function = abs_mean
-    settings_.continue_existing_experiments = False
-    settings_.save_step_period = 20000
+    experiment_class = EXPERIMENTS[application_name][method_name]
+    settings_ = Settings()
+    overrides = dict(APPLICATION_SETTINGS[application_name], **COMMON_SETTINGS)
+    overrides['steps_to_run'] = int(os.environ.get('SRGAN_STEPS', 100000))
+    for name, value in overrides.items():
+        setattr(settings_, name, value)
     settings_.local_setup()
     return experiment_class, settings_
 

@@ -116,15 +116,43 @@ class Experiment(ABC):
         if settings.should_save_models:
             self.save_models(step=settings.steps_to_run)
 
+    # (network attribute, optimizer attribute): also the keys of the checkpoint dictionary (reference srgan.py:88-97)
+    CHECKPOINT_PARTS = (('DNN', 'dnn_optimizer'), ('D', 'd_optimizer'), ('G', 'g_optimizer'))
+
     def save_models(self, step):
         """One torch.save dict with the reference's keys (srgan.py:88-97); written by rank 0 only."""
         self.join_dnn_stream()
         if self.dp is not None and self.dp.rank != 0:
             return
-        model = {'DNN': self.DNN.state_dict(), 'dnn_optimizer': self.dnn_optimizer.state_dict(),
-                 'D': self.D.state_dict(), 'd_optimizer': self.d_optimizer.state_dict(),
-                 'G': self.G.state_dict(), 'g_optimizer': self.g_optimizer.state_dict(), 'step': step}
+        model = {'step': step}
+        for network, optimizer in self.CHECKPOINT_PARTS:
+            model[network] = getattr(self, network).state_dict()
+            model[optimizer] = getattr(self, optimizer).state_dict()
         torch.save(model, os.path.join(self.trial_directory, f'model_{step}.pth'))
+
+    @staticmethod
+    def unpack_labeled(samples):
+        """(examples, labels) of a labeled batch; a third element is a secondary label (the crowd maps)."""
+        if len(samples) == 2:
+            return as_var(samples[0]), as_var(samples[1])
+        examples, primary_labels, secondary_labels = samples
+        return as_var(examples), as_var((primary_labels, secondary_labels))
+
+    def end_of_step(self, step, summary_writer, step_time_start):
+        """Periodic validation summaries, the stdin commands and periodic checkpoints (reference srgan.py:120-129);
+        returns the time stamp the next progress line is measured from."""
+        if summary_writer.is_summary_step() or step == self.settings.steps_to_run - 1:
+            print('\rStep {}, {}...'.format(step, datetime.datetime.now() - step_time_start), end='')
+            step_time_start = datetime.datetime.now()
+            self.join_dnn_stream()
+            self.eval_mode()
+            with no_grad():
+                self.validation_summaries(step)
+            self.train_mode()
+        self.handle_user_input(step)
+        if self.settings.save_step_period and step % self.settings.save_step_period == 0 and step != 0:
+            self.save_models(step=step)
+        return step_time_start
 
     def training_loop(self):
         """The per-step hot loop (reference srgan.py:99-129)."""
@@ -133,27 +161,11 @@ class Experiment(ABC):
         step_time_start = datetime.datetime.now()
         for step in range(self.starting_step, self.settings.steps_to_run):
             self.adjust_learning_rate(step)
-            samples = next(train_dataset_generator)
-            if len(samples) == 2:
-                labeled_examples, labels = samples
-            else:
-                labeled_examples, primary_labels, secondary_labels = samples
-                labels = (primary_labels, secondary_labels)
-            labeled_examples, labels = as_var(labeled_examples), as_var(labels)
+            labeled_examples, labels = self.unpack_labeled(next(train_dataset_generator))
             self.dnn_training_step(labeled_examples, labels, step)
             unlabeled_examples = as_var(next(unlabeled_dataset_generator)[0])
             self.gan_training_step(labeled_examples, labels, unlabeled_examples, step)
-
-            if self.gan_summary_writer.is_summary_step() or step == self.settings.steps_to_run - 1:
-                print('\rStep {}, {}...'.format(step, datetime.datetime.now() - step_time_start), end='')
-                step_time_start = datetime.datetime.now()
-                self.eval_mode()
-                with no_grad():
-                    self.validation_summaries(step)
-                self.train_mode()
-            self.handle_user_input(step)
-            if self.settings.save_step_period and step % self.settings.save_step_period == 0 and step != 0:
-                self.save_models(step=step)
+            step_time_start = self.end_of_step(step, self.gan_summary_writer, step_time_start)
 
     def prepare_optimizers(self):
         """Adam for D (with coupled L2), G and DNN (reference srgan.py:131-138) on the flat arenas."""
@@ -221,26 +233,28 @@ class Experiment(ABC):
             return model_path2
         return model_path1 if int(model_path1.group(1)) > int(model_path2.group(1)) else model_path2
 
-    def load_models(self, with_optimizers=True):
-        """Loads the latest ``model_<step>.pth`` from ``settings.load_model_path`` (reference srgan.py:221-251)."""
-        if not self.settings.load_model_path:
-            return
+    def latest_checkpoint_path(self):
+        """The ``model[_<step>].pth`` with the highest step in ``settings.load_model_path`` (None if there is none)."""
         latest_model = None
         for file_name in os.listdir(self.settings.load_model_path):
             match = re.search(r'model_?(\d+)?\.pth', file_name)
             if match:
                 latest_model = self.compare_model_path_for_latest(latest_model, match)
-        if latest_model is None:
+        return os.path.join(self.settings.load_model_path, latest_model.group(0)) if latest_model else None
+
+    def load_models(self, with_optimizers=True):
+        """Loads the latest checkpoint of ``settings.load_model_path`` (reference srgan.py:221-251)."""
+        if not self.settings.load_model_path:
             return
-        model_path = os.path.join(self.settings.load_model_path, latest_model.group(0))
+        model_path = self.latest_checkpoint_path()
+        if model_path is None:
+            return
         loaded_model = torch.load(model_path, map_location='cpu')
-        self.DNN.load_state_dict(loaded_model['DNN'])
-        self.D.load_state_dict(loaded_model['D'])
-        self.G.load_state_dict(loaded_model['G'])
+        for network, optimizer in self.CHECKPOINT_PARTS:
+            getattr(self, network).load_state_dict(loaded_model[network])
         if with_optimizers:
-            self.dnn_optimizer.load_state_dict(loaded_model['dnn_optimizer'])
-            self.d_optimizer.load_state_dict(loaded_model['d_optimizer'])
-            self.g_optimizer.load_state_dict(loaded_model['g_optimizer'])
+            for network, optimizer in self.CHECKPOINT_PARTS:
+                getattr(self, optimizer).load_state_dict(loaded_model[optimizer])
         print('Model loaded from `{}`.'.format(model_path))
         if self.settings.continue_existing_experiments:
             self.starting_step = loaded_model['step'] + 1

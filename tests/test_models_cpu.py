@@ -26,3 +26,19 @@ def test_crowd_dggan_networks_initialise_like_the_reference():
         for name, parameter in module.named_parameters():
             assert_close(checksum(parameter), g[f'{prefix}/{name}'], rtol=1e-9, atol=1e-12, what=f'{prefix} {name}')
     assert discriminator.count_layer.weight.shape[0] == 2 and discriminator.map_module1.count_layer.weight.shape[0] == 2
+
+
+def test_product_toy_dataset_reproduces_the_reference_draws():
+    """coefficient/data.py: the same seed gives the reference's dataset bit for bit (golden g0); small datasets are tiled
+    up to the batch size."""
+    from types import SimpleNamespace
+    import numpy as np
+    import srgan_amd  # noqa: F401
+    from srgan_amd.coefficient.data import ToyDataset
+    g = load_golden('g0_toydata')
+    dataset = ToyDataset(int(g['size']), 10, SimpleNamespace(batch_size=1), seed=int(g['seed']))
+    np.testing.assert_array_equal(dataset.examples, g['examples'])
+    np.testing.assert_array_equal(dataset.labels, g['labels'])
+    example, label = dataset[3]
+    assert example.shape == (50,) and example.dtype == np.float32 and len(dataset) == int(g['size'])
+    assert len(ToyDataset(3, 10, SimpleNamespace(batch_size=7), seed=1)) == 6
