@@ -36,8 +36,12 @@ constexpr int PKS_MAX_K = 2048;           // PRO: (a, b) of every input channel 
 template <bool PRO>
 __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplitParams p) {
   constexpr int MI = PKS_MI, ROWS = MI * 32, LDR = 33;
-  __shared__ float red[4 * ROWS * LDR];
-  __shared__ float2 coef[PRO ? PKS_MAX_K : 1];
+  // One LDS block: the (a, b) table of the prologue during the K loop, the four partial tiles afterwards (a barrier
+  // separates the two uses) -- 34 KB instead of 50, i.e. four workgroups per CU instead of three.
+  constexpr int RED_FLOATS = 4 * ROWS * LDR, COEF_FLOATS = PRO ? 2 * PKS_MAX_K : 0;
+  __shared__ float smem[RED_FLOATS > COEF_FLOATS ? RED_FLOATS : COEF_FLOATS];
+  float* red = smem;
+  float2* coef = reinterpret_cast<float2*>(smem);
 
   const int tid = (int)threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
   }
 
   // ---- sum the four waves' partial tiles (C/D fragment: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5))
+  if (PRO) __syncthreads();                  // every wave is done with the coefficient table that `red` overlays
   float* mine = red + wave * (ROWS * LDR);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
