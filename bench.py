@@ -195,11 +195,27 @@ def cpu_baseline_child(image_size):
                       f'crowd {image_size}x{image_size}, batch {batch}, {elapsed:.1f} s'}
 
 
+def ensure_library():
+    """libsrgan_hip.so normally arrives prebuilt with the working tree; if it is missing, local rank 0 compiles it
+    (hipcc, ~30 s) and the other ranks wait for the file.  There is still no fallback: without it nothing runs."""
+    from srgan_amd import _build
+    if os.path.exists(_build.LIBRARY):
+        return
+    if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+        _build.build()
+        return
+    deadline = time.time() + 600
+    while not os.path.exists(_build.LIBRARY) and time.time() < deadline:
+        time.sleep(2)
+    time.sleep(2)          # (the linker writes the file in place: let it finish)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_child:
         print(json.dumps(cpu_baseline_child(args.image_size)))
         return
+    ensure_library()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         if args.gpus != 1:
