@@ -609,11 +609,13 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
                   int* plan_only_split = nullptr);
 int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 
-// 1x1 / stride 1 / unpadded on images whose pixel count is a multiple of 32: the register-streamed pointwise kernel.
+// 1x1 / stride 1 / unpadded: the register-streamed pointwise kernel (any plane size: an image's last 32-pixel group may
+// be ragged; planes of fewer than 32 pixels stay on the generic kernel).
 static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
   const int in_channels = out_channels == g.K ? g.C : g.K;     // forward: C -> K; data gradient: K -> C
-  return force == 0 && pointwise_enabled() && pointwise(g) && (g.H * g.W) % 32 == 0 && out_channels >= 8 &&
-         in_channels % 2 == 0;
+  static const bool ragged = getenv("SRGAN_PW_NO_RAGGED") == nullptr;
+  const bool plane_ok = (g.H * g.W) % 32 == 0 || (ragged && g.H * g.W >= 32);
+  return force == 0 && pointwise_enabled() && pointwise(g) && plane_ok && out_channels >= 8 && in_channels % 2 == 0;
 }
 
 // 3x3 / stride 1 / pad 1 with enough width to fill half of a 32-pixel MFMA column block: the LDS-halo kernel.
@@ -833,7 +835,7 @@ int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
     return (use_conv3x3(g, g.K, 0) && g.C <= 512) ? 1 : 0;
   }
   if (pass == 1) {
-    if (pointwise(g)) return use_pointwise(g, g.C, 0) ? 1 : 0;
+    if (pointwise(g)) return (use_pointwise(g, g.C, 0) && (g.H * g.W) % 4 == 0) ? 1 : 0;   // float4 rows in the epilogue
     return (use_conv3x3(g, g.C, 0) && conv3x3_epilogue_supported(g.N, g.K, g.C, g.H, g.W)) ? 1 : 0;
   }
   if (pass == 2) {

@@ -34,6 +34,7 @@ struct PointwiseParams {
   int32_t N, CI, CO, HW;
   int64_t in_bs, out_bs;
   int32_t w_so, w_si;
+  int32_t gpi;          // pixel groups (of 32 * NI) per image, the last one possibly ragged
   int32_t tiles_m;
   int32_t xcd_remap;    // grid.x is a multiple of 8 and tiles_m > 1: XCD-aware workgroup order
   int32_t m_base;       // first output row of this launch (a second launch covers a shorter remainder tile)
@@ -75,12 +76,14 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
   int bid = (int)blockIdx.x;
   if (p.xcd_remap) bid = (bid & 7) * ((int)gridDim.x >> 3) + (bid >> 3);
   const int tm = bid % p.tiles_m;
+  // Pixel groups never straddle images: an image has gpi = ceil(HW / (32 * NI)) groups, the last one ragged when HW is
+  // not a multiple of the group (14 x 14 and 7 x 7 planes of the 224-pixel configuration): its surplus lanes read a
+  // clamped address and are never stored.
   const int64_t group = (int64_t)(bid / p.tiles_m) * 4 + wave;           // this wave's NI adjacent 32-pixel groups
-  const int64_t pixel0 = group * (32 * NI);
-  const int64_t total = (int64_t)p.N * p.HW;
-  const bool live = pixel0 < total;                                     // whole groups only (HW % (32 * NI) == 0)
-  const int n = live ? (int)(pixel0 / p.HW) : 0;
-  const int pix0 = live ? (int)(pixel0 - (int64_t)n * p.HW) : 0;
+  const int64_t total = (int64_t)p.N * p.gpi;                           // groups in the whole batch
+  const bool live = group < total;
+  const int n = live ? (int)(group / p.gpi) : 0;
+  const int pix0 = live ? (int)(group - (int64_t)n * p.gpi) * (32 * NI) : 0;
   const int pix = pix0 + l31;
   const int m0 = p.m_base + tm * BM;
   const int kbeg = (int)blockIdx.y * p.k_per_split;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
   // (pixel, and one image plane for the odd channel of the pair).  CI is even (checked by the caller), so a pair is
   // clamped as a whole.
   const float* b_wave = p.in + (int64_t)n * p.in_bs + pix0;
-  const uint32_t lane_off = (uint32_t)l31 + (uint32_t)lhi * (uint32_t)p.HW;
+  const uint32_t lane_off = (uint32_t)(min(pix0 + l31, p.HW - 1) - pix0) + (uint32_t)lhi * (uint32_t)p.HW;
 
   // A staging coordinates: lanes walk the weight's contiguous direction.
   const bool k_contiguous = p.w_si == 1;
@@ -233,10 +236,11 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     __syncthreads();
     constexpr int RPT = BM / 8;                    // rows per thread: row = (tid >> 5) + 8 * e
     const int half = tid >> 5, q4 = (tid & 31) * 4;
-    const int64_t my_pixel0 = ((int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5)) * 32;       // this lane's 32-pixel group
-    const bool my_live = my_pixel0 < total;
-    const int my_n = my_live ? (int)(my_pixel0 / p.HW) : 0;
-    const int my_pix = (my_live ? (int)(my_pixel0 - (int64_t)my_n * p.HW) : 0) + (q4 & 31);
+    const int64_t my_group = (int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5);               // this lane's 32-pixel group
+    const int my_n = my_group < total ? (int)(my_group / p.gpi) : 0;
+    const int my_start = my_group < total ? (int)(my_group - (int64_t)my_n * p.gpi) * 32 + (q4 & 31) : 0;
+    const bool my_live = my_group < total && my_start < p.HW;        // (HW % 4 == 0: a float4 is inside or outside)
+    const int my_pix = my_live ? my_start : 0;
     const float* x_lane = p.epi_x + (int64_t)my_n * p.epi_x_bs + my_pix;
     float* out_lane = p.out + (int64_t)my_n * p.out_bs + my_pix;
     const bool sums_wanted = p.epi_partial != nullptr;
@@ -300,10 +304,12 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     __syncthreads();
     constexpr int RPT = BM / 8;
     const int half = tid >> 5, q4 = (tid & 31) * 4;
-    const int64_t my_pixel0 = ((int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5)) * 32;
-    if (my_pixel0 >= total) return;
-    const int my_n = (int)(my_pixel0 / p.HW);
-    float* out_lane = p.out + (int64_t)my_n * p.out_bs + (int)(my_pixel0 - (int64_t)my_n * p.HW) + (q4 & 31);
+    const int64_t my_group = (int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5);
+    if (my_group >= total) return;
+    const int my_n = (int)(my_group / p.gpi);
+    const int my_start = (int)(my_group - (int64_t)my_n * p.gpi) * 32 + (q4 & 31);
+    if (my_start >= p.HW) return;                                    // (HW % 4 == 0: a float4 is inside or outside)
+    float* out_lane = p.out + (int64_t)my_n * p.out_bs + my_start;
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f olds[RPT];
     if (p.mode == 1) {
@@ -337,7 +343,8 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
         if (o >= p.CO) continue;
         const float bias = add_bias ? p.bias[o] : 0.f;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) write(out_lane + (int64_t)o * p.HW + 32 * ni, acc[mi][ni][r] + bias);
+        for (int ni = 0; ni < NI; ++ni)
+          if (pix + 32 * ni < p.HW) write(out_lane + (int64_t)o * p.HW + 32 * ni, acc[mi][ni][r] + bias);
       }
     }
   };
@@ -420,7 +427,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   // 10 % faster on the K = 128 data gradients, inside the training step it measured 0.7 % slower: off by default.
   static const int ni_cap = getenv("SRGAN_PW_NI") ? atoi(getenv("SRGAN_PW_NI")) : 1;
   int ni = (HW % 64 == 0 && ni_cap >= 2 && !epilogue) ? 2 : 1;
-  int64_t groups = (int64_t)N * HW / (32 * ni);
+  int64_t groups = (int64_t)N * ((HW + 32 * ni - 1) / (32 * ni));
   int64_t col_blocks = (groups + 3) / 4;
   // Tallest row tile that still yields ~4 workgroups per CU; otherwise shorter tiles, then split over input channels.
   static const int mi_cap_long = getenv("SRGAN_PW_MI") ? atoi(getenv("SRGAN_PW_MI")) : 2;
@@ -434,7 +441,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     if (mi > 2) mi = 2;
     if (mi < 2 || col_blocks * ((CO + 63) / 64) < 1024) {
       ni = 1;
-      groups = (int64_t)N * HW / 32;
+      groups = (int64_t)N * ((HW + 31) / 32);
       col_blocks = (groups + 3) / 4;
       mi = CO > 64 ? 4 : (CO > 32 ? 2 : 1);
       if (mi > mi_cap) mi = mi_cap;
@@ -479,7 +486,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   if (epilogue) {
     SRGAN_REQUIRE(!bn && !bias, SRGAN_EINVAL, "pointwise batch-norm backward epilogue: no prologue, no bias");
     SRGAN_REQUIRE(mi <= 2 && rest == 0, SRGAN_EUNSUPPORTED, "pointwise batch-norm backward epilogue: at most 64-row tiles");
-    SRGAN_REQUIRE(((((uintptr_t)epilogue->x | (uintptr_t)out) & 15) | ((epilogue->x_bs | out_bs) & 3)) == 0, SRGAN_EINVAL,
+    SRGAN_REQUIRE(((((uintptr_t)epilogue->x | (uintptr_t)out) & 15) | ((epilogue->x_bs | out_bs | HW) & 3)) == 0, SRGAN_EINVAL,
                   "pointwise batch-norm backward epilogue: 16-byte aligned x / gx rows");
     p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
     p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
@@ -490,7 +497,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     }
   }
   static const bool narrow = getenv("SRGAN_PW_NARROW_OUT") != nullptr;
-  p.wide_out = (!narrow && (((uintptr_t)out & 15) | (out_bs & 3)) == 0) ? 1 : 0;
+  p.wide_out = (!narrow && (((uintptr_t)out & 15) | (out_bs & 3) | (HW & 3)) == 0) ? 1 : 0;
+  p.gpi = (HW + 32 * ni - 1) / (32 * ni);
   profile_bracket_begin(stream);
   // (K slices of 64 measured no faster and spill at 128 rows: the slice is 32 channels.)
   auto launch = [&](int mi_, dim3 grid) {

@@ -440,9 +440,25 @@ def test_fused_batch_norm_convolutions(F):
         _lib.check(lib.srgan_conv2d_bwd_weight_bnrelu(desc, d['wide'].data_ptr(), bn, d['gy'].data_ptr(), gw.data_ptr(), 0,
                                                       stream), 'bwd_weight_bnrelu')
         close(gw, gw_ref, what=f'fused bn conv weight gradient {c}->{k} k{r}')
-    # geometries without a fused form are reported, not guessed
-    odd = _lib.ConvDesc(2, 32, 9, 7, 16, 1, 1, 1, 1, 0, 0, 9, 7, 0, 0)
-    assert lib.srgan_conv2d_bnrelu_supported(odd, 0) == 0 and lib.srgan_conv2d_bnrelu_supported(odd, 2) == 0
+    # geometries without a fused form are reported, not guessed: a plane of fewer than 32 pixels has none; a plane that
+    # is not a multiple of 32 pixels has the fused forward (ragged last pixel group) but not the fused weight gradient
+    tiny = _lib.ConvDesc(2, 32, 5, 5, 16, 1, 1, 1, 1, 0, 0, 5, 5, 0, 0)
+    assert lib.srgan_conv2d_bnrelu_supported(tiny, 0) == 0 and lib.srgan_conv2d_bnrelu_supported(tiny, 2) == 0
+    for (n, c, h, w, k) in [(2, 32, 9, 7, 16), (3, 200, 14, 14, 128), (2, 64, 7, 7, 40)]:
+        x = torch.randn(n, c, h, w, generator=gen)
+        mean, var = torch.randn(c, generator=gen) * 0.3, torch.rand(c, generator=gen) + 0.5
+        gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.3
+        weight = torch.randn(k, c, 1, 1, generator=gen) / c ** 0.5
+        y_ref = TF.conv2d(TF.batch_norm(x, mean, var, gamma, beta, training=False, eps=1e-5).relu(), weight)
+        d = {name: dev(t) for name, t in dict(x=x, mean=mean, inv=(var + 1e-5).rsqrt(), gamma=gamma, beta=beta,
+                                              weight=weight).items()}
+        desc = _lib.ConvDesc(n, c, h, w, k, 1, 1, 1, 1, 0, 0, h, w, 0, 0)
+        assert lib.srgan_conv2d_bnrelu_supported(desc, 0) == 1 and lib.srgan_conv2d_bnrelu_supported(desc, 2) == 0
+        bn = _lib.BnRelu(d['mean'].data_ptr(), d['inv'].data_ptr(), d['gamma'].data_ptr(), d['beta'].data_ptr())
+        y = torch.full(y_ref.shape, float('nan'), device='cuda')
+        _lib.check(lib.srgan_conv2d_fwd_bnrelu(desc, d['x'].data_ptr(), bn, d['weight'].data_ptr(), None, y.data_ptr(),
+                                               stream), 'fwd_bnrelu')
+        close(y, y_ref, what=f'fused bn conv forward on a ragged plane {h}x{w}')
 
 
 @gpu
