@@ -334,7 +334,10 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
   float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
   // Three straight-line passes selected once (store / accumulate / atomic): with the mode tested per element the
   // 16 * MI stores of a lane are separated by branches and cannot be issued back to back.
-  auto emit = [&](auto&& write) {
+  // A wave whose 32 * NI pixels all exist (every wave unless the plane is not a multiple of the group) stores without
+  // per-lane predicates: a lane-varying test around every store would put an exec-mask update between them.
+  const bool ragged = pix0 + 32 * NI > p.HW;                       // wave-uniform
+  auto emit = [&](auto&& write, auto check_lane) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -343,14 +346,22 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
         if (o >= p.CO) continue;
         const float bias = add_bias ? p.bias[o] : 0.f;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          if (pix + 32 * ni < p.HW) write(out_lane + (int64_t)o * p.HW + 32 * ni, acc[mi][ni][r] + bias);
+        for (int ni = 0; ni < NI; ++ni) {
+          if constexpr (decltype(check_lane)::value) {
+            if (pix + 32 * ni >= p.HW) continue;
+          }
+          write(out_lane + (int64_t)o * p.HW + 32 * ni, acc[mi][ni][r] + bias);
+        }
       }
     }
   };
-  if (p.mode == 0) emit([](float* dst, float v) { __builtin_nontemporal_store(v, dst); });   // consumed by a later kernel
-  else if (p.mode == 1) emit([](float* dst, float v) { *dst += v; });
-  else emit([](float* dst, float v) { unsafeAtomicAdd(dst, v); });
+  auto emit_mode = [&](auto check_lane) {
+    if (p.mode == 0) emit([](float* dst, float v) { __builtin_nontemporal_store(v, dst); }, check_lane);   // consumed by a later kernel
+    else if (p.mode == 1) emit([](float* dst, float v) { *dst += v; }, check_lane);
+    else emit([](float* dst, float v) { unsafeAtomicAdd(dst, v); }, check_lane);
+  };
+  if (ragged) emit_mode(std::true_type{});
+  else emit_mode(std::false_type{});
 }
 
 // Second level of the fused batch-norm backward's parameter gradients: column sums of partial[q][column block][CO]
