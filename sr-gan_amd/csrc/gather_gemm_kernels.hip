@@ -618,10 +618,12 @@ static bool use_pointwise(const ConvGeom& g, int out_channels, int force) {
   return force == 0 && pointwise_enabled() && pointwise(g) && plane_ok && out_channels >= 8 && in_channels % 2 == 0;
 }
 
-// 3x3 / stride 1 / pad 1 with enough width to fill half of a 32-pixel MFMA column block: the LDS-halo kernel.
+// 3x3 / stride 1 / pad 1 with enough width to fill most of a 16-pixel tile row (two image rows share a 32-pixel MFMA
+// column block): the LDS-halo kernel.
 static bool use_conv3x3(const ConvGeom& g, int out_channels, int force) {
+  static const int min_width = getenv("SRGAN_CONV3_MIN_W") ? atoi(getenv("SRGAN_CONV3_MIN_W")) : 7;   // the 14- and 7-wide planes at 224
   return force == 0 && conv3x3_enabled() && g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
-         g.W >= 16 && out_channels >= 8;
+         g.W >= min_width && out_channels >= 8;
 }
 
 bool conv3x3_wgrad_enabled();

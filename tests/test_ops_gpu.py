@@ -102,6 +102,9 @@ CONV_CASES = [
     (16, 128, 64, 64, 32, 3, 3, (1, 1), (1, 1)),
     (2, 128, 16, 16, 32, 3, 3, (1, 1), (1, 1)),      # 16-wide images: two image rows per 32-lane column block
     (3, 40, 13, 16, 24, 3, 3, (1, 1), (1, 1)),
+    (2, 128, 14, 14, 32, 3, 3, (1, 1), (1, 1)),      # 14-wide planes of the 224-pixel configuration: two dead columns per tile
+    (2, 32, 14, 13, 128, 3, 3, (1, 1), (1, 1)),
+    (3, 128, 7, 7, 32, 3, 3, (1, 1), (1, 1)),
     (3, 200, 20, 24, 40, 3, 3, (1, 1), (1, 1)),      # LDS-patch weight gradient: ragged channel chunks and tiles
     (4, 3, 96, 96, 16, 7, 7, (2, 2), (3, 3)),        # stem: the 3-row image gradient takes the few-rows kernel
     (2, 5, 72, 72, 7, 3, 3, (1, 1), (1, 1)),         # 5 and 7 rows (MR = 8) in the few-rows kernel
