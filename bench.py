@@ -1,20 +1,30 @@
 """Headline benchmark: SRGAN training images/s on the crowd workload (BASELINE.json configs[2]/[3]).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Started by ``torch.distributed.run`` (RANK / WORLD_SIZE in the environment) the
+script IS a rank; started plainly (``python bench.py --gpus 8``) it launches its N ranks itself -- as a child
+``torch.distributed.run`` on 127.0.0.1, BEFORE this process makes any GPU call -- relays rank 0's JSON line and exits
+with the children's status.
 
 One "step" = one iteration of the reference's training loop (srgan.py:104-118): ``dnn_training_step`` +
 ``gan_training_step`` (8 D forwards / 6 D backwards / GP double backward / G forward x2 + backward / 3 Adam
 updates in the reference's schedule) on a synthetic batch of 16 crowd images of 512x512 per GPU (weak scaling:
-global batch = 16 * N), inputs resident in HBM.  Prints ONE JSON line on rank 0.
+global batch = 16 * N), inputs resident in HBM.  The discriminator's convolution weights are scaled (``GP_SCALE``) so
+that the gradient penalty is ACTIVE (at the default initialisation every gradient norm is < 1 and the penalty's own
+backward would multiply exact zeros); ``config.gradient_penalty_last`` is its value in the last timed step.
+Prints ONE JSON line on rank 0.
 
 Extra legs (rank 0, N = 1 only):
-* ``roofline``: every contraction launch (the MFMA gather-GEMM kernel family = the dominant kernel) of one
-  extra step is bracketed with HIP events on its launch stream inside libsrgan_hip.so; achieved =
-  sum(logical 2*M*N*K) / sum(event durations), against the fp32 MFMA peak (157.3 TF/s,
-  MI355X_MICROARCH.md).  ``step_tflops`` is the end-to-end figure: BASELINE.md's algorithmic FLOPs per image x
-  images/s.
+* ``roofline``: every contraction launch (the MFMA kernel family = the dominant kernels) of one extra step is
+  bracketed with HIP events on its launch stream inside libsrgan_hip.so; achieved = sum(executed 2*M*N*K) /
+  sum(event durations), against the fp32 MFMA peak (157.3 TF/s, MI355X_MICROARCH.md).
+  ``step_frac_executed`` = the same executed FLOPs / the WHOLE step time / peak (everything else counted as lost time);
+  ``step_tflops_as_written_schedule`` divides BASELINE.md's as-written FLOPs of the reference schedule by the step time: a
+  speed-up statement, not a roofline fraction.  ``traffic`` comes from the rocprofv3 PMC passes committed under
+  profiles/ and is null unless that file was measured at this image size / batch on these kernel sources.
 * ``cpu_baseline``: the CPU oracle (PyTorch-CPU fp32 restatement of the reference step, kind "port") timed on
-  this box's host cores on a bounded sample (one full iteration at the same 512x512 shape, batch 1).
+  this box's host cores on a bounded sample (1 warm-up + 3 timed iterations at the same 512x512 shape, batch 1).
 """
 import argparse
 import json
@@ -33,6 +43,9 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 # algorithmic FLOPs per image of the reference's as-written schedule (conv + linear, 2*MAC)
 ALGORITHMIC_GFLOP_PER_IMAGE = {512: 1188.7 + 135.6, 224: 227.5 + 26.0}
+# Factor on every convolution weight of D that makes the gradient penalty active at the benchmark shapes (measured with
+# scratch/gp_scale.py: mean gradient norm of the interpolates ~2-4 instead of ~0.01 at the default initialisation).
+GP_SCALE = {512: 1.27, 224: 1.27}
 
 
 def parse():
@@ -53,6 +66,12 @@ def parse():
     parser.add_argument('--shape-report', default=None, help='write the per-shape contraction timing table here')
     parser.add_argument('--reference-schedule', action='store_true',
                         help='replay the reference forward/backward order instead of sharing forwards')
+    parser.add_argument('--gp-scale', type=float, default=None,
+                        help='factor on D\'s convolution weights (default: GP_SCALE for the image size; 1 = default '
+                             'initialisation, gradient penalty inactive)')
+    parser.add_argument('--no-overlap-exchange', action='store_true',
+                        help='data parallel: wait for each gradient all-reduce where it is started')
+    parser.add_argument('--master-port', type=int, default=None, help='self-launch only: rendezvous port on 127.0.0.1')
     return parser.parse_args()
 
 
@@ -69,11 +88,18 @@ def build_experiment(args, dp):
     settings.learning_rate = 1e-4
     settings.reference_schedule = args.reference_schedule
     settings.overlap_dnn_step = args.overlap_dnn
+    settings.overlap_gradient_exchange = not args.no_overlap_exchange
     experiment = CrowdExperiment(settings)
     experiment.dp = dp
     seed_all(0)
     experiment.dataset_setup()
     experiment.model_setup()
+    scale = gp_scale(args)
+    if scale != 1.0:
+        with torch.no_grad():
+            for module in experiment.D.modules():
+                if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                    module.weight.mul_(scale)
     experiment.gpu_mode()
     experiment.prepare_optimizers()
     experiment.train_mode()
@@ -85,6 +111,10 @@ def build_experiment(args, dp):
     return experiment
 
 
+def gp_scale(args):
+    return args.gp_scale if args.gp_scale is not None else GP_SCALE.get(args.image_size, 1.27)
+
+
 def one_step(experiment, labeled, unlabeled, step):
     x, heads, knn = next(labeled)
     u = next(unlabeled)[0]
@@ -92,15 +122,22 @@ def one_step(experiment, labeled, unlabeled, step):
     experiment.gan_training_step(x, (heads, knn), u, step + 1)
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per contraction launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE x 2 + WRITE_SIZE, see the note in that file); None when the file is absent.  PMC collection needs
-    rocprofv3 around the process, so it cannot be measured from inside this script."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+def pmc_traffic(args):
+    """(HBM bytes per contraction launch, provenance) from the committed rocprofv3 PMC passes -- FETCH_SIZE x 2 +
+    WRITE_SIZE per the guide's gfx950 correction, see profiles/README.md -- or (None, reason) unless the file was
+    measured at THIS image size and batch on THESE kernel sources.  PMC collection needs rocprofv3 around the process, so
+    it cannot be measured from inside this script; a constant from another configuration is not a measurement."""
+    from srgan_amd import _build
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
-        return json.load(open(path))['hbm_bytes_per_launch']
+        entries = json.load(open(path))['entries']
     except (OSError, KeyError, ValueError):
-        return None
+        return None, 'profiles/pmc_traffic.json absent'
+    for entry in entries:
+        if (entry.get('image_size') == args.image_size and entry.get('batch_per_gpu') == args.batch_per_gpu and
+                entry.get('kernel_source_id') == _build.source_id()):
+            return entry['hbm_bytes_per_launch'], entry.get('source', path)
+    return None, f'no PMC entry for image size {args.image_size}, batch {args.batch_per_gpu}, kernel sources {_build.source_id()}'
 
 
 def hbm_kernel_rates(experiment):
@@ -110,7 +147,7 @@ def hbm_kernel_rates(experiment):
     import srgan_amd  # noqa: F401
     from srgan_amd import _lib
     lib = _lib.library()
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = _lib.stream_handle()
 
     def timed(fn, reps):
         fn()
@@ -150,7 +187,17 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(image_size, limit_seconds=420):
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(image_size, limit_seconds=600):
     """Runs ``cpu_baseline_child`` in a child process under a hard time limit (it never touches the GPU)."""
     import subprocess
     command = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--image-size', str(image_size)]
@@ -158,12 +205,13 @@ def cpu_baseline(image_size, limit_seconds=420):
         output = subprocess.run(command, capture_output=True, text=True, timeout=limit_seconds).stdout
         return json.loads(output.strip().splitlines()[-1])
     except (subprocess.TimeoutExpired, ValueError, IndexError) as error:
-        return {'value': None, 'unit': 'images/s', 'cores': usable_cores(), 'kind': 'port',
+        return {'value': None, 'unit': 'images/s', 'cores': usable_cores(), 'kind': 'port', 'cpu': cpu_model(),
                 'sample': f'not measured: {type(error).__name__} (limit {limit_seconds} s)'}
 
 
-def cpu_baseline_child(image_size):
-    """The oracle's full iteration on the host cores, one timed step at batch 1 of the same image shape."""
+def cpu_baseline_child(image_size, warmup=1, timed=3):
+    """The oracle's full iteration (reference srgan.py:104-118) on the host cores: ``warmup`` + ``timed`` iterations at
+    batch 1 of the same image shape (1 warm-up + >= 3 timed steps for crowd)."""
     from types import SimpleNamespace
     from oracle import functional as OF, models as OM
     from oracle.experiment import OracleExperiment
@@ -179,6 +227,10 @@ def cpu_baseline_child(image_size):
     OF.seed_all(0)
     G = OM.DCGANGenerator(image_size=image_size)
     D, DNN = OM.KnnDenseNetCat(image_size=image_size), OM.KnnDenseNetCat(image_size=image_size)
+    with torch.no_grad():                        # the same active-gradient-penalty weights as the GPU legs
+        for module in D.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                module.weight.mul_(GP_SCALE.get(image_size, 1.27))
     oracle = OracleExperiment(settings, D, DNN, G,
                               labeled_loss_function=lambda p, y, order: OF.crowd_labeled_loss(p, y, order, 1e-3))
     generator = torch.Generator().manual_seed(0)
@@ -186,40 +238,65 @@ def cpu_baseline_child(image_size):
     u = torch.rand(batch, 3, image_size, image_size, generator=generator) * 2 - 1
     heads = (torch.rand(batch, image_size, image_size, generator=generator) < 0.002).float()
     knn = torch.rand(batch, image_size, image_size, generator=generator)
-    start = time.perf_counter()
-    oracle.dnn_training_step(x, (heads, knn))
-    oracle.gan_training_step(x, (heads, knn), u, 0)
-    elapsed = time.perf_counter() - start
-    return {'value': batch / elapsed, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 full iteration (dnn_training_step + gan_training_step) of the PyTorch-CPU fp32 oracle, '
-                      f'crowd {image_size}x{image_size}, batch {batch}, {elapsed:.1f} s'}
+    seconds = []
+    for iteration in range(warmup + timed):
+        start = time.perf_counter()
+        oracle.dnn_training_step(x, (heads, knn))
+        oracle.gan_training_step(x, (heads, knn), u, iteration)
+        seconds.append(time.perf_counter() - start)
+    elapsed = sum(seconds[warmup:])
+    return {'value': batch * timed / elapsed, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'cpu': cpu_model(),
+            'sample': f'{warmup} warm-up + {timed} timed iterations (dnn_training_step + gan_training_step) of the '
+                      f'PyTorch-CPU fp32 oracle, crowd {image_size}x{image_size}, batch {batch}: '
+                      + ' / '.join(f'{t:.2f}' for t in seconds[warmup:]) + f' s (warm-up {seconds[0]:.2f} s)'}
 
 
 def ensure_library():
-    """libsrgan_hip.so normally arrives prebuilt with the working tree; if it is missing, local rank 0 compiles it
-    (hipcc, ~30 s) and the other ranks wait for the file.  There is still no fallback: without it nothing runs."""
+    """libsrgan_hip.so normally arrives prebuilt with the working tree; when it is missing or was built from other
+    kernel sources (compared by content: ``_build.is_current``), local rank 0 compiles it (hipcc, about a minute) and
+    the other ranks wait for the finished file (it is renamed into place).  No GPU call is made here, and there is
+    still no fallback: without the library nothing runs."""
     from srgan_amd import _build
-    if os.path.exists(_build.LIBRARY):
+    if _build.is_current():
         return
     if int(os.environ.get('LOCAL_RANK', '0')) == 0:
         _build.build()
         return
-    deadline = time.time() + 600
-    while not os.path.exists(_build.LIBRARY) and time.time() < deadline:
+    deadline = time.time() + 900
+    while not _build.is_current() and time.time() < deadline:
         time.sleep(2)
-    time.sleep(2)          # (the linker writes the file in place: let it finish)
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` from a plain shell: start the N ranks as a child ``torch.distributed.run`` (one process
+    per GPU, rendezvous on 127.0.0.1) and relay its output.  This process has made no GPU call (importing torch and
+    compiling with hipcc do not initialise the device), and it never replaces itself with another program."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if port is None:
+        with socket.socket() as probe:
+            probe.bind(('127.0.0.1', 0))
+            port = probe.getsockname()[1]
+    command = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    environment = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SRGAN_BENCH_SELF_LAUNCHED='1')
+    child = subprocess.run(command, env=environment)
+    return child.returncode
 
 
 def main():
     args = parse()
     if args.cpu_baseline_child:
         print(json.dumps(cpu_baseline_child(args.image_size)))
-        return
+        return 0
     ensure_library()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if args.gpus != 1:
-            raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+        raise SystemExit(f'--gpus {args.gpus} but torch.distributed.run started {world} ranks')
     local_rank = 0 if args.single_device else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dp = None
@@ -233,6 +310,7 @@ def main():
     unlabeled = experiment.infinite_iter(experiment.unlabeled_dataset_loader)
 
     def fence():
+        experiment.join_dnn_stream()       # also applies optimizer updates still waiting for their gradient exchange
         if dp is not None:
             dp.barrier()
         torch.cuda.synchronize()
@@ -249,6 +327,13 @@ def main():
         elapsed = dp.all_reduce_max_float(elapsed)
     global_batch = experiment.settings.batch_size
     images_per_second = global_batch * args.steps / elapsed
+    # after the timed region: the penalty really was active, and nothing diverged
+    penalty = experiment.loss_value(experiment.last_losses['gradient_penalty'], partial=True)
+    finite = all(bool(torch.isfinite(v.data).all()) for v in experiment.last_losses.values() if v is not None)
+    if gp_scale(args) != 1.0 and not penalty > 0.0:
+        raise SystemExit(f'gradient penalty inactive ({penalty}) at GP scale {gp_scale(args)}: the benchmark would time zeros')
+    if not finite:
+        raise SystemExit('non-finite losses in the last timed step')
 
     result = {
         'metric': 'SRGAN train images/sec (G+D step)', 'value': images_per_second, 'unit': 'images/s',
@@ -258,12 +343,17 @@ def main():
                                f'batch {args.batch_per_gpu}/GPU, dnn_training_step + gan_training_step per step',
                    'global_batch': global_batch, 'image_size': args.image_size,
                    'schedule': 'reference' if args.reference_schedule else 'shared-forwards',
-                   'parallelism': f'dp{world}', 'random_init_weights': True},
+                   'parallelism': f'dp{world}', 'random_init_weights': True,
+                   'gradient_penalty': 'active' if penalty > 0.0 else 'inactive', 'gradient_penalty_last': penalty,
+                   'discriminator_weight_scale': gp_scale(args)},
     }
+    if dp is not None:
+        result['config']['gradient_exchange'] = ('blocking' if args.no_overlap_exchange else
+                                                 'asynchronous, overlapped with backward / next phase') + f' ({args.backend})'
     gflop = ALGORITHMIC_GFLOP_PER_IMAGE.get(args.image_size)
     if gflop:
-        result['step_tflops'] = images_per_second * gflop / 1e3
-        result['step_frac_of_fp32_mfma_peak'] = result['step_tflops'] / (FP32_MFMA_PEAK_TFLOPS * world)
+        result['step_tflops_as_written_schedule'] = images_per_second * gflop / 1e3
+        result['step_frac_as_written_schedule'] = result['step_tflops_as_written_schedule'] / (FP32_MFMA_PEAK_TFLOPS * world)
 
     if rank == 0 and world == 1 and not args.no_roofline:
         import ctypes
@@ -271,35 +361,47 @@ def main():
         lib = _lib.library()
         lib.srgan_profile_begin()
         one_step(experiment, labeled, unlabeled, args.warmup + args.steps)
+        experiment.join_dnn_stream()
         kernel_ms, flops, mfma_flops, launches = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         _lib.check(lib.srgan_profile_end(ctypes.byref(kernel_ms), ctypes.byref(flops), ctypes.byref(mfma_flops),
                                          ctypes.byref(launches)), 'srgan_profile_end')
+        algorithmic_bytes = ctypes.c_double()
+        _lib.check(lib.srgan_profile_bytes(ctypes.byref(algorithmic_bytes)), 'srgan_profile_bytes')
         torch.cuda.synchronize()
         if args.shape_report:
             size = lib.srgan_profile_report(None, 0)
             text = ctypes.create_string_buffer(size)
             lib.srgan_profile_report(text, size)
             with open(args.shape_report, 'w') as handle:
+                handle.write('# M N K kind bm bn split akf bkf count ms bytes   (kind: 0 gg_direct 1 gg_mfma 2 conv3x3_lds '
+                             '3 pointwise 4 conv3x3_wgrad 5 gg_rows 6 pointwise_wgrad 8 pointwise_ksplit 9 gg_dot)\n')
                 handle.write(text.value.decode())
         achieved = flops.value / (kernel_ms.value * 1e-3) / 1e12 if kernel_ms.value > 0 else 0.0
+        traffic, traffic_source = pmc_traffic(args)
+        step_seconds = elapsed / args.steps
         result['roofline'] = {
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic_per_launch(),
+            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
             'kernel': 'all contraction kernels of one step: srgan::pointwise_kernel / conv3x3_lds_kernel / conv3x3_wgrad_kernel / '
                       'pointwise_wgrad_kernel / gg_mfma_kernel / gg_rows_kernel (every conv and linear pass)',
             'launches': launches.value, 'kernel_ms_per_step': kernel_ms.value,
-            'logical_gflop_per_step': flops.value / 1e9, 'mfma_share_of_flops': mfma_flops.value / max(flops.value, 1.0),
+            'executed_gflop_per_step': flops.value / 1e9, 'mfma_share_of_flops': mfma_flops.value / max(flops.value, 1.0),
             'avg_launch_us': 1e3 * kernel_ms.value / max(launches.value, 1),
+            'algorithmic_bytes_per_step': algorithmic_bytes.value,
+            'algorithmic_bytes_per_launch': algorithmic_bytes.value / max(launches.value, 1),
+            'step_frac_executed': flops.value / step_seconds / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         }
     if rank == 0 and world == 1 and not args.no_roofline:
         result['hbm_kernels'] = hbm_kernel_rates(experiment)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args.image_size)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dp is not None:
         dp.barrier()
+        torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

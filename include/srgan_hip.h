@@ -9,8 +9,15 @@
  *   - every function returns int: 0 = ok, < 0 = argument / shape error (-1 invalid, -2 unsupported,
  *     -3 out of range), > 0 = hipError_t.  srgan_last_error() returns a thread-local message.
  *   - pointers are DEVICE pointers to contiguous fp32 (int32 for arg-max), borrowed for the call only;
- *     nothing is allocated, retained or freed.  Activations are NCHW, conv weights [K, C, R, S],
- *     transposed-conv weights [Cin, Cout, R, S] (torch layouts).
+ *     the library never allocates or frees device memory.  The one block it keeps between calls is the split-K
+ *     workspace the CALLER registers per (device, stream) with srgan_set_workspace (below); a contraction that
+ *     needs it on a stream without one fails with -1 and a message.  Activations are NCHW, conv weights
+ *     [K, C, R, S], transposed-conv weights [Cin, Cout, R, S] (torch layouts).
+ *   - thread safety: calls may come from several host threads (the registry and the profile state are locked,
+ *     srgan_last_error is thread-local); two threads must not launch on the SAME stream with the same workspace
+ *     concurrently, as with any stream-ordered resource.
+ *   - collectives are deliberately NOT part of this ABI: the data-parallel exchange (feature sums, gradient arenas)
+ *     stays in torch.distributed (backend "nccl" = RCCL over xGMI) on the host side, see INTEGRATION.md.
  *   - `stream` is a hipStream_t (NULL = default stream); every call is asynchronous on it.
  *   - `accumulate` != 0 adds into the existing output (gradient accumulation across the four
  *     discriminator backward passes, reference srgan.py:280-295) instead of overwriting it.
@@ -28,7 +35,36 @@ extern "C" {
 #endif
 
 int srgan_version(void);               /* 100 = ABI 1.0 */
+/* 16 hex digits: sha256 over the kernel sources this library was compiled from (sr-gan_amd/_build.py source_id()).
+ * The Python loader refuses a library whose id differs from the sources next to it: a stale prebuilt .so must not
+ * silently run old kernels under new parity tests. */
+const char* srgan_build_id(void);
 const char* srgan_last_error(void);
+
+/* ---- capabilities, caller-owned workspace -------------------------------------------------------------------
+ * srgan_capabilities fills the struct below (pass sizeof(srgan_capabilities_t)); SRGAN_DTYPE_* / SRGAN_FEATURE_*
+ * are bit masks.  Reference analogue: none (torch picks kernels internally); SURVEY.md 8b asks for the query. */
+#define SRGAN_DTYPE_F32 0x1u            /* fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32): the parity path */
+#define SRGAN_FEATURE_FUSED_BNRELU 0x1u /* norm -> relu -> conv evaluated inside the convolution kernels */
+#define SRGAN_FEATURE_SPLITK_WORKSPACE 0x2u
+#define SRGAN_FEATURE_LIVE_PROFILE 0x4u
+typedef struct srgan_capabilities_t {
+  int32_t abi_version;          /* = srgan_version() */
+  int32_t struct_bytes;         /* sizeof(srgan_capabilities_t) as the library was built */
+  char arch[16];                /* "gfx950" */
+  uint32_t dtypes;              /* SRGAN_DTYPE_* */
+  uint32_t features;            /* SRGAN_FEATURE_* */
+  int64_t workspace_bytes;      /* = srgan_workspace_bytes() */
+  int64_t max_tensor_elements;  /* 2^31 - 1 */
+} srgan_capabilities_t;
+int srgan_capabilities(srgan_capabilities_t* out, int32_t out_bytes);
+/* Split-K launches with a tiny output (M*N < 512, >= 32 K-slices: the map heads' weight gradients) write their
+ * partial tiles to a workspace and sum them in a second kernel (atomics from a thousand workgroups into a few cache
+ * lines serialise in L2).  The caller owns that memory: register one block of >= srgan_workspace_bytes() bytes
+ * (16-byte aligned, device memory) per (current device, stream) before the first contraction on that stream;
+ * NULL unregisters.  Launches on one stream are ordered, so one block per stream is enough. */
+int64_t srgan_workspace_bytes(void);
+int srgan_set_workspace(void* workspace, int64_t bytes, void* stream);
 
 /* ---- convolution ------------------------------------------------------------------------------------------
  * Geometry of y = conv2d(x, w): x [N,C,H,W], w [K,C,R,S], y [N,K,OH,OW].  Batch strides (elements) allow a
@@ -222,8 +258,13 @@ int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  * part of it executed by the MFMA kernel, and the launch count (bench.py's roofline leg). */
 int srgan_profile_begin(void);
 int srgan_profile_end(double* kernel_ms, double* flops, double* mfma_flops, int64_t* launches);
-/* Per-shape text report of the last profiled region ("M N K kind bm bn split akf bkf count ms" per line);
- * returns the bytes needed (tuning aid). */
+/* Algorithmic HBM bytes of the bracketed launches: every operand / result element once, 4 B each (a 3x3 tap or a
+ * stride class does not count an input element twice): the figure bench.py's roofline.algorithmic_bytes_per_step
+ * reports next to the PMC traffic. */
+int srgan_profile_bytes(double* algorithmic_bytes_total);
+/* Per-shape text report of the last profiled region ("M N K kind bm bn split akf bkf count ms bytes" per line; kind:
+ * 0 gg_direct, 1 gg_mfma, 2 conv3x3_lds, 3 pointwise, 4 conv3x3_wgrad, 5 gg_rows, 6 pointwise_wgrad,
+ * 8 pointwise_ksplit, 9 gg_dot); returns the bytes needed. */
 int64_t srgan_profile_report(char* buffer, int64_t capacity);
 
 #ifdef __cplusplus

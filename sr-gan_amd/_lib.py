@@ -3,7 +3,7 @@ missing or a call fails, an exception is raised."""
 import ctypes
 import os
 
-from ._build import LIBRARY
+from ._build import LIBRARY, source_id
 
 c_float_p = ctypes.c_void_p
 i32, i64, f32, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -20,8 +20,15 @@ class BnRelu(ctypes.Structure):
     _fields_ = [(name, vp) for name in ('mean', 'inv_std', 'gamma', 'beta')]
 
 
+class Capabilities(ctypes.Structure):
+    """Mirror of ``srgan_capabilities_t``."""
+    _fields_ = [('abi_version', i32), ('struct_bytes', i32), ('arch', ctypes.c_char * 16), ('dtypes', ctypes.c_uint32),
+                ('features', ctypes.c_uint32), ('workspace_bytes', i64), ('max_tensor_elements', i64)]
+
+
 SIGNATURES = {
     'srgan_version': ([], ctypes.c_int),
+    'srgan_build_id': ([], ctypes.c_char_p),
     'srgan_last_error': ([], ctypes.c_char_p),
     'srgan_conv2d_fwd': ([ctypes.POINTER(ConvDesc), vp, vp, vp, vp, ctypes.c_int, vp], ctypes.c_int),
     'srgan_conv2d_bwd_data': ([ctypes.POINTER(ConvDesc), vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp],
@@ -66,6 +73,10 @@ SIGNATURES = {
     'srgan_profile_end': ([ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     'srgan_profile_report': ([ctypes.c_char_p, ctypes.c_int64], ctypes.c_int64),
+    'srgan_profile_bytes': ([ctypes.POINTER(ctypes.c_double)], ctypes.c_int),
+    'srgan_capabilities': ([ctypes.POINTER(Capabilities), i32], ctypes.c_int),
+    'srgan_workspace_bytes': ([], ctypes.c_int64),
+    'srgan_set_workspace': ([vp, i64, vp], ctypes.c_int),
     'srgan_crowd_density_label': ([vp, i32, i32, i32, f32, vp, vp, vp], ctypes.c_int),
     'srgan_crowd_iknn_map': ([vp, i32, i32, i32, i32, f32, f32, vp, vp], ctypes.c_int),
     'srgan_crowd_extract_patches': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
@@ -73,8 +84,15 @@ SIGNATURES = {
 }
 
 
+EINVAL, EUNSUPPORTED, ERANGE = -1, -2, -3      # negative status codes of include/srgan_hip.h
+
+
 class HipLibraryError(RuntimeError):
-    pass
+    """A failed library call; ``status`` is the C ABI's return code (< 0 argument errors, > 0 hipError_t)."""
+
+    def __init__(self, message, status=None):
+        super().__init__(message)
+        self.status = status
 
 
 _library = None
@@ -93,11 +111,40 @@ def library():
             function = getattr(lib, name)      # AttributeError if the ABI lost a symbol
             function.argtypes = argtypes
             function.restype = restype
+        built_from = lib.srgan_build_id().decode()
+        if built_from != source_id() and os.environ.get('SRGAN_ALLOW_STALE_LIBRARY') != '1':
+            raise HipLibraryError(f'{LIBRARY} was built from other kernel sources (library {built_from}, tree '
+                                  f'{source_id()}): rebuild with `python -c "import __graft_entry__ as g; g.build()"`')
         _library = lib
     return _library
+
+
+def capabilities():
+    out = Capabilities()
+    check(library().srgan_capabilities(ctypes.byref(out), ctypes.sizeof(out)), 'srgan_capabilities')
+    return out
+
+
+_workspaces = {}      # (device index, stream handle) -> the torch tensor registered as that stream's split-K workspace
+
+
+def stream_handle(stream=None):
+    """The hipStream_t of ``stream`` (default: torch's current stream), with the caller-owned split-K workspace of
+    include/srgan_hip.h registered for it on first use (one 2 MiB block per device and stream; the library itself
+    never allocates)."""
+    import torch
+    stream = torch.cuda.current_stream() if stream is None else stream
+    key = (stream.device.index, stream.cuda_stream)
+    if key not in _workspaces:
+        lib = library()
+        block = torch.empty(lib.srgan_workspace_bytes() // 4, dtype=torch.float32, device=stream.device)
+        with torch.cuda.device(stream.device):
+            check(lib.srgan_set_workspace(block.data_ptr(), block.numel() * 4, stream.cuda_stream), 'srgan_set_workspace')
+        _workspaces[key] = block
+    return stream.cuda_stream
 
 
 def check(status, what):
     if status != 0:
         message = library().srgan_last_error()
-        raise HipLibraryError(f'{what} failed with status {status}: {message.decode() if message else ""}')
+        raise HipLibraryError(f'{what} failed with status {status}: {message.decode() if message else ""}', status)

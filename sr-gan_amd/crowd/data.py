@@ -108,8 +108,13 @@ class DeviceCrowdPatchLoader:
     ``CrowdExperiment``.  Positions and flips come from a private ``numpy`` generator (the reference's
     multi-process workers make its own stream irreproducible anyway)."""
 
-    def __init__(self, examples, batch_size, image_patch_size=224, seed=0, device=None, flip=True):
+    def __init__(self, examples, batch_size, image_patch_size=224, seed=0, device=None, flip=True, dp=None):
+        """``batch_size`` is the GLOBAL batch; under data parallelism (``dp``) every rank draws the positions of the whole
+        batch from the shared seed and cuts only its own contiguous slice (same examples as one device would see)."""
         from .. import _lib
+        self.dp = dp if dp is not None and dp.world_size > 1 else None
+        if self.dp is not None:
+            self.dp.local_batch(batch_size)           # raises unless the global batch divides over the ranks
         from ..utility import current_device
         self._lib = _lib
         self.device = device or current_device()
@@ -142,6 +147,9 @@ class DeviceCrowdPatchLoader:
             columns = width - 2 * half + 1
             y_index, x_index = divmod(index - self.start_indexes[scene], columns)
             draws.append((scene, half + y_index, half + x_index, int(self.flip and self.generator.randint(2))))
+        if self.dp is not None:
+            local = self.batch_size // self.dp.world_size
+            draws = draws[self.dp.rank * local:(self.dp.rank + 1) * local]
         return draws
 
     def batch_for(self, draws):

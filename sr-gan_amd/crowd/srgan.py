@@ -37,9 +37,9 @@ class CrowdExperiment(Experiment):
                 return PreprocessedCrowdDataset(directory, 'train', part, number_of_examples=count,
                                                 map_directory_name=maps).examples()
             self.train_dataset_loader = DeviceCrowdPatchLoader(scenes(settings.labeled_dataset_size), settings.batch_size,
-                                                               size, seed=settings.labeled_dataset_seed)
+                                                               size, seed=settings.labeled_dataset_seed, dp=self.dp)
             self.unlabeled_dataset_loader = DeviceCrowdPatchLoader(scenes(settings.unlabeled_dataset_size),
-                                                                   settings.batch_size, size, seed=100)
+                                                                   settings.batch_size, size, seed=100, dp=self.dp)
             self.dataset_class = lambda dataset, map_directory_name: PreprocessedCrowdDataset(
                 directory, dataset, part, map_directory_name=map_directory_name)
             return

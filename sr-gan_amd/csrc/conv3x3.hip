@@ -312,7 +312,8 @@ static void launch_conv3(const Conv3Params& p, int th, int tw, dim3 grid, hipStr
 
 // Declared in gather_gemm_kernels.hip: records a launch for the bench's live event timing.
 int profile_bracket_begin(hipStream_t stream);
-int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
 
 bool conv3x3_enabled() {
   static const bool disabled = getenv("SRGAN_NO_CONV3") != nullptr;
@@ -413,7 +414,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
     }
   }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);
-  profile_bracket_begin(stream);
+  const int profile_slot = profile_bracket_begin(stream);
   if (bm == 32 && plan.ci_t == 16) launch_conv3<32, 16>(p, th, tw, grid, stream);
   else if (bm == 32) launch_conv3<32, 8>(p, th, tw, grid, stream);
   else if (bm == 64 && plan.ci_t == 8) launch_conv3<64, 8>(p, th, tw, grid, stream);
@@ -422,7 +423,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   if (p.epi_partial)
     bn_partial_reduce_run(p.epi_partial, p.epi_tiles, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
-  profile_bracket_end(stream, CO, (int64_t)N * H * W, (int64_t)CI * 9, 2, bm, th * 32, split);
+  profile_bracket_end(profile_slot, stream, CO, (int64_t)N * H * W, (int64_t)CI * 9, 2, bm, th * 32, split);
   return status;
 }
 

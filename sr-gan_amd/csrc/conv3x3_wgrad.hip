@@ -194,7 +194,8 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
 }
 
 int profile_bracket_begin(hipStream_t stream);
-int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
 
 bool conv3x3_wgrad_enabled() {
   static const bool disabled = getenv("SRGAN_NO_WGRAD3") != nullptr;
@@ -233,11 +234,11 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   if (walkers < 1) walkers = 1;
   if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)CO * CI * 9 * sizeof(float), stream));
   dim3 grid((unsigned)walkers, (unsigned)ci_chunks, (unsigned)co_chunks);
-  profile_bracket_begin(stream);
+  const int profile_slot = profile_bracket_begin(stream);
   if (th == 4) hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WG3_THREADS), 0, stream, p);
   else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(WG3_THREADS), 0, stream, p);
   const int status = launch_status();
-  profile_bracket_end(stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers);
+  profile_bracket_end(profile_slot, stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers);
   return status;
 }
 

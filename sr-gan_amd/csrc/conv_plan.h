@@ -26,9 +26,16 @@ inline bool geom_ok(ConvGeom& g) {
   // Every forward tap of every output must come from the declared geometry.
   if ((int64_t)(g.OH - 1) * g.sh - g.ph + g.R - 1 > (int64_t)g.H - 1 + g.ph) return false;
   if ((int64_t)(g.OW - 1) * g.sw - g.pw + g.S - 1 > (int64_t)g.W - 1 + g.pw) return false;
-  const int64_t lim = (int64_t)1 << 31;
-  if (g.x_bs * g.N >= lim || g.y_bs * g.N >= lim || (int64_t)g.K * g.C * g.R * g.S >= lim) return false;
   return true;
+}
+
+// The gather-GEMM addresses with 32-bit element offsets: the largest of the three tensors' extents (in elements), to be
+// compared with 2^31 -- the caller reports SRGAN_ERANGE with this number (a batch stacked too high; split it).
+inline int64_t geom_largest_extent(const ConvGeom& g) {
+  int64_t largest = g.x_bs * g.N;
+  if (g.y_bs * g.N > largest) largest = g.y_bs * g.N;
+  const int64_t weights = (int64_t)g.K * g.C * g.R * g.S;
+  return weights > largest ? weights : largest;
 }
 
 inline int32_t innermost_run(const Dec3& d) {
@@ -64,6 +71,7 @@ inline GatherGemm gg_blank() {
   p.A = nullptr; p.B = nullptr; p.C = nullptr; p.bias = nullptr; p.bias_cols = 0;
   p.hlim = 1; p.wlim = 1; p.M = p.N = p.K = 0; p.a_kfast = 1; p.b_kfast = 0;
   p.mode = GG_STORE; p.split_k = 1; p.k_per_split = 0; p.debug = 0; p.partial = nullptr; p.use_partial = 0;
+  p.b_unique = 0;
   p.am = p.ak = p.bk = p.bn = p.cm = p.cn = dec_linear(0, 0);
   return p;
 }
@@ -79,6 +87,7 @@ inline GatherGemm gg_transposed(const GatherGemm& p) {
   t.cm = p.cn; t.cn = p.cm;
   t.M = p.N; t.N = p.M;
   t.bias_cols = p.bias_cols ? 0 : 1;
+  t.b_unique = 0;
   return t;
 }
 
@@ -94,6 +103,7 @@ inline GatherGemm plan_conv_fwd(const ConvGeom& g, const float* x, const float* 
   p.hlim = g.H; p.wlim = g.W;
   p.C = y; p.cm = dec_linear(g.K, OHW); p.cn = dec_3d(g.N, g.OH, g.OW, (int32_t)g.y_bs, g.OW, 1, 0, 0, 0, 0, 0);
   p.bias = bias;
+  p.b_unique = (int64_t)g.N * g.C * g.H * g.W;
   if (pointwise(g)) strip_halo(p);
   choose_staging(p);
   return p;
@@ -158,6 +168,7 @@ inline std::vector<GatherGemm> plan_conv_bwd_data(const ConvGeom& g, const float
       p.cn = dec_3d(g.N, nqh, nqw, (int32_t)g.x_bs, g.sh * g.W, g.sw,
                     (g.sh * qh0 + ch - g.ph) * g.W + (g.sw * qw0 + cw - g.pw), 0, 0, 0, 0);
       p.bias = bias;
+      p.b_unique = (int64_t)g.N * g.K * OHW / (g.sh * g.sw);      // the classes share one read of gy
       if (pointwise(g)) strip_halo(p);
       choose_staging(p);
       plans.push_back(p);
@@ -178,6 +189,7 @@ inline GatherGemm plan_conv_bwd_weight(const ConvGeom& g, const float* x, const 
   p.bn = dec_3d(g.C, g.R, g.S, g.H * g.W, g.W, 1, 0, 1, 0, 1, 0);
   p.hlim = g.H; p.wlim = g.W;
   p.C = gw; p.cm = dec_linear(g.K, CRS); p.cn = dec_linear(CRS, 1);
+  p.b_unique = (int64_t)g.N * g.C * g.H * g.W;
   if (pointwise(g)) strip_halo(p);
   choose_staging(p);
   return p;

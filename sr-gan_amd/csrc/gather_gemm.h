@@ -114,7 +114,8 @@ struct GatherGemm {
   int32_t debug;                                         // tuning experiments (SRGAN_GG_DEBUG): 1 no re-staging, 2 no MFMA
   float* partial;                                        // GG_PARTIAL: K-slice z stores to partial[(z*M + i)*N + j]
   int32_t use_partial;                                   // launcher: combine K-slices through a workspace, not atomics
-};
+  int64_t b_unique;                                      // distinct B elements the gather touches (0: K * N); bookkeeping
+};                                                       //   for the algorithmic-bytes figure of the live profile only
 
 // Reference semantics of one output element (used by the CPU emulator and by the direct kernel).
 GG_HD float gg_a(const GatherGemm& p, const Side& m, const Side& k) {

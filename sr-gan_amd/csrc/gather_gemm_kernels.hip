@@ -15,8 +15,11 @@
 #include <stdarg.h>
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 
 namespace srgan {
 
@@ -414,19 +417,31 @@ __global__ __launch_bounds__(256) void gg_reduce_partials_kernel(const GatherGem
   *dst = p.mode == GG_ACCUMULATE ? *dst + acc : acc;
 }
 
-// Grow-only per-stream workspace for the partial sums (launches on one stream are ordered, so reuse is safe).
+// Split-K partial sums of tiny outputs go through a workspace the CALLER owns (srgan_set_workspace: one block per
+// (device, stream), at least srgan_workspace_bytes() long; launches on one stream are ordered, so reuse is safe).
+// The library never allocates device memory.
+constexpr size_t WORKSPACE_BYTES = (size_t)2 << 20;   // M*N < 512 outputs x at most 1024 K-slices x 4 B
+struct WorkspaceSlot { float* ptr = nullptr; size_t bytes = 0; };
+static std::mutex g_workspace_mutex;
+static std::map<std::pair<int, hipStream_t>, WorkspaceSlot> g_workspaces;
+
+int workspace_register(float* ptr, size_t bytes, hipStream_t stream) {
+  int device = 0;
+  SRGAN_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(g_workspace_mutex);
+  if (ptr == nullptr) { g_workspaces.erase({device, stream}); return SRGAN_OK; }
+  WorkspaceSlot& slot = g_workspaces[{device, stream}];
+  slot.ptr = ptr; slot.bytes = bytes;
+  return SRGAN_OK;
+}
+
 float* partial_workspace(size_t bytes, hipStream_t stream) {
-  struct Slot { float* ptr = nullptr; size_t bytes = 0; };
-  static std::map<hipStream_t, Slot> slots;
-  Slot& slot = slots[stream];
-  if (slot.bytes < bytes) {
-    if (slot.ptr) (void)hipFree(slot.ptr);          // synchronises the device: nothing still reads the old block
-    slot.ptr = nullptr; slot.bytes = 0;
-    const size_t want = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : bytes;
-    if (hipMalloc(&slot.ptr, want) != hipSuccess) { slot.ptr = nullptr; return nullptr; }
-    slot.bytes = want;
-  }
-  return slot.ptr;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_workspace_mutex);
+  auto found = g_workspaces.find({device, stream});
+  if (found == g_workspaces.end() || found->second.bytes < bytes) return nullptr;
+  return found->second.ptr;
 }
 
 // ------------------------------------------------------------------------------------------- launcher
@@ -549,49 +564,73 @@ bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
   choose_split(p, c, true);
   if (out) *out = c;
   static const bool no_partial = getenv("SRGAN_NO_PARTIAL") != nullptr;
-  p.use_partial = !no_partial && c.kind == 1 && p.split_k >= 32 && (int64_t)p.M * p.N < 512;
+  p.use_partial = !no_partial && c.kind == 1 && p.split_k >= 32 && (int64_t)p.M * p.N < 512 &&
+                  (size_t)p.M * p.N * p.split_k * sizeof(float) <= WORKSPACE_BYTES;
   return p.split_k > 1 && !p.use_partial;
 }
 
 // ---- optional live timing of every contraction launch with HIP events on the launch stream -------------------
 // (bench.py: roofline.achieved = sum of logical 2*M*N*K over launches / sum of their event-timed durations)
-struct ProfileRecord { int32_t M, N, K, kind, bm, bn, split, akf, bkf; };
+struct ProfileRecord { int32_t M, N, K, kind, bm, bn, split, akf, bkf; double bytes; };
+// Algorithmic HBM bytes of one contraction launch: every operand element once, 4 B each.  `taps` = how many times the
+// gather visits one element of the big operand (9 for a 3x3 kernel, R*S of a strided one divided over its classes).
+static double algorithmic_bytes(double M, double N, double K, int kind) {
+  if (kind == 2) return 4.0 * (M * N + M * K + (K / 9.0) * N);     // conv3x3: K = CI * 9 taps over one input plane
+  if (kind == 4) return 4.0 * (M * N + M * K + (N / 9.0) * K);     // conv3x3 weight gradient: N = CI * 9
+  return 4.0 * (M * N + M * K + K * N);
+}
 struct ProfileState {
-  bool enabled = false;
-  std::vector<hipEvent_t> events;     // pairs: start, stop
-  std::vector<ProfileRecord> records; // one per pair
-  size_t used = 0;
-  double flops = 0.0;
-  double mfma_flops = 0.0;
+  std::atomic<bool> enabled{false};
+  std::mutex mutex;                   // guards every other member (launches may come from several host threads)
+  std::vector<hipEvent_t> events;     // two per slot: start, stop
+  std::vector<ProfileRecord> records; // one per slot (M < 0: begun, not ended)
+  size_t slots = 0;
+  double flops = 0.0, mfma_flops = 0.0, bytes = 0.0;
   int64_t launches = 0;
 };
 static ProfileState g_profile;
 
 static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStream_t stream);
 
-// Event bracket for contraction kernels that live in other translation units (conv3x3.hip).
+// Event bracket around one contraction launch (also called from the other translation units).  begin() reserves a slot
+// and records its start event on the launch stream; returns -1 when profiling is off.
 int profile_bracket_begin(hipStream_t stream) {
-  if (!g_profile.enabled) return SRGAN_OK;
-  if (g_profile.used + 2 > g_profile.events.size()) {
-    for (int i = 0; i < 2; ++i) {
+  if (!g_profile.enabled.load(std::memory_order_acquire)) return -1;
+  hipEvent_t start;
+  int slot;
+  {
+    std::lock_guard<std::mutex> lock(g_profile.mutex);
+    slot = (int)g_profile.slots++;
+    while (g_profile.events.size() < 2 * g_profile.slots) {
       hipEvent_t e;
-      SRGAN_HIP(hipEventCreate(&e));
+      if (hipEventCreate(&e) != hipSuccess) { --g_profile.slots; return -1; }
       g_profile.events.push_back(e);
     }
+    g_profile.records.resize(g_profile.slots, ProfileRecord{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0});
+    start = g_profile.events[2 * slot];
   }
-  SRGAN_HIP(hipEventRecord(g_profile.events[g_profile.used], stream));
-  return SRGAN_OK;
+  if (hipEventRecord(start, stream) != hipSuccess) return -1;
+  return slot;
 }
 
-int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split) {
-  if (!g_profile.enabled) return SRGAN_OK;
-  SRGAN_HIP(hipEventRecord(g_profile.events[g_profile.used + 1], stream));
-  g_profile.used += 2;
-  g_profile.records.push_back(ProfileRecord{(int32_t)M, (int32_t)N, (int32_t)K, kind, bm, bn, split, 0, 0});
-  const double f = 2.0 * (double)M * (double)N * (double)K;
-  g_profile.flops += f;
-  g_profile.mfma_flops += f;
-  g_profile.launches += 1;
+int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split,
+                        int akf, int bkf, int64_t b_unique) {
+  if (slot < 0) return SRGAN_OK;
+  hipEvent_t stop;
+  {
+    std::lock_guard<std::mutex> lock(g_profile.mutex);
+    if ((size_t)slot >= g_profile.slots) return SRGAN_OK;          // the region was closed in between
+    stop = g_profile.events[2 * slot + 1];
+    const double f = 2.0 * (double)M * (double)N * (double)K;
+    const double bytes = b_unique > 0 ? 4.0 * ((double)M * N + (double)M * K + (double)b_unique)
+                                      : algorithmic_bytes((double)M, (double)N, (double)K, kind);
+    g_profile.records[slot] = ProfileRecord{(int32_t)M, (int32_t)N, (int32_t)K, kind, bm, bn, split, akf, bkf, bytes};
+    g_profile.flops += f;
+    if (kind != 0 && kind != 5 && kind != 9) g_profile.mfma_flops += f;      // direct / few-rows / lanes-along-K: VALU
+    g_profile.bytes += bytes;
+    g_profile.launches += 1;
+  }
+  SRGAN_HIP(hipEventRecord(stop, stream));
   return SRGAN_OK;
 }
 
@@ -661,24 +700,10 @@ static bool use_pointwise_wgrad(const ConvGeom& g, const float* x, const float* 
 }
 
 int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
-  if (!g_profile.enabled || p.M <= 0 || p.N <= 0) return gg_launch_unprofiled(p, c, stream);
-  if (g_profile.used + 2 > g_profile.events.size()) {
-    for (int i = 0; i < 2; ++i) {
-      hipEvent_t e;
-      SRGAN_HIP(hipEventCreate(&e));
-      g_profile.events.push_back(e);
-    }
-  }
-  hipEvent_t start = g_profile.events[g_profile.used], stop = g_profile.events[g_profile.used + 1];
-  SRGAN_HIP(hipEventRecord(start, stream));
+  if (p.M <= 0 || p.N <= 0) return SRGAN_OK;
+  const int slot = profile_bracket_begin(stream);
   const int status = gg_launch_unprofiled(p, c, stream);
-  SRGAN_HIP(hipEventRecord(stop, stream));
-  g_profile.used += 2;
-  g_profile.records.push_back(ProfileRecord{p.M, p.N, p.K, c.kind, c.bm, c.bn, p.split_k, p.a_kfast, p.b_kfast});
-  const double f = 2.0 * (double)p.M * (double)p.N * (double)p.K;
-  g_profile.flops += f;
-  if (c.kind == 1) g_profile.mfma_flops += f;
-  g_profile.launches += 1;
+  profile_bracket_end(slot, stream, p.M, p.N, p.K, c.kind, c.bm, c.bn, p.split_k, p.a_kfast, p.b_kfast, p.b_unique);
   return status;
 }
 
@@ -705,7 +730,8 @@ static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStrea
     SRGAN_REQUIRE(p.mode == GG_STORE || p.mode == GG_ACCUMULATE, SRGAN_EINVAL, "partial-sum launch mode");
     const int64_t mn = (int64_t)p.M * p.N;
     float* ws = partial_workspace((size_t)mn * p.split_k * sizeof(float), stream);
-    SRGAN_REQUIRE(ws != nullptr, (int)hipErrorOutOfMemory, "split-K workspace allocation");
+    SRGAN_REQUIRE(ws != nullptr, SRGAN_EINVAL,
+                  "split-K workspace: call srgan_set_workspace(ptr, >= srgan_workspace_bytes(), stream) for this stream first");
     GatherGemm q = p;
     q.mode = GG_PARTIAL; q.partial = ws; q.use_partial = 0;
     const int status = gg_launch_unprofiled(q, c, stream);
@@ -760,14 +786,25 @@ static bool to_geom(const srgan_conv_desc* d, ConvGeom& g) {
   return geom_ok(g);
 }
 
+// Descriptor -> geometry with the two failure classes kept apart: a malformed descriptor (-1) and one whose tensors pass
+// the 2^31-element limit of the 32-bit offsets (-3, with the extent in the message so that the caller can split the batch).
+#define SRGAN_GEOM(desc, g, what)                                                                        \
+  do {                                                                                                   \
+    SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, what " geometry");                                     \
+    if (geom_largest_extent(g) >= ((int64_t)1 << 31)) {                                                  \
+      set_error(what ": a tensor of %lld elements (batch %d) exceeds the 2^31 - 1 element limit",       \
+                (long long)geom_largest_extent(g), (int)g.N);                                            \
+      return SRGAN_ERANGE;                                                                               \
+    }                                                                                                    \
+  } while (0)
+
 const char* srgan_last_error(void) { return last_error(); }
 
 int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w, const float* bias, float* y,
                      int force_kernel, void* stream) {
   ConvGeom g;
-  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_fwd geometry");
+  SRGAN_GEOM(desc, g, "srgan_conv2d_fwd");
   SRGAN_REQUIRE(x && w && y, SRGAN_EINVAL, "srgan_conv2d_fwd pointers");
-  SRGAN_REQUIRE(g.y_bs == (int64_t)g.K * g.OH * g.OW || true, SRGAN_EINVAL, "");
   if (use_pointwise(g, g.K, force_kernel) && ((uintptr_t)w & 15) == 0 &&
       pointwise_ksplit_wanted(g.N, g.C, g.K, g.H * g.W, false))
     return pointwise_ksplit_run(x, g.x_bs, w, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream, nullptr);
@@ -798,7 +835,7 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
 int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const float* w, const float* bias,
                           float* gx, int accumulate, int force_kernel, void* stream) {
   ConvGeom g;
-  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_data geometry");
+  SRGAN_GEOM(desc, g, "srgan_conv2d_bwd_data");
   SRGAN_REQUIRE(gy && w && gx, SRGAN_EINVAL, "srgan_conv2d_bwd_data pointers");
   SRGAN_REQUIRE(g.x_bs == (int64_t)g.C * g.H * g.W, SRGAN_EUNSUPPORTED, "srgan_conv2d_bwd_data dense gx");
   if (use_pointwise(g, g.C, force_kernel))   // the data gradient of a 1x1 convolution is the 1x1 convolution with W^T
@@ -814,7 +851,7 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
 int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const float* gy, float* gw,
                             int accumulate, int force_kernel, void* stream) {
   ConvGeom g;
-  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_weight geometry");
+  SRGAN_GEOM(desc, g, "srgan_conv2d_bwd_weight");
   SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
   if (use_pointwise_wgrad(g, x, gy, force_kernel))
     return pointwise_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, accumulate, (hipStream_t)stream);
@@ -831,7 +868,7 @@ static bool bn_ok(const srgan_bn_relu* bn) { return bn && bn->mean && bn->inv_st
 
 int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
   ConvGeom g;
-  if (!to_geom(desc, g)) return 0;
+  if (!to_geom(desc, g) || geom_largest_extent(g) >= ((int64_t)1 << 31)) return 0;
   if (pass == 0) {
     if (pointwise(g)) return use_pointwise(g, g.K, 0) ? 1 : 0;
     return (use_conv3x3(g, g.K, 0) && g.C <= 512) ? 1 : 0;
@@ -852,7 +889,7 @@ int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
 static int fwd_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* w, const float* bias,
                       float* y, int y_state, int* plan_only_split, void* stream) {
   ConvGeom g;
-  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu geometry");
+  SRGAN_GEOM(desc, g, "srgan_conv2d_fwd_bnrelu");
   SRGAN_REQUIRE(plan_only_split || (x && w && y && bn_ok(bn)), SRGAN_EINVAL, "srgan_conv2d_fwd_bnrelu pointers");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 0), SRGAN_EUNSUPPORTED, "srgan_conv2d_fwd_bnrelu geometry support");
   const float* const coefficients[4] = {bn ? bn->mean : nullptr, bn ? bn->inv_std : nullptr, bn ? bn->gamma : nullptr,
@@ -889,7 +926,7 @@ int srgan_conv2d_fwd_bnrelu_splits(const srgan_conv_desc* desc) {
 int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
                                  const float* x, float* gx, float* g_gamma, float* g_beta, int accumulate, void* stream) {
   ConvGeom g;
-  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_data_bnrelu geometry");
+  SRGAN_GEOM(desc, g, "srgan_conv2d_bwd_data_bnrelu");
   SRGAN_REQUIRE(gy && w && x && gx && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_bwd_data_bnrelu pointers");
   SRGAN_REQUIRE((g_gamma == nullptr) == (g_beta == nullptr), SRGAN_EINVAL,
                 "srgan_conv2d_bwd_data_bnrelu parameter gradients (both or neither)");
@@ -910,7 +947,7 @@ int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, c
 int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,
                                    float* gw, int accumulate, void* stream) {
   ConvGeom g;
-  SRGAN_REQUIRE(to_geom(desc, g), SRGAN_EINVAL, "srgan_conv2d_bwd_weight_bnrelu geometry");
+  SRGAN_GEOM(desc, g, "srgan_conv2d_bwd_weight_bnrelu");
   SRGAN_REQUIRE(x && gy && gw && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_bwd_weight_bnrelu pointers");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 2), SRGAN_EUNSUPPORTED,
                 "srgan_conv2d_bwd_weight_bnrelu geometry support");
@@ -924,22 +961,24 @@ int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, 
 }
 
 int srgan_profile_begin(void) {
-  g_profile.enabled = true;
-  g_profile.used = 0;
+  std::lock_guard<std::mutex> lock(g_profile.mutex);
+  g_profile.slots = 0;
   g_profile.records.clear();
-  g_profile.flops = 0.0;
-  g_profile.mfma_flops = 0.0;
+  g_profile.flops = g_profile.mfma_flops = g_profile.bytes = 0.0;
   g_profile.launches = 0;
+  g_profile.enabled.store(true, std::memory_order_release);
   return SRGAN_OK;
 }
 
 int srgan_profile_end(double* kernel_ms, double* flops, double* mfma_flops, int64_t* launches) {
-  g_profile.enabled = false;
+  g_profile.enabled.store(false, std::memory_order_release);
+  std::lock_guard<std::mutex> lock(g_profile.mutex);
   double total = 0.0;
-  for (size_t i = 0; i + 1 < g_profile.used; i += 2) {
-    SRGAN_HIP(hipEventSynchronize(g_profile.events[i + 1]));
+  for (size_t i = 0; i < g_profile.slots; ++i) {
+    if (g_profile.records[i].M < 0) continue;
+    SRGAN_HIP(hipEventSynchronize(g_profile.events[2 * i + 1]));
     float ms = 0.f;
-    SRGAN_HIP(hipEventElapsedTime(&ms, g_profile.events[i], g_profile.events[i + 1]));
+    SRGAN_HIP(hipEventElapsedTime(&ms, g_profile.events[2 * i], g_profile.events[2 * i + 1]));
     total += ms;
   }
   if (kernel_ms) *kernel_ms = total;
@@ -949,27 +988,38 @@ int srgan_profile_end(double* kernel_ms, double* flops, double* mfma_flops, int6
   return SRGAN_OK;
 }
 
-// Per-shape breakdown of the last profiled region as text lines "M N K kind bm bn split akf bkf count ms"
-// (tuning aid; call after srgan_profile_end).  Returns the number of bytes needed.
+int srgan_profile_bytes(double* algorithmic_bytes_total) {
+  std::lock_guard<std::mutex> lock(g_profile.mutex);
+  if (algorithmic_bytes_total) *algorithmic_bytes_total = g_profile.bytes;
+  return SRGAN_OK;
+}
+
+// Per-shape breakdown of the last profiled region as text lines "M N K kind bm bn split akf bkf count ms bytes"
+// (kind: 0 direct, 1 gg_mfma, 2 conv3x3_lds, 3 pointwise, 4 conv3x3_wgrad, 5 gg_rows, 6 pointwise_wgrad,
+// 8 pointwise_ksplit, 9 gg_dot; bytes = algorithmic HBM bytes of all `count` launches; call after srgan_profile_end).
+// Returns the number of bytes needed.
 int64_t srgan_profile_report(char* buffer, int64_t capacity) {
   struct Key { int32_t v[9]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
-  struct Acc { int64_t count = 0; double ms = 0.0; };
+  struct Acc { int64_t count = 0; double ms = 0.0, bytes = 0.0; };
   std::map<Key, Acc> table;
-  for (size_t i = 0; i < g_profile.records.size(); ++i) {
+  std::lock_guard<std::mutex> lock(g_profile.mutex);
+  for (size_t i = 0; i < g_profile.slots; ++i) {
     const ProfileRecord& r = g_profile.records[i];
+    if (r.M < 0) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, g_profile.events[2 * i], g_profile.events[2 * i + 1]) != hipSuccess) continue;
     Key k{{r.M, r.N, r.K, r.kind, r.bm, r.bn, r.split, r.akf, r.bkf}};
     Acc& a = table[k];
     a.count += 1;
     a.ms += ms;
+    a.bytes += r.bytes;
   }
   std::string out;
-  char line[160];
+  char line[200];
   for (const auto& kv : table) {
     const int32_t* v = kv.first.v;
-    snprintf(line, sizeof(line), "%d %d %d %d %d %d %d %d %d %lld %.4f\n", v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7],
-             v[8], (long long)kv.second.count, kv.second.ms);
+    snprintf(line, sizeof(line), "%d %d %d %d %d %d %d %d %d %lld %.4f %.0f\n", v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7],
+             v[8], (long long)kv.second.count, kv.second.ms, kv.second.bytes);
     out += line;
   }
   if (buffer && capacity > 0) {
@@ -978,6 +1028,41 @@ int64_t srgan_profile_report(char* buffer, int64_t capacity) {
     buffer[n] = 0;
   }
   return (int64_t)out.size() + 1;
+}
+
+// ---- caller-owned workspace, capabilities -----------------------------------------------------------------------
+int64_t srgan_workspace_bytes(void) { return (int64_t)WORKSPACE_BYTES; }
+
+int srgan_set_workspace(void* workspace, int64_t bytes, void* stream) {
+  SRGAN_REQUIRE(workspace == nullptr || bytes >= (int64_t)WORKSPACE_BYTES, SRGAN_EINVAL,
+                "srgan_set_workspace: at least srgan_workspace_bytes() bytes");
+  SRGAN_REQUIRE(((uintptr_t)workspace & 15) == 0, SRGAN_EINVAL, "srgan_set_workspace: 16-byte alignment");
+  return workspace_register((float*)workspace, (size_t)(bytes > 0 ? bytes : 0), (hipStream_t)stream);
+}
+
+struct srgan_capabilities_t {
+  int32_t abi_version;         // = srgan_version()
+  int32_t struct_bytes;        // sizeof(this struct) as the library knows it
+  char arch[16];               // "gfx950"
+  uint32_t dtypes;             // bit 0: fp32 (the parity path)
+  uint32_t features;           // SRGAN_FEATURE_* bits
+  int64_t workspace_bytes;     // = srgan_workspace_bytes()
+  int64_t max_tensor_elements; // 2^31 - 1
+};
+
+int srgan_capabilities(srgan_capabilities_t* out, int32_t out_bytes) {
+  SRGAN_REQUIRE(out != nullptr && out_bytes >= (int32_t)sizeof(srgan_capabilities_t), SRGAN_EINVAL,
+                "srgan_capabilities: output struct");
+  memset(out, 0, sizeof(*out));
+  out->abi_version = 100;
+  out->struct_bytes = (int32_t)sizeof(*out);
+  snprintf(out->arch, sizeof(out->arch), "gfx950");
+  out->dtypes = 1u;
+  out->features = 0x1u /* fused batch-norm + relu prologues / epilogues */ | 0x2u /* split-K through a workspace */ |
+                  0x4u /* live event profile of the contraction launches */;
+  out->workspace_bytes = (int64_t)WORKSPACE_BYTES;
+  out->max_tensor_elements = ((int64_t)1 << 31) - 1;
+  return SRGAN_OK;
 }
 
 int srgan_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,

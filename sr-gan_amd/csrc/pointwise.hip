@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __r
 }
 
 int profile_bracket_begin(hipStream_t stream);
-int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
 float* partial_workspace(size_t bytes, hipStream_t stream);
 
 // g_beta[c] += sum_t partial[0][t][c];  g_gamma[c] += inv_std[c] * sum_t partial[1][t][c]   (t = workgroup tiles)
@@ -510,7 +511,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   static const bool narrow = getenv("SRGAN_PW_NARROW_OUT") != nullptr;
   p.wide_out = (!narrow && (((uintptr_t)out & 15) | (out_bs & 3) | (HW & 3)) == 0) ? 1 : 0;
   p.gpi = (HW + 32 * ni - 1) / (32 * ni);
-  profile_bracket_begin(stream);
+  const int profile_slot = profile_bracket_begin(stream);
   // (K slices of 64 measured no faster and spill at 128 rows: the slice is 32 channels.)
   auto launch = [&](int mi_, dim3 grid) {
     if (ni == 2) launch_pointwise<2, 32, 2>(p, grid, stream);
@@ -529,7 +530,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   }
   if (p.epi_partial) bn_partial_reduce_run(p.epi_partial, (int)col_blocks, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
-  profile_bracket_end(stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);
+  profile_bracket_end(profile_slot, stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);
   return status;
 }
 

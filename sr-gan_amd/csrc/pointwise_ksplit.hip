@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
 }
 
 int profile_bracket_begin(hipStream_t stream);
-int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
 
 bool pointwise_ksplit_enabled() {
   static const bool disabled = getenv("SRGAN_NO_PW_KSPLIT") != nullptr;
@@ -175,11 +176,11 @@ int pointwise_ksplit_run(const float* in, int64_t in_bs, const float* w, const f
   SRGAN_REQUIRE(groups < ((int64_t)1 << 31) && tiles_m <= 65535, SRGAN_ERANGE, "pointwise (K split over waves) grid");
   SRGAN_REQUIRE(K % 32 == 0 && (((uintptr_t)w) & 15) == 0, SRGAN_EINVAL, "pointwise (K split over waves) weights");
   dim3 grid((unsigned)groups, (unsigned)tiles_m, 1);
-  profile_bracket_begin(stream);
+  const int profile_slot = profile_bracket_begin(stream);
   if (bn) hipLaunchKernelGGL(pointwise_ksplit_kernel<true>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(pointwise_ksplit_kernel<false>, grid, dim3(256), 0, stream, p);
   const int status = launch_status();
-  profile_bracket_end(stream, M, (int64_t)N * HW, K, 8, PKS_MI * 32, 32, 4);
+  profile_bracket_end(profile_slot, stream, M, (int64_t)N * HW, K, 8, PKS_MI * 32, 32, 4);
   return status;
 }
 

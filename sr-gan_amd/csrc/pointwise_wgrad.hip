@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradPa
 }
 
 int profile_bracket_begin(hipStream_t stream);
-int profile_bracket_end(hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split);
+int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
 
 // The un-fused weight gradient stays on the generic gather-GEMM by default (measured equal: both are bound by the
 // operand stream at 64 x 64 tiles); this kernel serves the fused batch-norm form, where the generic one cannot.
@@ -203,11 +204,11 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
   p.mode = split > 1 ? 2 : 1;
   if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)CO * CI * sizeof(float), stream));
   dim3 grid((unsigned)tiles, (unsigned)split, 1);
-  profile_bracket_begin(stream);
+  const int profile_slot = profile_bracket_begin(stream);
   if (bn) hipLaunchKernelGGL(pointwise_wgrad_kernel<true>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(pointwise_wgrad_kernel<false>, grid, dim3(256), 0, stream, p);
   const int status = launch_status();
-  profile_bracket_end(stream, CO, CI, (int64_t)N * HW, 6, PWG_MI * 32, PWG_NI * 32, split);
+  profile_bracket_end(profile_slot, stream, CO, CI, (int64_t)N * HW, 6, PWG_MI * 32, PWG_NI * 32, split);
   return status;
 }
 

@@ -16,7 +16,7 @@ class DnnExperiment(Experiment, ABC):
     """A trial with only a DNN."""
 
     def prepare_summary_writers(self):
-        self.dnn_summary_writer = SummaryWriter(os.path.join(self.trial_directory, 'DNN'))
+        self.dnn_summary_writer = SummaryWriter(self.summary_directory('DNN'))
         self.dnn_summary_writer.summary_period = self.settings.summary_step_period
         self.dnn_summary_writer.steps_to_run = self.settings.steps_to_run
 

@@ -21,7 +21,7 @@ FORCE_KERNEL = 0   # tests set 1 (direct) / 2 (MFMA) to cross-check the two cont
 
 # ------------------------------------------------------------------------------------------- plumbing
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.stream_handle()
 
 
 def _ptr(x):

@@ -160,7 +160,7 @@ def dense_block(x, layers):
         overlap = WGRAD_STREAM and want_params and prologue and not recorded
         if overlap:
             main, side = torch.cuda.current_stream(device), _side_stream(device)
-            wstream = side.cuda_stream
+            wstream = _lib.stream_handle(side)
             alive = []                            # tensors the side stream still reads
         else:
             wstream = stream

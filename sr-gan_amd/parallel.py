@@ -10,7 +10,11 @@ reference's arithmetic.  Everything is expressed as SUMs:
   identity on the local sum (every rank already holds dL/d(mean));
 * per-example means (labeled loss, gradient penalty) are local sums / global batch;
 * backward: all-reduce(sum) of each network's flat gradient arena, in large buckets (xGMI is point-to-point,
-  7 links x ~153 GB/s per GPU: few large messages, not one per tensor).
+  7 links x ~153 GB/s per GPU: few large messages, not one per tensor), ASYNCHRONOUSLY: ``GradientExchange`` starts a
+  bucket as soon as the last backward pass of the step can no longer touch it (the tape reports the frontier,
+  ``tape.backward(..., grad_ready=...)``), so the collectives run under the rest of that backward pass and under
+  whatever the step does next; the optimizer update waits for them only when the weights are needed again
+  (``Experiment.finish_update``).
 
 The same object drives the CPU oracle over gloo in the world-size-2 tests (it only needs tensors).
 """
@@ -19,7 +23,49 @@ import os
 import torch
 import torch.distributed as dist
 
-BUCKET_ELEMENTS = 32 * 1024 * 1024     # 128 MiB fp32 per all-reduce call
+BUCKET_ELEMENTS = 32 * 1024 * 1024     # 128 MiB fp32 per all-reduce call at most
+MIN_BUCKET_ELEMENTS = 2 * 1024 * 1024  # start a bucket once >= 8 MiB of the arena is final (below that a ring all-reduce
+#                                        over xGMI is latency-bound; the remainder goes out with finish())
+
+
+class GradientExchange:
+    """Asynchronous all-reduce(sum) of one flat gradient buffer, from its END towards its start.
+
+    Parameters sit in the arena in forward order, so the backward pass finishes the tail first: ``ready_from(o)``
+    declares every element at or after offset ``o`` final and starts buckets over the part not yet sent;
+    ``finish()`` sends the remainder; ``wait()`` makes the current stream (NCCL) / the host (gloo) wait for all of
+    them.  Every rank makes the same calls with the same offsets (they run the same graph), so the collectives match."""
+
+    def __init__(self, dp, flat, bucket_elements=BUCKET_ELEMENTS, min_bucket_elements=MIN_BUCKET_ELEMENTS):
+        self.dp, self.flat = dp, flat
+        self.bucket, self.min_bucket = bucket_elements, min_bucket_elements
+        self.sent_from = flat.numel()       # [sent_from, numel) is already on its way
+        self.works = []
+        self.launched = []                  # (start, stop) of every bucket, in launch order (tests / diagnostics)
+
+    def _send(self, start, stop):
+        while stop > start:
+            first = max(start, stop - self.bucket)
+            self.works.append(dist.all_reduce(self.flat[first:stop], op=dist.ReduceOp.SUM, group=self.dp.group,
+                                              async_op=True))
+            self.launched.append((first, stop))
+            stop = first
+        self.sent_from = min(self.sent_from, start)
+
+    def ready_from(self, offset):
+        offset = max(0, min(int(offset), self.sent_from))
+        if self.sent_from - offset >= self.min_bucket:
+            self._send(offset, self.sent_from)
+
+    def finish(self):
+        if self.sent_from > 0:
+            self._send(0, self.sent_from)
+        return self
+
+    def wait(self):
+        for work in self.works:
+            work.wait()
+        self.works = []
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -100,10 +146,20 @@ class DataParallel:
         return out
 
     def all_reduce_gradients(self, arena):
-        """Sum the flat gradient arena over ranks in 128 MiB buckets."""
-        grad = arena.grad
-        for start in range(0, grad.numel(), BUCKET_ELEMENTS):
-            dist.all_reduce(grad[start:start + BUCKET_ELEMENTS], op=dist.ReduceOp.SUM, group=self.group)
+        """Sum the flat gradient arena over ranks in 128 MiB buckets (blocking form)."""
+        self.gradient_exchange(arena).finish().wait()
+
+    def gradient_exchange(self, arena):
+        """A fresh asynchronous exchange of ``arena.grad`` (see GradientExchange)."""
+        return GradientExchange(self, arena.grad)
+
+    def broadcast_object(self, value, source=0):
+        """A small picklable host object from rank ``source`` to every rank (trial directory, stdin commands)."""
+        holder = [value if self.rank == source else None]
+        dist.broadcast_object_list(holder, src=source, group=self.group,
+                                   device=torch.device('cuda', torch.cuda.current_device())
+                                   if dist.get_backend(self.group) == 'nccl' else None)
+        return holder[0]
 
     def broadcast_parameters(self, arena, source=0):
         """Make every rank start from rank ``source``'s weights."""

@@ -4,7 +4,9 @@ hyper-parameters run.py:28-70, trial naming :85-105, the settings grid loop :108
     python -m torch.distributed.run --nproc-per-node 8 -m srgan_amd.run      (or plain ``python -m srgan_amd.run``)
 
 Application / method default to the reference's (age, srgan); override with SRGAN_APPLICATION / SRGAN_METHOD /
-SRGAN_STEPS for smoke runs (additive: the reference has no argv/env handling)."""
+SRGAN_STEPS / SRGAN_BATCH_SIZE for smoke runs (additive: the reference has no argv/env handling).  Under
+torch.distributed.run ``batch_size`` is the GLOBAL batch and must be divisible by the number of ranks (the crowd
+default of 15 is not divisible by 8: set SRGAN_BATCH_SIZE=16); ``Experiment.train`` checks it."""
 import os
 
 from .age.sgan import AgeSganExperiment
@@ -60,6 +62,8 @@ def build_settings(application_name, method_name):
     settings_ = Settings()
     overrides = dict(APPLICATION_SETTINGS[application_name], **COMMON_SETTINGS)
     overrides['steps_to_run'] = int(os.environ.get('SRGAN_STEPS', 100000))
+    if os.environ.get('SRGAN_BATCH_SIZE'):
+        overrides['batch_size'] = int(os.environ['SRGAN_BATCH_SIZE'])
     for name, value in overrides.items():
         setattr(settings_, name, value)
     settings_.local_setup()

@@ -11,7 +11,11 @@ Differences from the reference that are deliberate (each keeps results identical
 * the discriminator's weight gradients are not computed during the generator update (the reference computes
   and discards them, srgan.py:304 then :278).
 * one process per GPU: an optional data-parallel context shards the three batches and exchanges feature
-  sums and gradients over RCCL (``parallel.py``).
+  sums and gradients over RCCL (``parallel.py``).  The gradient all-reduces are asynchronous: each starts during the
+  last backward pass into its network's arena (reference srgan.py:264 for the DNN, :295 for D, :304 for G are where those
+  gradients complete) and the optimizer update that needs it is applied when the weights are next used
+  (``finish_update``): the DNN's exchange runs under the whole GAN step, D's under the generator forward, G's under
+  the next iteration's DNN step.  The arithmetic is unchanged.
 """
 import datetime
 import os
@@ -24,6 +28,7 @@ import numpy as np
 import torch
 from scipy.stats import norm
 
+from . import _lib
 from . import functional as F
 from . import nn
 from .optim import Adam
@@ -77,29 +82,52 @@ class Experiment(ABC):
         self.gradient_norm = None
 
         self.dp = None                 # optional parallel.DataParallel context
+        self._pending_updates = {}     # network name -> (gradient exchange in flight, optimizer to step after it)
         self.injected_draws = None     # tests: dict with 'z_d', 'z_g', 'alpha' device/CPU tensors, used once
         self.last_losses = {}          # device scalars of the latest step (no host sync)
 
     # ------------------------------------------------------------------------------------------ lifecycle
+    def _trial_decision(self):
+        """What reference srgan.py:54-70 decides from the file system before a trial starts: skip it, its (unique)
+        directory, and where to load a model from.  Taken on rank 0 only and broadcast, so that every rank of a
+        data-parallel run trains the same trial from the same checkpoint."""
+        settings = self.settings
+        trial_directory = os.path.join(settings.logs_directory, settings.trial_name)
+        decision = dict(skip=False, trial_directory=trial_directory, load_model_path=settings.load_model_path,
+                        continue_existing_experiments=settings.continue_existing_experiments)
+        if (settings.skip_completed_experiment and os.path.exists(trial_directory) and
+                '/check' not in trial_directory and not settings.continue_existing_experiments):
+            decision['skip'] = True
+            return decision
+        if not settings.continue_existing_experiments:
+            decision['trial_directory'] = make_directory_name_unique(trial_directory)
+        else:
+            if os.path.exists(trial_directory) and settings.load_model_path is not None:
+                raise ValueError('Cannot load from path and continue existing at the same time.')
+            elif settings.load_model_path is None:
+                decision['load_model_path'] = trial_directory
+            elif not os.path.exists(trial_directory):
+                decision['continue_existing_experiments'] = False
+        os.makedirs(os.path.join(decision['trial_directory'], settings.temporary_directory), exist_ok=True)
+        return decision
+
     def train(self):
         """Run the SRGAN training for the experiment (reference srgan.py:52-86)."""
         settings = self.settings
-        self.trial_directory = os.path.join(settings.logs_directory, settings.trial_name)
-        if (settings.skip_completed_experiment and os.path.exists(self.trial_directory) and
-                '/check' not in self.trial_directory and not settings.continue_existing_experiments):
+        parallel = self.dp is not None and self.dp.world_size > 1
+        if parallel and settings.batch_size % self.dp.world_size:
+            raise ValueError(f'batch_size {settings.batch_size} is the GLOBAL batch and must be divisible by the '
+                             f'{self.dp.world_size} data-parallel ranks')
+        decision = self._trial_decision() if not parallel or self.dp.rank == 0 else None
+        if parallel:
+            decision = self.dp.broadcast_object(decision)
+        self.trial_directory = decision['trial_directory']
+        if decision['skip']:
             print('`{}` experiment already exists. Skipping...'.format(self.trial_directory))
             return
-        if not settings.continue_existing_experiments:
-            self.trial_directory = make_directory_name_unique(self.trial_directory)
-        else:
-            if os.path.exists(self.trial_directory) and settings.load_model_path is not None:
-                raise ValueError('Cannot load from path and continue existing at the same time.')
-            elif settings.load_model_path is None:
-                settings.load_model_path = self.trial_directory
-            elif not os.path.exists(self.trial_directory):
-                settings.continue_existing_experiments = False
+        settings.load_model_path = decision['load_model_path']
+        settings.continue_existing_experiments = decision['continue_existing_experiments']
         print(self.trial_directory)
-        os.makedirs(os.path.join(self.trial_directory, settings.temporary_directory), exist_ok=True)
         self.prepare_summary_writers()
         seed_all(0)
 
@@ -108,6 +136,10 @@ class Experiment(ABC):
         self.gpu_mode()              # parameters move into flat device arenas before the optimizers bind
         self.prepare_optimizers()
         self.load_models()
+        if parallel:                 # every rank starts from rank 0's weights (and the checkpoint it may have loaded)
+            for module in (self.D, self.DNN, self.G):
+                if module is not None and getattr(module, '_srgan_arena', None) is not None:
+                    self.dp.broadcast_parameters(module._srgan_arena)
         self.train_mode()
 
         self.training_loop()
@@ -121,7 +153,7 @@ class Experiment(ABC):
 
     def save_models(self, step):
         """One torch.save dict with the reference's keys (srgan.py:88-97); written by rank 0 only."""
-        self.join_dnn_stream()
+        self.join_dnn_stream()         # also applies optimizer updates still waiting for their gradient exchange
         if self.dp is not None and self.dp.rank != 0:
             return
         model = {'step': step}
@@ -177,32 +209,56 @@ class Experiment(ABC):
         self.g_optimizer = Adam(self.G._srgan_arena, lr=d_lr)
         self.dnn_optimizer = Adam(self.DNN._srgan_arena, lr=d_lr, weight_decay=weight_decay)
 
+    def summary_directory(self, name):
+        """Rank 0 writes the trial's event files; the other ranks of a data-parallel run log in memory only."""
+        if self.dp is not None and self.dp.rank != 0:
+            return None
+        return os.path.join(self.trial_directory, name)
+
     def prepare_summary_writers(self):
-        self.dnn_summary_writer = SummaryWriter(os.path.join(self.trial_directory, 'DNN'))
-        self.gan_summary_writer = SummaryWriter(os.path.join(self.trial_directory, 'GAN'))
+        self.dnn_summary_writer = SummaryWriter(self.summary_directory('DNN'))
+        self.gan_summary_writer = SummaryWriter(self.summary_directory('GAN'))
         for writer in (self.dnn_summary_writer, self.gan_summary_writer):
             writer.summary_period = self.settings.summary_step_period
             writer.steps_to_run = self.settings.steps_to_run
 
-    def handle_user_input(self, step):
-        """'save' / 'quit' typed on stdin, polled without blocking (reference srgan.py:149-163); rank 0 only."""
-        if self.dp is not None and self.dp.rank != 0:
-            return
+    USER_INPUT_EXCHANGE_PERIOD = 50     # data-parallel runs agree on typed commands every this many steps
+
+    def _poll_stdin(self):
+        """'save' / 'quit' typed on stdin since the last poll, without blocking (reference srgan.py:149-163)."""
+        commands = set()
         try:
             ready = sys.stdin in select.select([sys.stdin], [], [], 0)[0]
         except (ValueError, OSError):
-            return
+            return commands
         while ready:
             line = sys.stdin.readline()
             if not line:
                 break
-            if 'save' in line:
-                self.save_models(step)
-                print('\rSaved model for step {}...'.format(step))
-            if 'quit' in line:
-                self.signal_quit = True
-                print('\rQuit requested after current experiment...')
+            commands.update(word for word in ('save', 'quit') if word in line)
             ready = sys.stdin in select.select([sys.stdin], [], [], 0)[0]
+        return commands
+
+    def handle_user_input(self, step):
+        """Acts on 'save' / 'quit' (reference srgan.py:149-163).  Under data parallelism rank 0 reads stdin and the ranks
+        exchange what it saw every ``USER_INPUT_EXCHANGE_PERIOD`` steps, so that all of them save / stop together
+        (one rank leaving the loop alone would leave the others hanging in their next collective)."""
+        parallel = self.dp is not None and self.dp.world_size > 1
+        if not parallel:
+            commands = self._poll_stdin()
+        else:
+            if self.dp.rank == 0:
+                self._typed_commands = getattr(self, '_typed_commands', set()) | self._poll_stdin()
+            if step % self.USER_INPUT_EXCHANGE_PERIOD != 0 and step != self.settings.steps_to_run - 1:
+                return
+            commands = self.dp.broadcast_object(sorted(getattr(self, '_typed_commands', set())))
+            self._typed_commands = set()
+        if 'save' in commands:
+            self.save_models(step)
+            print('\rSaved model for step {}...'.format(step))
+        if 'quit' in commands:
+            self.signal_quit = True
+            print('\rQuit requested after current experiment...')
 
     def train_mode(self):
         for module in (self.D, self.DNN, self.G):
@@ -268,20 +324,28 @@ class Experiment(ABC):
             return value
         return None
 
+    def _global_draw(self, local_batch, draw):
+        """Under data parallelism every rank draws the tensor for the GLOBAL batch from its (identically seeded) host
+        stream and keeps its own shard: the ranks' examples differ, and together they are exactly what the
+        single-device reference draws at the global batch size."""
+        if self.dp is None or self.dp.world_size == 1:
+            return draw(local_batch)
+        return self.dp.shard(draw(self.dp.global_batch(local_batch)))
+
     def sample_discriminator_noise(self, batch_size):
         """float64 two-Gaussian mixture from NumPy's global stream cast to float32 (srgan.py:286-289)."""
         z = self._take_draw('z_d')
         if z is None:
             offset = self.settings.mean_offset
-            z = torch.tensor(MixtureModel([norm(-offset, 1), norm(offset, 1)]).rvs(
-                size=[batch_size, self.G.input_size]).astype(np.float32))
+            z = self._global_draw(batch_size, lambda count: torch.tensor(
+                MixtureModel([norm(-offset, 1), norm(offset, 1)]).rvs(size=[count, self.G.input_size]).astype(np.float32)))
         return as_var(z)
 
     def sample_generator_noise(self, batch_size):
         """N(0, 1) from torch's CPU stream (srgan.py:301)."""
         z = self._take_draw('z_g')
         if z is None:
-            z = torch.randn(batch_size, self.G.input_size)
+            z = self._global_draw(batch_size, lambda count: torch.randn(count, self.G.input_size))
         return as_var(z)
 
     def sample_interpolation_alpha(self, batch_size):
@@ -289,7 +353,7 @@ class Experiment(ABC):
         across devices; here it comes from torch's CPU stream and is copied over."""
         alpha = self._take_draw('alpha')
         if alpha is None:
-            alpha = torch.rand(batch_size)
+            alpha = self._global_draw(batch_size, lambda count: torch.rand(count))
         return as_var(alpha.reshape(-1))
 
     # ------------------------------------------------------------------------------------------ batch reductions
@@ -334,20 +398,63 @@ class Experiment(ABC):
             self._dnn_stream = torch.cuda.Stream()
         return self._dnn_stream
 
-    def join_dnn_stream(self):
-        """Make the current stream wait for an enqueued DNN step (no-op without one)."""
+    def _join_side_stream(self):
         stream = getattr(self, '_dnn_stream', None)
         if stream is not None:
             torch.cuda.current_stream().wait_stream(stream)
 
+    def join_dnn_stream(self):
+        """Settle the networks before anything outside the training step reads them: the current stream waits for an
+        enqueued DNN step, and optimizer updates still waiting for their gradient exchange are applied."""
+        self.finish_update()
+        self._join_side_stream()
+
+    # ---- data-parallel gradient exchange, overlapped with the step (no-ops on one device) ----------------------
+    def gradient_exchange(self, module):
+        """The asynchronous all-reduce of ``module``'s gradient arena for the LAST backward pass into it (handed to
+        ``tape.backward(grad_ready=...)``); None on a single device."""
+        if self.dp is None or self.dp.world_size == 1:
+            return None
+        return self.dp.gradient_exchange(module._srgan_arena)
+
+    def start_update(self, name, optimizer, exchange):
+        """The optimizer step of network ``name``: at once on a single device; under data parallelism after its gradient
+        exchange, i.e. in ``finish_update`` -- the rest of the arena goes out now and the step continues meanwhile."""
+        if exchange is None:
+            optimizer.step()
+            return
+        exchange.finish()
+        if not getattr(self.settings, 'overlap_gradient_exchange', True):
+            exchange.wait()
+            optimizer.step()
+            return
+        self._pending_updates[name] = (exchange, optimizer)
+
+    def finish_update(self, *names):
+        """Wait for the gradient exchange of the named networks (default: all) and apply their optimizer updates."""
+        for name in (names or tuple(self._pending_updates)):
+            pending = self._pending_updates.pop(name, None)
+            if pending is None:
+                continue
+            exchange, optimizer = pending
+            side = self._dnn_side_stream() if name == 'DNN' else None
+            if side is not None:                    # the DNN's step and exchange live on the side stream
+                with torch.cuda.stream(side):
+                    exchange.wait()
+                    optimizer.step()
+            else:
+                exchange.wait()
+                optimizer.step()
+
     def _dnn_training_step(self, examples, labels, step):
         self.DNN.apply(disable_batch_norm_updates)
         self.dnn_summary_writer.step = step
+        self.finish_update('DNN')
         self.dnn_optimizer.zero_grad()
         dnn_loss = self.dnn_loss_calculation(examples, labels)
-        backward(dnn_loss)
-        self.synchronize_gradients(self.DNN)
-        self.dnn_optimizer.step()
+        exchange = self.gradient_exchange(self.DNN)
+        backward(dnn_loss, grad_ready=exchange)
+        self.start_update('DNN', self.dnn_optimizer, exchange)       # finished at the end of gan_training_step
         self.last_losses['dnn_loss'] = dnn_loss
         if self.dnn_summary_writer.is_summary_step():
             self.dnn_summary_writer.add_scalar('Discriminator/Labeled Loss', self.loss_value(dnn_loss, partial=True))
@@ -362,6 +469,7 @@ class Experiment(ABC):
         unlabeled_examples = as_var(unlabeled_examples)
         self.D.apply(disable_batch_norm_updates)
         self.gan_summary_writer.step = step
+        self.finish_update('G', 'D')         # the previous iteration's generator update (its exchange ran under the DNN step)
         self.d_optimizer.zero_grad()
         batch_size = unlabeled_examples.shape[0]
         if getattr(settings, 'reference_schedule', False):
@@ -382,21 +490,23 @@ class Experiment(ABC):
                 labeled_examples, labels, unlabeled_examples, fake_examples)
             backward(F.add(F.add(labeled_loss, unlabeled_loss), fake_loss))
         gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
-        backward(gradient_penalty)
-        self.synchronize_gradients(self.D)
-        self.d_optimizer.step()
+        exchange = self.gradient_exchange(self.D)
+        backward(gradient_penalty, grad_ready=exchange)      # the last of the backward passes into D's arena (srgan.py:295)
+        self.start_update('D', self.d_optimizer, exchange)
         generator_loss = None
         if step % settings.generator_training_step_period == 0:
             self.g_optimizer.zero_grad()
             z = self.sample_generator_noise(batch_size)
-            fake_examples = self.G(z)
+            fake_examples = self.G(z)                        # runs while D's gradients are still being exchanged
+            self.finish_update('D')
             generator_loss = self.generator_loss_calculation(fake_examples, unlabeled_examples)
-            backward(generator_loss)
-            self.synchronize_gradients(self.G)
-            self.g_optimizer.step()
+            exchange = self.gradient_exchange(self.G)
+            backward(generator_loss, grad_ready=exchange)
+            self.start_update('G', self.g_optimizer, exchange)      # finished when G is next used (next iteration)
+        self.finish_update('D', 'DNN')
         self.last_losses.update(labeled_loss=labeled_loss, unlabeled_loss=unlabeled_loss, fake_loss=fake_loss,
                                 gradient_penalty=gradient_penalty, generator_loss=generator_loss)
-        self.join_dnn_stream()
+        self._join_side_stream()
         if self.gan_summary_writer.is_summary_step():
             writer = self.gan_summary_writer
             if generator_loss is not None:
@@ -421,6 +531,7 @@ class Experiment(ABC):
         return value
 
     def synchronize_gradients(self, module):
+        """Blocking form of the gradient exchange (methods that do not overlap it: the DNN-only experiment)."""
         if self.dp is not None and self.dp.world_size > 1:
             self.dp.all_reduce_gradients(module._srgan_arena)
 
@@ -431,11 +542,23 @@ class Experiment(ABC):
         three over B triples the work per kernel launch, which is what the 16x16 / 32x32 dense blocks lack."""
         settings = self.settings
         sizes = (labeled_examples.shape[0], unlabeled_examples.shape[0], fake_examples.shape[0])
-        if getattr(settings, 'batched_discriminator', True) and \
-                tuple(labeled_examples.shape[1:]) == tuple(unlabeled_examples.shape[1:]) == tuple(fake_examples.shape[1:]):
-            stacked = F.cat_rows([labeled_examples, unlabeled_examples, fake_examples.detach()])
-            predicted = self.D(stacked)
-            features = self.D.features
+        stackable = getattr(settings, 'batched_discriminator', True) and not getattr(self, '_stack_too_large', False) and \
+            tuple(labeled_examples.shape[1:]) == tuple(unlabeled_examples.shape[1:]) == tuple(fake_examples.shape[1:])
+        if stackable:
+            # Stacking triples the batch of every activation; one of them may then pass the 2^31-element limit of the
+            # kernels' 32-bit offsets although the three batches fit on their own (e.g. VGG-16 at batch 600: 1800 x 64 x
+            # 128 x 128).  The library reports that as SRGAN_ERANGE; the three separate passes are the same mathematics.
+            try:
+                stacked = F.cat_rows([labeled_examples, unlabeled_examples, fake_examples.detach()])
+                predicted = self.D(stacked)
+                features = self.D.features
+            except _lib.HipLibraryError as error:
+                if error.status != _lib.ERANGE:
+                    raise
+                print(f'stacked discriminator pass too large ({error}); using three separate passes')
+                self._stack_too_large = True
+                stackable = False
+        if stackable:
             take = lambda value, first, count: (tuple(F.narrow_rows(v, first, count) for v in value)
                                                 if isinstance(value, (tuple, list)) else F.narrow_rows(value, first, count))
             predicted_labels = take(predicted, 0, sizes[0])
@@ -606,11 +729,25 @@ class Experiment(ABC):
         """distance(mean_b(base) - mean_b(other)) (reference srgan.py:438-449)."""
         if distance_function is None:
             distance_function = self.settings.matching_distance_function
-        if self.settings.normalize_feature_norm:
-            raise NotImplementedError('normalize_feature_norm=True (off by default, and broadcasting un-meaned '
-                                      'features in the reference, srgan.py:447) is not implemented')
         base_mean_features = self.batch_mean_of_features(base_features)
         other_mean_features = self.batch_mean_of_features(other_features)
+        if self.settings.normalize_feature_norm:
+            # The reference's branch AS WRITTEN (srgan.py:444-447): the base mean is divided by its norm, but line 447
+            # divides the un-meaned ``other_features`` (B, F) by the norm of their mean, so the difference broadcasts to
+            # (B, F) and the distance function averages over examples as well.  Off by default (settings.py:39).
+            if self.dp is not None and self.dp.world_size > 1:
+                raise NotImplementedError('normalize_feature_norm=True averages over the (B, F) broadcast of the '
+                                          'reference (srgan.py:447); it is single-device only')
+            epsilon = 1e-5
+
+            def inverse_norm(vector):
+                norm = F.sqrt(F.sum_all(F.square(vector)))
+                return F.div(F.full_like(norm, 1.0), F.add_scalar(norm, epsilon))
+            base_normalized = F.scalar_mul(base_mean_features, inverse_norm(base_mean_features))
+            other_rows = F.flatten2d(other_features)
+            other_normalized = F.scalar_mul(other_rows, inverse_norm(other_mean_features))
+            difference = F.sub(F.col_broadcast(base_normalized, other_rows.shape[0]), other_normalized)
+            return distance_function(difference)
         return distance_function(F.sub(base_mean_features, other_mean_features))
 
     @property

@@ -130,8 +130,31 @@ def _relevant_set(root, inputs):
     return {key for key, value in memo.items() if value}
 
 
-def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None):
+def _frontiers(order, flat):
+    """frontier[i] = the largest end offset (in elements of the flat gradient buffer ``flat``) that node ``order[i]`` or
+    any LATER node of the sweep can still write: once the sweep has processed nodes 0..i-1, every element of ``flat``
+    at or after frontier[i] is final."""
+    base, count = flat.data_ptr(), flat.numel()
+    frontier = [0] * (len(order) + 1)
+    for i in range(len(order) - 1, -1, -1):
+        reach = frontier[i + 1]
+        node = order[i].node
+        for parent, required in zip(node.inputs, node.input_requires):
+            if not required or parent.node is not None or parent.grad_buffer is None:
+                continue
+            offset = (parent.grad_buffer.data_ptr() - base) // 4
+            if 0 <= offset < count:
+                reach = max(reach, offset + parent.grad_buffer.numel())
+        frontier[i] = reach
+    return frontier
+
+
+def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None, grad_ready=None):
     """Reverse sweep from ``root``.
+
+    ``grad_ready`` (a ``parallel.GradientExchange`` over a network's flat gradient arena; only for the LAST backward
+    pass of a step into that arena): after every node the sweep reports from which arena offset on no later node can
+    write, and the exchange starts all-reducing that tail while the sweep continues.
 
     Without ``inputs`` gradients are accumulated into the ``grad_buffer`` (parameters) or ``grad`` (other
     leaves) of every leaf that requires grad, like ``Tensor.backward``.  With ``inputs`` the gradients of
@@ -154,10 +177,13 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
     context = enable_grad() if create_graph else no_grad()
     results = {}
     wanted = {id(v): v for v in inputs} if inputs is not None else {}
+    frontier = _frontiers(order, grad_ready.flat) if grad_ready is not None else None
     with context:
         if id(root) in wanted:
             results[id(root)] = grad
-        for var in order:
+        for position, var in enumerate(order):
+            if frontier is not None:
+                grad_ready.ready_from(frontier[position])
             g = grads.pop(id(var), None)
             if g is None:
                 continue
@@ -186,6 +212,8 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
             if not retain_graph:
                 node.backward = _released
                 node.inputs = ()
+    if frontier is not None:
+        grad_ready.ready_from(0)
     if inputs is not None:
         return [results.get(id(v)) for v in inputs]
     return None

@@ -12,13 +12,13 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """Compile libsrgan_hip.so when it is MISSING (it normally arrives prebuilt with the working tree; file times do not
-    survive the copy to the GPU box, so staleness is not judged here).  hipcc cross-compiles for gfx950 without a GPU.
-    The product itself never builds on demand: it fails loudly instead."""
+    """Compile libsrgan_hip.so when it is missing or was built from other kernel sources (judged by content -- the
+    source id compiled into the library -- because file times do not survive the copy to the GPU box).  hipcc
+    cross-compiles for gfx950 without a GPU.  The product itself never builds on demand: it fails loudly instead."""
     try:
         import srgan_amd  # noqa: F401
         from srgan_amd import _build
-        if not os.path.exists(_build.LIBRARY):
+        if not _build.is_current():
             _build.build()
     except Exception as error:           # the tests that need the library then report the real problem
         print(f'[conftest] could not build libsrgan_hip.so: {error}', file=sys.stderr)

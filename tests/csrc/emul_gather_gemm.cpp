@@ -30,7 +30,7 @@ extern "C" {
 
 int emul_conv2d_fwd(const ConvGeom* geom, const float* x, const float* w, const float* bias, float* y) {
   ConvGeom g = *geom;
-  if (!geom_ok(g)) return -1;
+  if (!geom_ok(g) || geom_largest_extent(g) >= ((int64_t)1 << 31)) return -1;
   run(plan_conv_fwd(g, x, w, bias, y));
   return 0;
 }
@@ -38,7 +38,7 @@ int emul_conv2d_fwd(const ConvGeom* geom, const float* x, const float* w, const 
 int emul_conv2d_bwd_data(const ConvGeom* geom, const float* gy, const float* w, const float* bias, float* gx,
                          int accumulate) {
   ConvGeom g = *geom;
-  if (!geom_ok(g)) return -1;
+  if (!geom_ok(g) || geom_largest_extent(g) >= ((int64_t)1 << 31)) return -1;
   std::vector<GatherGemm> plans = plan_conv_bwd_data(g, gy, w, bias, gx);
   for (GatherGemm& p : plans) { p.mode = accumulate ? GG_ACCUMULATE : GG_STORE; run(p); }
   return (int)plans.size();
@@ -46,7 +46,7 @@ int emul_conv2d_bwd_data(const ConvGeom* geom, const float* gy, const float* w, 
 
 int emul_conv2d_bwd_weight(const ConvGeom* geom, const float* x, const float* gy, float* gw, int accumulate) {
   ConvGeom g = *geom;
-  if (!geom_ok(g)) return -1;
+  if (!geom_ok(g) || geom_largest_extent(g) >= ((int64_t)1 << 31)) return -1;
   GatherGemm p = plan_conv_bwd_weight(g, x, gy, gw);
   p.mode = accumulate ? GG_ACCUMULATE : GG_STORE;
   run(p);

@@ -411,7 +411,7 @@ def test_fused_batch_norm_convolutions(F):
     kernels) against the two-step form relu(bn(x)) -> conv of torch, 1x1 and 3x3, dense and channel-slice inputs."""
     from srgan_amd import _lib
     lib = _lib.library()
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = _lib.stream_handle()
     gen = torch.Generator().manual_seed(23)
     for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 320, 352, 16, 16, 96, 1),
                                       (1, 512, 512, 8, 8, 40, 1), (2, 32, 32, 16, 16, 8, 3),
@@ -472,7 +472,7 @@ def test_fused_batch_norm_backward_in_the_data_gradient(F):
     (stored), gy a channel-slice view, 16- and 32-wide tiles, ragged heights."""
     from srgan_amd import _lib
     lib = _lib.library()
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = _lib.stream_handle()
     gen = torch.Generator().manual_seed(29)
     for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 192, 224, 32, 32, 128, 1),
                                       (1, 512, 512, 8, 8, 40, 1), (4, 96, 256, 64, 64, 128, 1), (2, 300, 300, 16, 16, 128, 1),

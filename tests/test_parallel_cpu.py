@@ -109,3 +109,91 @@ def test_shard_and_batch_bookkeeping():
     assert dp.shard(torch.arange(8)).tolist() == [2, 3]
     with pytest.raises(ValueError):
         dp.local_batch(30)
+
+
+def _exchange_worker(rank, world_size, port, queue):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    torch.set_num_threads(1)
+    import srgan_amd  # noqa: F401
+    from srgan_amd.parallel import DataParallel, GradientExchange
+    dp = DataParallel.from_environment('gloo')
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    exchange = GradientExchange(dp, flat, bucket_elements=256, min_bucket_elements=100)
+    exchange.ready_from(950)            # 50 final elements: below the minimum bucket, nothing starts
+    assert exchange.launched == []
+    exchange.ready_from(700)            # [700, 1000) goes out, from the end, in buckets of at most 256
+    assert exchange.launched == [(744, 1000), (700, 744)]
+    exchange.ready_from(800)            # a frontier behind what was sent is ignored
+    exchange.ready_from(650)            # 50 more: waits
+    exchange.finish()
+    assert exchange.launched[2:] == [(444, 700), (188, 444), (0, 188)]
+    exchange.wait()
+    queue.put((rank, flat.numpy().copy()))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_exchange_buckets_from_the_end():
+    """The asynchronous bucketed all-reduce behind the overlapped gradient exchange: offsets, order, and the sum."""
+    context = mp.get_context('spawn')
+    queue = context.Queue()
+    port = _free_port()
+    workers = [context.Process(target=_exchange_worker, args=(rank, 2, port, queue)) for rank in range(2)]
+    for worker in workers:
+        worker.start()
+    outputs = [queue.get(timeout=120) for _ in workers]
+    for worker in workers:
+        worker.join(timeout=60)
+        assert worker.exitcode == 0
+    expected = np.arange(1000, dtype=np.float32) * 3
+    for _, values in outputs:
+        np.testing.assert_array_equal(values, expected)
+
+
+def test_backward_reports_the_final_tail_of_the_arena():
+    """tape._frontiers: after the sweep has passed node i, no later node writes the arena at or beyond frontier[i + 1]."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd.tape import Var, Node, _frontiers
+    arena = torch.zeros(100)
+
+    def parameter(first, count):
+        var = Var(torch.zeros(count), requires_grad=True)
+        var.grad_buffer = arena[first:first + count]
+        return var
+    stem, middle, head = parameter(0, 10), parameter(10, 60), parameter(70, 30)
+    foreign = Var(torch.zeros(5), requires_grad=True)
+    foreign.grad_buffer = torch.zeros(5)                      # another network's arena: ignored
+    x = Var(torch.zeros(1), requires_grad=True)
+    a = Var(torch.zeros(1), requires_grad=True, node=Node((x, stem), None, 'stem'))
+    b = Var(torch.zeros(1), requires_grad=True, node=Node((a, middle, foreign), None, 'middle'))
+    c = Var(torch.zeros(1), requires_grad=True, node=Node((b, head), None, 'head'))
+    d = Var(torch.zeros(1), requires_grad=True, node=Node((c, middle), None, 'reuses the middle parameters'))
+    order = [d, c, b, a]                                      # consumers first
+    assert _frontiers(order, arena) == [100, 100, 70, 10, 0]
+
+
+def test_noise_draws_under_data_parallelism_are_shards_of_the_global_draw():
+    """Every rank draws the global batch from the shared seed and keeps its shard (the ranks' z must differ
+    and together equal the single-device draw at the global batch size)."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd.parallel import DataParallel
+    from srgan_amd.srgan import Experiment
+    from srgan_amd.settings import Settings
+
+    class Bare(Experiment):
+        def dataset_setup(self): pass
+        def model_setup(self): pass
+        def validation_summaries(self, step): pass
+
+    def draw(rank, world):
+        experiment = Bare(Settings())
+        if world > 1:
+            dp = DataParallel.__new__(DataParallel)
+            dp.group, dp.rank, dp.world_size = None, rank, world
+            experiment.dp = dp
+        torch.manual_seed(0)
+        return experiment._global_draw(8 // world, lambda count: torch.randn(count, 4))
+    whole = draw(0, 1)
+    halves = [draw(rank, 2) for rank in range(2)]
+    assert halves[0].shape == (4, 4) and not torch.equal(halves[0], halves[1])
+    assert torch.equal(torch.cat(halves), whole)
