@@ -11,7 +11,8 @@ from torch import nn as torch_nn
 from .. import functional as F
 from .. import nn
 from .. import fused
-from ..age.models import Generator as _DCGANGenerator
+from ..age.models import Generator as _DCGANGenerator, convolution, LEAK
+from ..utility import seed_all
 
 
 class DCGenerator(_DCGANGenerator):
@@ -19,6 +20,35 @@ class DCGenerator(_DCGANGenerator):
 
     def __init__(self, z_dim=256, image_size=224, conv_dim=64):
         super().__init__(z_dim=z_dim, image_size=image_size, conv_dim=conv_dim)
+
+
+class JointDCDiscriminator(nn.Module):
+    """DCGAN-like discriminator with two heads on the 512 x S/16 x S/16 trunk: ``count_layer5`` -> count (B) or class
+    logits (B, n), ``density_layer5`` -> a quarter-resolution density map (B, S/4, S/4); ``features`` = the flattened
+    trunk (reference crowd/models.py:150-178; no batch-norm: its module switch is off, crowd/models.py:108)."""
+
+    def __init__(self, image_size=128, conv_dim=64, number_of_outputs=1):
+        seed_all(0)
+        super().__init__()
+        self.number_of_outputs = number_of_outputs
+        self.layer1 = convolution(3, conv_dim, 4, bn=False)
+        self.layer2 = convolution(conv_dim, conv_dim * 2, 4)
+        self.layer3 = convolution(conv_dim * 2, conv_dim * 4, 4)
+        self.layer4 = convolution(conv_dim * 4, conv_dim * 8, 4)
+        self.count_layer5 = convolution(conv_dim * 8, self.number_of_outputs, int(image_size / 16), 1, 0, False)
+        self.density_layer5 = convolution(conv_dim * 8, int(image_size / 4) ** 2, int(image_size / 16), 1, 0, False)
+        self.features = None
+
+    def forward(self, x):
+        out = x
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            out = F.leaky_relu(stage(out), LEAK)
+        self.features = F.flatten2d(out)
+        count = self.count_layer5(out)
+        count = F.view(count, (-1,) if self.number_of_outputs == 1 else (-1, self.number_of_outputs))
+        side = int(x.shape[2] / 4)
+        density = F.view(self.density_layer5(out), (-1, side, side))
+        return density, count
 
 
 class _DenseLayer(nn.Sequential):

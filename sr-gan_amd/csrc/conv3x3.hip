@@ -410,7 +410,8 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
     p.epi_tiles = (int32_t)(blocks / plan.tiles_m);
     if (epilogue->g_gamma) {
       p.epi_partial = partial_workspace((size_t)2 * p.epi_tiles * CO * sizeof(float), stream);
-      SRGAN_REQUIRE(p.epi_partial, (int)hipErrorOutOfMemory, "conv3x3 batch-norm backward workspace");
+      SRGAN_REQUIRE(p.epi_partial, SRGAN_EINVAL, "conv3x3 batch-norm backward epilogue: register a workspace for this "
+                    "stream first (srgan_set_workspace, >= srgan_workspace_bytes())");
     }
   }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);

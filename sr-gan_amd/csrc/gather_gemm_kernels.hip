@@ -417,10 +417,13 @@ __global__ __launch_bounds__(256) void gg_reduce_partials_kernel(const GatherGem
   *dst = p.mode == GG_ACCUMULATE ? *dst + acc : acc;
 }
 
-// Split-K partial sums of tiny outputs go through a workspace the CALLER owns (srgan_set_workspace: one block per
-// (device, stream), at least srgan_workspace_bytes() long; launches on one stream are ordered, so reuse is safe).
-// The library never allocates device memory.
-constexpr size_t WORKSPACE_BYTES = (size_t)2 << 20;   // M*N < 512 outputs x at most 1024 K-slices x 4 B
+// Partial sums that a second small kernel combines go through a workspace the CALLER owns (srgan_set_workspace: one
+// block per (device, stream), at least srgan_workspace_bytes() long; launches on one stream are ordered, so reuse is
+// safe): the K-slices of split-K launches with a tiny output (M*N < 512 outputs x at most 1024 slices x 4 B = 2 MiB) and
+// the per-workgroup batch-norm parameter sums of the fused data-gradient epilogues (2 x column blocks x channels x 4 B =
+// at most 1/32 of the gradient tensor's bytes: 64 MiB covers tensors of up to 2^29 elements; larger ones report "unsupported"
+// from srgan_conv2d_bnrelu_supported and take the two-kernel form).  The library never allocates device memory.
+constexpr size_t WORKSPACE_BYTES = (size_t)64 << 20;
 struct WorkspaceSlot { float* ptr = nullptr; size_t bytes = 0; };
 static std::mutex g_workspace_mutex;
 static std::map<std::pair<int, hipStream_t>, WorkspaceSlot> g_workspaces;
@@ -434,6 +437,8 @@ int workspace_register(float* ptr, size_t bytes, hipStream_t stream) {
   slot.ptr = ptr; slot.bytes = bytes;
   return SRGAN_OK;
 }
+
+size_t workspace_capacity() { return WORKSPACE_BYTES; }
 
 float* partial_workspace(size_t bytes, hipStream_t stream) {
   int device = 0;
@@ -874,6 +879,8 @@ int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
     return (use_conv3x3(g, g.K, 0) && g.C <= 512) ? 1 : 0;
   }
   if (pass == 1) {
+    // the epilogue's per-workgroup parameter sums must fit the caller's workspace (<= 1/32 of the gradient tensor's bytes)
+    if ((size_t)g.N * g.H * g.W * g.C / 8 > WORKSPACE_BYTES) return 0;
     if (pointwise(g)) return (use_pointwise(g, g.C, 0) && (g.H * g.W) % 4 == 0) ? 1 : 0;   // float4 rows in the epilogue
     return (use_conv3x3(g, g.C, 0) && conv3x3_epilogue_supported(g.N, g.K, g.C, g.H, g.W)) ? 1 : 0;
   }

@@ -505,7 +505,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     p.epi_cols = (int32_t)col_blocks;
     if (epilogue->g_gamma) {
       p.epi_partial = partial_workspace((size_t)2 * col_blocks * CO * sizeof(float), stream);
-      SRGAN_REQUIRE(p.epi_partial, (int)hipErrorOutOfMemory, "pointwise batch-norm backward workspace");
+      SRGAN_REQUIRE(p.epi_partial, SRGAN_EINVAL, "pointwise batch-norm backward epilogue: register a workspace for this "
+                    "stream first (srgan_set_workspace, >= srgan_workspace_bytes())");
     }
   }
   static const bool narrow = getenv("SRGAN_PW_NARROW_OUT") != nullptr;

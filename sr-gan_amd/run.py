@@ -16,6 +16,7 @@ from .crowd.dggan import CrowdDgganExperiment
 from .coefficient.sgan import CoefficientSganExperiment
 from .coefficient.srgan import CoefficientExperiment
 from .crowd.dnn import CrowdDnnExperiment
+from .crowd.sgan import CrowdSganExperiment
 from .crowd.srgan import CrowdExperiment
 from .driving.srgan import DrivingExperiment
 from .settings import Settings, convert_to_settings_list, ApplicationName, MethodName
@@ -29,8 +30,8 @@ EXPERIMENTS = {
     ApplicationName.driving: {method: DrivingExperiment for method in MethodName},
     ApplicationName.coefficient: {MethodName.srgan: CoefficientExperiment, MethodName.sgan: CoefficientSganExperiment,
                                   MethodName.dggan: CoefficientDgganExperiment},
-    ApplicationName.crowd: {MethodName.srgan: CrowdExperiment, MethodName.dnn: CrowdDnnExperiment,
-                            MethodName.dggan: CrowdDgganExperiment},
+    ApplicationName.crowd: {MethodName.srgan: CrowdExperiment, MethodName.sgan: CrowdSganExperiment,
+                            MethodName.dnn: CrowdDnnExperiment, MethodName.dggan: CrowdDgganExperiment},
 }
 APPLICATION_SETTINGS = {
     ApplicationName.age: dict(matching_loss_multiplier=[1e2], contrasting_loss_multiplier=[1e1], batch_size=600,

@@ -38,16 +38,23 @@ class SganExperiment(Experiment, ABC):
         self.bins = as_var(self.bins)
         return self.bins
 
+    def class_logits(self, network, examples):
+        """The (B, bins) class logits of ``network`` (applications whose networks return more than the logits override
+        this, e.g. the crowd SGAN's (density, logits) pair)."""
+        return network(examples)
+
     def dnn_loss_calculation(self, labeled_examples, labels):
-        loss = cross_entropy_with_bins(self.DNN(labeled_examples), labels, self._bins(), self.batch_mean_of_examples)
+        loss = cross_entropy_with_bins(self.class_logits(self.DNN, labeled_examples), labels, self._bins(),
+                                       self.batch_mean_of_examples)
         return F.scale(loss, self.settings.labeled_loss_multiplier)
 
     def labeled_loss_calculation(self, labeled_examples, labels):
-        loss = cross_entropy_with_bins(self.D(labeled_examples), labels, self._bins(), self.batch_mean_of_examples)
+        loss = cross_entropy_with_bins(self.class_logits(self.D, labeled_examples), labels, self._bins(),
+                                       self.batch_mean_of_examples)
         return F.scale(loss, self.settings.labeled_loss_multiplier)
 
     def _binary_loss(self, examples, target):
-        return bce_with_logits(logsumexp(self.D(examples), dim=1), target, self.batch_mean_of_examples)
+        return bce_with_logits(logsumexp(self.class_logits(self.D, examples), dim=1), target, self.batch_mean_of_examples)
 
     def unlabeled_loss_calculation(self, labeled_examples, unlabeled_examples):
         return F.scale(self._binary_loss(unlabeled_examples, 1.0), self.settings.matching_loss_multiplier)

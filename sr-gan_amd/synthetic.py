@@ -37,6 +37,20 @@ class SyntheticLoader:
         return cls(make, pool)
 
     @classmethod
+    def crowd_density(cls, batch_size, size, seed=0, dp=None, pool=2):
+        """(image, quarter-resolution density label f32[S/4, S/4]) batches: the crowd SGAN's batch contract (reference
+        crowd/sgan.py:28-38: ``labels`` is the density map whose sum is the head count)."""
+        generator = torch.Generator().manual_seed(seed)
+        device = current_device()
+
+        def make(_):
+            image = torch.rand(batch_size, 3, size, size, generator=generator) * 2 - 1
+            density = (torch.rand(batch_size, size // 4, size // 4, generator=generator) < 0.1).float() * \
+                torch.rand(batch_size, 1, 1, generator=generator) * 8
+            return tuple(cls._shard(t, dp).to(device) for t in (image, density))
+        return cls(make, pool)
+
+    @classmethod
     def images(cls, batch_size, size, label_range=(10.0, 95.0), seed=0, dp=None, pool=2):
         """(image f32[3,H,W] in [-1,1], scalar label) batches: age (10..95 years) / driving (angle) contract
         (age/data.py:52-60)."""

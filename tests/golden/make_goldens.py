@@ -796,9 +796,117 @@ def g12_crowd_labels():
     save('g12_crowd_labels', **out)
 
 
+def g13_crowd_patches():
+    """the training-batch assembly of the reference's crowd pipeline, by its own transforms
+    (crowd/shanghai_tech_data.py:76-104 composes them): ``ExtractPatchForPosition(allow_padded=True)`` around a centre
+    (crowd/data.py:370-453, zero padding where the patch leaves the scene), ``RandomHorizontalFlip`` (crowd/data.py:
+    92-112; driven by ``random.choice`` -- the fixture seeds ``random`` per example and records what was chosen),
+    ``NegativeOneToOneNormalizeImage`` and ``NumpyArraysToTorchTensors`` (crowd/data.py:41-62,115-128).  Scenes larger
+    than, equal to and smaller than a patch; centres inside, on the border and in every corner."""
+    import random
+    from crowd.data import (CrowdExample, ExtractPatchForPosition, RandomHorizontalFlip, NegativeOneToOneNormalizeImage,
+                            NumpyArraysToTorchTensors)
+    generator = np.random.RandomState(13)
+    size = 32
+    out = {'patch_size': np.array(size)}
+    scenes = []
+    for index, shape in enumerate([(50, 70), (32, 32), (20, 45), (64, 33)]):
+        image = generator.randint(0, 256, size=shape + (3,)).astype(np.uint8)
+        label = (generator.rand(*shape) < 0.02).astype(np.float32) * generator.rand(*shape).astype(np.float32)
+        map_ = generator.rand(*shape).astype(np.float32)
+        scenes.append((image, label, map_))
+        out[f'scene{index}/image'], out[f'scene{index}/label'], out[f'scene{index}/map'] = image, label, map_
+    draws = [(0, 16, 16), (0, 25, 35), (0, 34, 54), (0, 0, 0), (0, 49, 69), (0, 3, 60), (0, 45, 8), (1, 16, 16),
+             (1, 0, 31), (2, 10, 22), (2, 19, 0), (2, 0, 44), (3, 32, 16), (3, 63, 32), (3, 5, 17), (0, 16, 53)]
+    extract = ExtractPatchForPosition(size, size, allow_padded=True)
+    records = []
+    for number, (scene, y, x) in enumerate(draws):
+        image, label, map_ = scenes[scene]
+        example = extract(CrowdExample(image=image, label=label, map_=map_), y, x)
+        random.seed(1000 + number)
+        flipped = random.choice([True, False])
+        random.seed(1000 + number)
+        example = RandomHorizontalFlip()(example)
+        example = NumpyArraysToTorchTensors()(NegativeOneToOneNormalizeImage()(example))
+        records.append((scene, y, x, int(flipped)))
+        out[f'patch{number}/image'] = example.image.numpy()
+        out[f'patch{number}/label'] = example.label.numpy()
+        out[f'patch{number}/map'] = example.map.numpy()
+        assert example.image.shape == (3, size, size) and example.label.shape == (size, size)
+    out['draws'] = np.array(records, dtype=np.int32)
+    assert 0 < out['draws'][:, 3].sum() < len(draws)          # both flip states occur
+    save('g13_crowd_patches', **out)
+
+
+def g14_crowd_sgan(size=64, batch=4, steps=2, d_scale=3.0):
+    """the crowd SGAN (reference crowd/sgan.py:10-87 on ``JointDCDiscriminator``,
+    crowd/models.py:150-178, dispatched at run.py:55).  Upstream the experiment is stale -- its ``model_setup`` pairs a
+    224-pixel generator with a 128-pixel discriminator and ``CrowdExperiment`` no longer produces quarter-resolution
+    density labels -- so, as for g10, the fixture binds the reference's own loss methods onto an experiment whose three
+    networks are the reference classes at ONE image size and feeds it density-label batches (B, S/4, S/4): two whole
+    training iterations through the reference's dnn_training_step / gan_training_step.  D's convolutions are scaled so
+    that the gradient penalty (on the batch-mean binary cross-entropy, multiplier applied twice: Appendix A.7) is active."""
+    import crowd.models as cm
+    from crowd.sgan import CrowdSganExperiment
+    bins_count = 10
+
+    def builders():
+        return (cm.DCGenerator(image_size=size), cm.JointDCDiscriminator(image_size=size, number_of_outputs=bins_count),
+                cm.JointDCDiscriminator(image_size=size, number_of_outputs=bins_count))
+    settings = Settings()
+    settings.batch_size, settings.number_of_bins = batch, bins_count
+    settings.matching_loss_multiplier, settings.gradient_penalty_multiplier = 1e1, 1e1
+    experiment = _ImageExperiment(settings)
+    experiment.builders = builders
+    experiment.labeled_criterion, experiment.gan_criterion = torch.nn.CrossEntropyLoss(), torch.nn.BCEWithLogitsLoss()
+    experiment.bins = torch.linspace(0, 300, bins_count)
+    for method in ('dnn_loss_calculation', 'labeled_loss_calculation', 'unlabeled_loss_calculation', 'fake_loss_calculation',
+                   'interpolate_loss_calculation', 'generator_loss_calculation', 'images_to_predicted_labels'):
+        setattr(experiment, method, getattr(CrowdSganExperiment, method).__get__(experiment))
+    ref_utility.seed_all(0)
+    experiment.model_setup()
+    experiment.prepare_optimizers()
+    experiment.train_mode()
+    attach_writers(experiment)
+    with torch.no_grad():
+        for module in experiment.D.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                module.weight.mul_(d_scale)
+    out = {'batch_size': np.array(batch), 'image_size': np.array(size), 'input_seed': np.array(140 + size),
+           'd_scale': np.array(d_scale), 'number_of_bins': np.array(bins_count),
+           'matching_loss_multiplier': np.array(1e1), 'gradient_penalty_multiplier': np.array(1e1)}
+    out.update(checksum_arrays('init_ck/D', experiment.D))
+    out.update(checksum_arrays('init_ck/DNN', experiment.DNN))
+    out.update(checksum_arrays('init_ck/G', experiment.G))
+    generator = torch.Generator().manual_seed(140 + size)
+    batches = []
+    for _ in range(steps):
+        x, u = _uniform_images(generator, batch, size), _uniform_images(generator, batch, size)
+        # quarter-resolution density labels: sparse heads, counts spread over several of the bins of [0, 300]
+        density = (torch.rand(batch, size // 4, size // 4, generator=generator) < 0.1).float() * \
+            torch.rand(batch, 1, 1, generator=generator) * 8
+        batches.append((x, density, u))
+    experiment.D.apply(ref_srgan.disable_batch_norm_updates)
+    with torch.no_grad():
+        density, logits = experiment.D(batches[0][0])
+        _, counts = experiment.images_to_predicted_labels(experiment.D, batches[0][0])
+    out['fwd/density'] = np32(density)
+    out['fwd/count_logits'] = np32(logits)
+    out['fwd/predicted_counts'] = np32(counts)
+    out['fwd/label_counts'] = np32(batches[0][1].sum(1).sum(1))
+    run_recorded_steps(experiment, batches, out, with_grads_on_step0=False, features=False)
+    assert float(out['s0/gradient_penalty']) > 0 and float(out[f's{steps - 1}/gradient_penalty']) > 0, 'penalty inactive'
+    print({k: float(v) for k, v in out.items() if k.startswith('s') and np.ndim(v) == 0})
+    out.update(checksum_arrays('final_ck/D', experiment.D))
+    out.update(checksum_arrays('final_ck/DNN', experiment.DNN))
+    out.update(checksum_arrays('final_ck/G', experiment.G))
+    save('g14_crowd_sgan64_gp_active', **out)
+
+
 ALL = {'g0': g0_toydata, 'g1': g1_distance, 'g2': g2_sgan_math, 'g3': g3_coefficient_srgan,
        'g4': g4_coefficient_sgan, 'g4b': g4b_coefficient_dggan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
-       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan, 'g11': g11_crowd_evaluation, 'g12': g12_crowd_labels}
+       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan, 'g11': g11_crowd_evaluation, 'g12': g12_crowd_labels,
+       'g13': g13_crowd_patches, 'g14': g14_crowd_sgan}
 
 if __name__ == '__main__':
     wanted = sys.argv[1:] or ['all']

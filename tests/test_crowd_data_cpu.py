@@ -64,3 +64,25 @@ def test_point_density_map_matches_the_reference():
         np.testing.assert_array_equal(density, g[f'scene{index}/point_map'])
     _, outside = generate_point_density_map(np.array([[3.0, 99.0], [1.0, 1.0]]), (10, 10))
     assert outside == 1
+
+
+def test_host_patch_transforms_against_the_reference_fixture():
+    """``extract_padded_patch`` / ``negative_one_to_one`` + a left-right flip against golden g13, which the reference's own
+    transforms produced (ExtractPatchForPosition(allow_padded=True), RandomHorizontalFlip, NegativeOneToOneNormalizeImage,
+    NumpyArraysToTorchTensors; tests/golden/make_goldens.py g13): scenes larger / equal / smaller than a patch, centres
+    inside, on the borders and in the corners."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd.crowd.data import extract_padded_patch, negative_one_to_one
+    from helpers import load_golden
+    g = load_golden('g13_crowd_patches')
+    size = int(g['patch_size'])
+    for number, (scene, y, x, flip) in enumerate(g['draws']):
+        image, label, map_ = (g[f'scene{scene}/{k}'] for k in ('image', 'label', 'map'))
+        patch = negative_one_to_one(extract_padded_patch(image, int(y), int(x), size))
+        patch_label = extract_padded_patch(label[:, :, None], int(y), int(x), size)[:, :, 0]
+        patch_map = extract_padded_patch(map_[:, :, None], int(y), int(x), size)[:, :, 0]
+        if flip:
+            patch, patch_label, patch_map = (np.flip(a, axis=1) for a in (patch, patch_label, patch_map))
+        np.testing.assert_array_equal(patch.transpose(2, 0, 1), g[f'patch{number}/image'])
+        np.testing.assert_array_equal(patch_label, g[f'patch{number}/label'])
+        np.testing.assert_array_equal(patch_map, g[f'patch{number}/map'])

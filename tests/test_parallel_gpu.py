@@ -47,6 +47,7 @@ def _step(dp, queue=None):
     y = tuple(shard(t).cuda() for t in y)
     sharded = {f's0/{k}': shard(torch.from_numpy(g[f's0/{k}'])).numpy() for k in ('z_d', 'z_g', 'alpha')}
     result = run_step(experiment, x, y, u, 0, sharded)
+    experiment.finish_update()       # the generator's update waits for its (asynchronous) gradient exchange until G is used again
     if dp is not None:     # the logged gradient-norm mean is a local mean
         result['gradient_norm_mean'] = dp.all_reduce_sum_float(result['gradient_norm_mean']) / dp.world_size
     tensors = {}
