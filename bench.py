@@ -48,6 +48,23 @@ ALGORITHMIC_GFLOP_PER_IMAGE = {512: 1188.7 + 135.6, 224: 227.5 + 26.0}
 GP_SCALE = {512: 1.27, 224: 1.27}
 
 
+LOW_PRECISION_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 (MI355X_MICROARCH.md); never the 2:1-sparsity figure
+# The other BASELINE.json configurations that name a precision mode (secondary bench lines; the headline stays crowd).
+WORKLOADS = {
+    'crowd': None,
+    'age-vgg-bf16': dict(application='age', architecture='vgg', image_size=64, batch_per_gpu=128, gp_scale=1.3, dtype='bf16',
+                         settings=dict(compute_dtype='bf16', matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
+                                       gradient_penalty_multiplier=1e2),
+                         name='age SRGAN, VGG-16 D/DNN + DCGAN G on 64x64 faces (BASELINE.json configs[1]), bf16 MFMA operands'),
+    'driving-fp16': dict(application='driving', image_size=(64, 192), batch_per_gpu=128, gp_scale=2.2, dtype='f16',
+                         settings=dict(compute_dtype='f16', gradient_penalty_dtype='f32', loss_scale=256.0,
+                                       matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
+                                       gradient_penalty_multiplier=1e2),
+                         name='driving SRGAN, DCGAN D/DNN/G on 64x192 frames (BASELINE.json configs[4]), fp16 MFMA operands with '
+                              'the gradient-penalty chain in fp32, static loss scale 256'),
+}
+
+
 def parse():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
@@ -66,6 +83,9 @@ def parse():
     parser.add_argument('--shape-report', default=None, help='write the per-shape contraction timing table here')
     parser.add_argument('--reference-schedule', action='store_true',
                         help='replay the reference forward/backward order instead of sharing forwards')
+    parser.add_argument('--workload', default='crowd', choices=sorted(WORKLOADS),
+                        help='crowd (the headline, BASELINE.json configs[2]/[3]) or one of the mixed-precision configurations: '
+                             'age-vgg-bf16 (configs[1]), driving-fp16 (configs[4]: fp16 with the gradient-penalty chain in fp32)')
     parser.add_argument('--gp-scale', type=float, default=None,
                         help='factor on D\'s convolution weights (default: GP_SCALE for the image size; 1 = default '
                              'initialisation, gradient penalty inactive)')
@@ -81,6 +101,9 @@ def build_experiment(args, dp):
     from srgan_amd.crowd.srgan import CrowdExperiment
     from srgan_amd.utility import SummaryWriter, seed_all
     settings = Settings()                                   # run.py:57-68 crowd hyper-parameters
+    workload = WORKLOADS[args.workload]
+    if workload is not None:
+        args.batch_per_gpu, args.image_size = workload['batch_per_gpu'], workload['image_size']
     settings.batch_size = args.batch_per_gpu * (dp.world_size if dp else 1)
     settings.image_patch_size = settings.label_patch_size = args.image_size
     settings.matching_loss_multiplier, settings.contrasting_loss_multiplier = 1e3, 1e2
@@ -89,7 +112,19 @@ def build_experiment(args, dp):
     settings.reference_schedule = args.reference_schedule
     settings.overlap_dnn_step = args.overlap_dnn
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
-    experiment = CrowdExperiment(settings)
+    if workload is None:
+        experiment = CrowdExperiment(settings)
+    else:
+        for key, value in workload['settings'].items():
+            setattr(settings, key, value)
+        if workload['application'] == 'age':
+            import srgan_amd.age.srgan as age
+            age.model_architecture = workload['architecture']       # the reference's module-level switch (age/srgan.py:14)
+            experiment = age.AgeExperiment(settings)
+        else:
+            from srgan_amd.driving.srgan import DrivingExperiment
+            experiment = DrivingExperiment(settings)
+        experiment.image_size = workload['image_size']
     experiment.dp = dp
     seed_all(0)
     experiment.dataset_setup()
@@ -98,7 +133,7 @@ def build_experiment(args, dp):
     if scale != 1.0:
         with torch.no_grad():
             for module in experiment.D.modules():
-                if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.Linear)):
                     module.weight.mul_(scale)
     experiment.gpu_mode()
     experiment.prepare_optimizers()
@@ -112,14 +147,18 @@ def build_experiment(args, dp):
 
 
 def gp_scale(args):
-    return args.gp_scale if args.gp_scale is not None else GP_SCALE.get(args.image_size, 1.27)
+    if args.gp_scale is not None:
+        return args.gp_scale
+    workload = WORKLOADS[args.workload]
+    return workload['gp_scale'] if workload is not None else GP_SCALE.get(args.image_size, 1.27)
 
 
 def one_step(experiment, labeled, unlabeled, step):
-    x, heads, knn = next(labeled)
+    batch = next(labeled)
+    x, labels = (batch[0], (batch[1], batch[2])) if len(batch) == 3 else batch
     u = next(unlabeled)[0]
-    experiment.dnn_training_step(x, (heads, knn), step + 1)      # step + 1 with a huge summary period: no host sync
-    experiment.gan_training_step(x, (heads, knn), u, step + 1)
+    experiment.dnn_training_step(x, labels, step + 1)      # step + 1 with a huge summary period: no host sync
+    experiment.gan_training_step(x, labels, u, step + 1)
 
 
 def pmc_traffic(args):
@@ -338,8 +377,11 @@ def main():
     result = {
         'metric': 'SRGAN train images/sec (G+D step)', 'value': images_per_second, 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'crowd SRGAN (KnnDenseNetCat D/DNN + DCGenerator) {args.image_size}x{args.image_size}, '
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': WORKLOADS[args.workload]['dtype'] if WORKLOADS[args.workload] else 'f32', 'data': 'synthetic',
+        'config': {'workload': (WORKLOADS[args.workload]['name'] + f', batch {args.batch_per_gpu}/GPU, dnn_training_step + '
+                                'gan_training_step per step') if WORKLOADS[args.workload] else
+                               f'crowd SRGAN (KnnDenseNetCat D/DNN + DCGenerator) {args.image_size}x{args.image_size}, '
                                f'batch {args.batch_per_gpu}/GPU, dnn_training_step + gan_training_step per step',
                    'global_batch': global_batch, 'image_size': args.image_size,
                    'schedule': 'reference' if args.reference_schedule else 'shared-forwards',
@@ -350,7 +392,7 @@ def main():
     if dp is not None:
         result['config']['gradient_exchange'] = ('blocking' if args.no_overlap_exchange else
                                                  'asynchronous, overlapped with backward / next phase') + f' ({args.backend})'
-    gflop = ALGORITHMIC_GFLOP_PER_IMAGE.get(args.image_size)
+    gflop = ALGORITHMIC_GFLOP_PER_IMAGE.get(args.image_size) if args.workload == 'crowd' else None
     if gflop:
         result['step_tflops_as_written_schedule'] = images_per_second * gflop / 1e3
         result['step_frac_as_written_schedule'] = result['step_tflops_as_written_schedule'] / (FP32_MFMA_PEAK_TFLOPS * world)
@@ -391,9 +433,26 @@ def main():
             'algorithmic_bytes_per_launch': algorithmic_bytes.value / max(launches.value, 1),
             'step_frac_executed': flops.value / step_seconds / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         }
-    if rank == 0 and world == 1 and not args.no_roofline:
+        if args.workload != 'crowd':
+            # mixed precision: the bf16 / fp16 launches are priced against the dense low-precision peak, the fp32 remainder
+            # (gradient-penalty chain of the fp16 mode, VALU kernels) against the fp32 one
+            low_flops, low_ms = ctypes.c_double(), ctypes.c_double()
+            _lib.check(lib.srgan_profile_mixed(ctypes.byref(low_flops), ctypes.byref(low_ms)), 'srgan_profile_mixed')
+            low = low_flops.value / (low_ms.value * 1e-3) / 1e12 if low_ms.value > 0 else 0.0
+            rest_ms, rest_flops = kernel_ms.value - low_ms.value, flops.value - low_flops.value
+            roofline = result['roofline']
+            roofline.update({
+                'achieved': low, 'peak': LOW_PRECISION_MFMA_PEAK_TFLOPS, 'frac': low / LOW_PRECISION_MFMA_PEAK_TFLOPS,
+                'kernel': 'srgan::gg_mfma_kernel<..., PREC> (v_mfma_f32_32x32x16_bf16 / _f16): every contraction launched in the '
+                          'low-precision mode',
+                'low_precision_kernel_ms_per_step': low_ms.value, 'low_precision_gflop_per_step': low_flops.value / 1e9,
+                'fp32_part': {'kernel_ms_per_step': rest_ms, 'gflop_per_step': rest_flops / 1e9,
+                              'achieved': rest_flops / (rest_ms * 1e-3) / 1e12 if rest_ms > 0 else 0.0,
+                              'peak': FP32_MFMA_PEAK_TFLOPS},
+                'step_frac_executed': None})
+    if rank == 0 and world == 1 and not args.no_roofline and args.workload == 'crowd':
         result['hbm_kernels'] = hbm_kernel_rates(experiment)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'crowd':
         result['cpu_baseline'] = cpu_baseline(args.image_size)
     if rank == 0:
         print(json.dumps(result), flush=True)

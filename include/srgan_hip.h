@@ -45,6 +45,8 @@ const char* srgan_last_error(void);
  * srgan_capabilities fills the struct below (pass sizeof(srgan_capabilities_t)); SRGAN_DTYPE_* / SRGAN_FEATURE_*
  * are bit masks.  Reference analogue: none (torch picks kernels internally); SURVEY.md 8b asks for the query. */
 #define SRGAN_DTYPE_F32 0x1u            /* fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32): the parity path */
+#define SRGAN_DTYPE_BF16 0x2u           /* bf16 MFMA operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
+#define SRGAN_DTYPE_F16 0x4u            /* fp16 MFMA operands, fp32 accumulate (v_mfma_f32_32x32x16_f16) */
 #define SRGAN_FEATURE_FUSED_BNRELU 0x1u /* norm -> relu -> conv evaluated inside the convolution kernels */
 #define SRGAN_FEATURE_SPLITK_WORKSPACE 0x2u
 #define SRGAN_FEATURE_LIVE_PROFILE 0x4u
@@ -75,7 +77,20 @@ typedef struct srgan_conv_desc {
   int32_t stride_h, stride_w, pad_h, pad_w;
   int32_t OH, OW;
   int64_t x_batch_stride, y_batch_stride;
+  int32_t compute_dtype;   /* SRGAN_COMPUTE_*: the MFMA operand type of this pass */
 } srgan_conv_desc;
+
+/* Mixed precision (BASELINE.json configs 2 and 5: "bf16", "fp16 with fp32 GP"; the reference itself is fp32-only).
+ * Tensors stay fp32 in HBM -- activations, weights (the master copy), gradients, Adam moments -- and accumulation is
+ * fp32; with SRGAN_COMPUTE_BF16 / _F16 the two operands of every contraction are rounded to bf16 / fp16 when the MFMA
+ * fragments are formed (v_mfma_f32_32x32x16_bf16 / _f16, 16x the fp32 matrix rate).  The choice is per call, so a
+ * caller keeps e.g. the gradient-penalty chain in SRGAN_COMPUTE_F32 while the rest of the step runs in fp16.  The
+ * specialised fp32 kernels (fused batch-norm forms included: srgan_conv2d_bnrelu_supported then returns 0) are not
+ * used in these modes; fp32 remains the parity path (1e-3), the mixed modes are tested against it with their own,
+ * stated tolerances (tests/test_mixed_precision_gpu.py). */
+#define SRGAN_COMPUTE_F32 0
+#define SRGAN_COMPUTE_BF16 1
+#define SRGAN_COMPUTE_F16 2
 
 /* y = conv2d(x, w) + bias[k] (bias may be NULL).
  * Replaces torch.nn.Conv2d.forward at reference crowd/models.py:340-345,369,770-775,1072,1134-1135;
@@ -130,6 +145,10 @@ int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, 
 int srgan_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,
                    int64_t sbk, int64_t sbj, float* C, int64_t sci, int64_t scj, const float* bias,
                    int32_t bias_on_columns, int accumulate, int force_kernel, void* stream);
+/* The same with the MFMA operand type chosen per call (compute_dtype = SRGAN_COMPUTE_*; srgan_gemm_f32 = fp32). */
+int srgan_gemm(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,
+               int64_t sbk, int64_t sbj, float* C, int64_t sci, int64_t scj, const float* bias,
+               int32_t bias_on_columns, int accumulate, int force_kernel, int compute_dtype, void* stream);
 
 /* ---- elementwise ------------------------------------------------------------------------------------------
  * Unary op codes: 0 copy, 1 neg, 2 abs, 3 sign, 4 sqrt, 5 exp, 6 log, 7 log1p, 8 square, 9 reciprocal, 10 tanh,
@@ -262,6 +281,9 @@ int srgan_profile_end(double* kernel_ms, double* flops, double* mfma_flops, int6
  * stride class does not count an input element twice): the figure bench.py's roofline.algorithmic_bytes_per_step
  * reports next to the PMC traffic. */
 int srgan_profile_bytes(double* algorithmic_bytes_total);
+/* The part of the bracketed launches that ran with bf16 / fp16 MFMA operands: logical FLOPs and summed kernel time (the
+ * mixed-precision bench lines price it against the 2.5 PFLOP/s dense bf16 / fp16 peak, the rest against 157.3 TFLOP/s). */
+int srgan_profile_mixed(double* flops, double* kernel_ms);
 /* Per-shape text report of the last profiled region ("M N K kind bm bn split akf bkf count ms bytes" per line; kind:
  * 0 gg_direct, 1 gg_mfma, 2 conv3x3_lds, 3 pointwise, 4 conv3x3_wgrad, 5 gg_rows, 6 pointwise_wgrad,
  * 8 pointwise_ksplit, 9 gg_dot); returns the bytes needed. */

@@ -12,7 +12,7 @@ i32, i64, f32, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_voi
 class ConvDesc(ctypes.Structure):
     """Mirror of ``srgan_conv_desc``."""
     _fields_ = [(name, i32) for name in ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride_h', 'stride_w', 'pad_h', 'pad_w',
-                                         'OH', 'OW')] + [('x_batch_stride', i64), ('y_batch_stride', i64)]
+                                         'OH', 'OW')] + [('x_batch_stride', i64), ('y_batch_stride', i64), ('compute_dtype', i32)]
 
 
 class BnRelu(ctypes.Structure):
@@ -46,6 +46,8 @@ SIGNATURES = {
                                        ctypes.c_int),
     'srgan_gemm_f32': ([i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i32, ctypes.c_int, ctypes.c_int,
                         vp], ctypes.c_int),
+    'srgan_gemm': ([i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i32, ctypes.c_int, ctypes.c_int,
+                    ctypes.c_int, vp], ctypes.c_int),
     'srgan_ew_unary': ([ctypes.c_int, vp, vp, i64, f32, f32, vp], ctypes.c_int),
     'srgan_ew_binary': ([ctypes.c_int, vp, vp, vp, i64, f32, vp], ctypes.c_int),
     'srgan_fill': ([vp, i64, f32, vp], ctypes.c_int),
@@ -74,6 +76,7 @@ SIGNATURES = {
                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     'srgan_profile_report': ([ctypes.c_char_p, ctypes.c_int64], ctypes.c_int64),
     'srgan_profile_bytes': ([ctypes.POINTER(ctypes.c_double)], ctypes.c_int),
+    'srgan_profile_mixed': ([ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)], ctypes.c_int),
     'srgan_capabilities': ([ctypes.POINTER(Capabilities), i32], ctypes.c_int),
     'srgan_workspace_bytes': ([], ctypes.c_int64),
     'srgan_set_workspace': ([vp, i64, vp], ctypes.c_int),

@@ -313,7 +313,7 @@ static void launch_conv3(const Conv3Params& p, int th, int tw, dim3 grid, hipStr
 // Declared in gather_gemm_kernels.hip: records a launch for the bench's live event timing.
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
-                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
 
 bool conv3x3_enabled() {
   static const bool disabled = getenv("SRGAN_NO_CONV3") != nullptr;

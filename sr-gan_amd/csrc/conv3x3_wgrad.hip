@@ -195,7 +195,7 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
 
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
-                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
 
 bool conv3x3_wgrad_enabled() {
   static const bool disabled = getenv("SRGAN_NO_WGRAD3") != nullptr;

@@ -71,7 +71,7 @@ inline GatherGemm gg_blank() {
   p.A = nullptr; p.B = nullptr; p.C = nullptr; p.bias = nullptr; p.bias_cols = 0;
   p.hlim = 1; p.wlim = 1; p.M = p.N = p.K = 0; p.a_kfast = 1; p.b_kfast = 0;
   p.mode = GG_STORE; p.split_k = 1; p.k_per_split = 0; p.debug = 0; p.partial = nullptr; p.use_partial = 0;
-  p.b_unique = 0;
+  p.b_unique = 0; p.precision = 0;
   p.am = p.ak = p.bk = p.bn = p.cm = p.cn = dec_linear(0, 0);
   return p;
 }

@@ -115,7 +115,8 @@ struct GatherGemm {
   float* partial;                                        // GG_PARTIAL: K-slice z stores to partial[(z*M + i)*N + j]
   int32_t use_partial;                                   // launcher: combine K-slices through a workspace, not atomics
   int64_t b_unique;                                      // distinct B elements the gather touches (0: K * N); bookkeeping
-};                                                       //   for the algorithmic-bytes figure of the live profile only
+  int32_t precision;                                     // MFMA operand type: 0 fp32 (exact), 1 bf16, 2 fp16 (fp32 accumulate,
+};                                                       //   for the live profile only.  precision: fp32 data in HBM and LDS, rounded when the MFMA operands are formed
 
 // Reference semantics of one output element (used by the CPU emulator and by the direct kernel).
 GG_HD float gg_a(const GatherGemm& p, const Side& m, const Side& k) {

@@ -19,6 +19,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <utility>
 
 namespace srgan {
@@ -35,6 +36,8 @@ void set_error(const char* fmt, ...) {
 const char* last_error() { return g_error; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GG_BK = 32;   // K-slice alignment of split-K chunks (the largest per-config BK)
 
@@ -48,7 +51,11 @@ struct TileBK { static constexpr int value = (BM * BN >= 128 * 128 || BN >= 256)
 // VEC: both operands are staged with 16-byte loads along their contiguous direction (groups of 4 consecutive k or
 // m/n that share one address decode): the 1x1 convolutions and linear layers, i.e. plain GEMMs on NCHW data.
 // The host (vec_eligible) guarantees that every group is 16-byte aligned and entirely valid or entirely invalid.
-template <int BM, int BN, int WGM, bool AKF, bool BKF, bool VEC>
+// PREC: 0 = v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak); 1 / 2 = v_mfma_f32_32x32x16_bf16 / _f16 (2.5 PF/s peak):
+// the tiles in LDS stay fp32 and every lane rounds its 8 consecutive-k operand values when it forms the fragment (lane l
+// holds row / column l & 31 and k = 8 * (l >> 5) .. + 7 of a 16-deep step), accumulation is fp32 and the C/D fragment
+// layout is the same, so staging and epilogue are shared.  The mixed-precision modes of BASELINE.json configs 2 and 5.
+template <int BM, int BN, int WGM, bool AKF, bool BKF, bool VEC, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
   constexpr int BK = TileBK<BM, BN, VEC>::value;
   constexpr int WGN = 4 / WGM;
@@ -186,6 +193,35 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const bool more = (k0 + BK < kend) && !(p.debug & 1);
       if (more) fetch(k0 + BK);
+      if constexpr (PREC != 0) {
+        static_assert(PREC == 0 || BK % 16 == 0, "16-deep MFMA steps");
+        using frag = typename std::conditional<PREC == 1, bf16x8, f16x8>::type;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+          frag a[MI], b[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float v = As[(kk + 8 * lhi + j) * LDA + wm0 + mi * 32 + l31];
+              if constexpr (PREC == 1) a[mi][j] = (__bf16)v; else a[mi][j] = (_Float16)v;
+            }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float v = Bs[(kk + 8 * lhi + j) * LDB + wn0 + ni * 32 + l31];
+              if constexpr (PREC == 1) b[ni][j] = (__bf16)v; else b[ni][j] = (_Float16)v;
+            }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              if constexpr (PREC == 1) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+              else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+      } else
 #pragma unroll
       for (int kk = 0; kk < ((p.debug & 2) ? 0 : BK); kk += 2) {
         float a[MI], b[NI];
@@ -547,9 +583,19 @@ static bool vec_eligible(const GatherGemm& p) {
   return a && b && p.K % 4 == 0;
 }
 
+template <int BM, int BN, int WGM, int PREC>
+static void launch_mfma_mixed(const GatherGemm& p, dim3 grid, hipStream_t stream) {
+  if (p.a_kfast && p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, true, false, PREC>), grid, dim3(256), 0, stream, p);
+  else if (p.a_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, true, false, false, PREC>), grid, dim3(256), 0, stream, p);
+  else if (p.b_kfast) hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, true, false, PREC>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((gg_mfma_kernel<BM, BN, WGM, false, false, false, PREC>), grid, dim3(256), 0, stream, p);
+}
+
 template <int BM, int BN, int WGM>
 static void launch_mfma(const GatherGemm& p, dim3 grid, hipStream_t stream) {
-  if (vec_eligible(p)) launch_mfma_v<BM, BN, WGM, true>(p, grid, stream);
+  if (p.precision == 1) launch_mfma_mixed<BM, BN, WGM, 1>(p, grid, stream);        // (scalar staging only)
+  else if (p.precision == 2) launch_mfma_mixed<BM, BN, WGM, 2>(p, grid, stream);
+  else if (vec_eligible(p)) launch_mfma_v<BM, BN, WGM, true>(p, grid, stream);
   else launch_mfma_v<BM, BN, WGM, false>(p, grid, stream);
 }
 
@@ -576,7 +622,7 @@ bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
 
 // ---- optional live timing of every contraction launch with HIP events on the launch stream -------------------
 // (bench.py: roofline.achieved = sum of logical 2*M*N*K over launches / sum of their event-timed durations)
-struct ProfileRecord { int32_t M, N, K, kind, bm, bn, split, akf, bkf; double bytes; };
+struct ProfileRecord { int32_t M, N, K, kind, bm, bn, split, akf, bkf; double bytes; int32_t precision; };
 // Algorithmic HBM bytes of one contraction launch: every operand element once, 4 B each.  `taps` = how many times the
 // gather visits one element of the big operand (9 for a 3x3 kernel, R*S of a strided one divided over its classes).
 static double algorithmic_bytes(double M, double N, double K, int kind) {
@@ -611,7 +657,7 @@ int profile_bracket_begin(hipStream_t stream) {
       if (hipEventCreate(&e) != hipSuccess) { --g_profile.slots; return -1; }
       g_profile.events.push_back(e);
     }
-    g_profile.records.resize(g_profile.slots, ProfileRecord{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0});
+    g_profile.records.resize(g_profile.slots, ProfileRecord{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0});
     start = g_profile.events[2 * slot];
   }
   if (hipEventRecord(start, stream) != hipSuccess) return -1;
@@ -619,7 +665,7 @@ int profile_bracket_begin(hipStream_t stream) {
 }
 
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split,
-                        int akf, int bkf, int64_t b_unique) {
+                        int akf, int bkf, int64_t b_unique, int precision) {
   if (slot < 0) return SRGAN_OK;
   hipEvent_t stop;
   {
@@ -629,7 +675,7 @@ int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int6
     const double f = 2.0 * (double)M * (double)N * (double)K;
     const double bytes = b_unique > 0 ? 4.0 * ((double)M * N + (double)M * K + (double)b_unique)
                                       : algorithmic_bytes((double)M, (double)N, (double)K, kind);
-    g_profile.records[slot] = ProfileRecord{(int32_t)M, (int32_t)N, (int32_t)K, kind, bm, bn, split, akf, bkf, bytes};
+    g_profile.records[slot] = ProfileRecord{(int32_t)M, (int32_t)N, (int32_t)K, kind, bm, bn, split, akf, bkf, bytes, precision};
     g_profile.flops += f;
     if (kind != 0 && kind != 5 && kind != 9) g_profile.mfma_flops += f;      // direct / few-rows / lanes-along-K: VALU
     g_profile.bytes += bytes;
@@ -708,7 +754,8 @@ int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return SRGAN_OK;
   const int slot = profile_bracket_begin(stream);
   const int status = gg_launch_unprofiled(p, c, stream);
-  profile_bracket_end(slot, stream, p.M, p.N, p.K, c.kind, c.bm, c.bn, p.split_k, p.a_kfast, p.b_kfast, p.b_unique);
+  profile_bracket_end(slot, stream, p.M, p.N, p.K, c.kind, c.bm, c.bn, p.split_k, p.a_kfast, p.b_kfast, p.b_unique,
+                      c.kind == 1 ? p.precision : 0);
   return status;
 }
 
@@ -781,7 +828,10 @@ extern "C" {
 struct srgan_conv_desc {
   int32_t N, C, H, W, K, R, S, stride_h, stride_w, pad_h, pad_w, OH, OW;
   int64_t x_batch_stride, y_batch_stride;
+  int32_t compute_dtype;      // 0 fp32, 1 bf16, 2 fp16 MFMA operands (fp32 data and accumulation)
 };
+
+static bool dtype_ok(int dtype) { return dtype >= 0 && dtype <= 2; }
 
 static bool to_geom(const srgan_conv_desc* d, ConvGeom& g) {
   if (d == nullptr) return false;
@@ -810,6 +860,9 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   ConvGeom g;
   SRGAN_GEOM(desc, g, "srgan_conv2d_fwd");
   SRGAN_REQUIRE(x && w && y, SRGAN_EINVAL, "srgan_conv2d_fwd pointers");
+  const int dtype = desc->compute_dtype;
+  SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_fwd compute_dtype");
+  if (dtype) force_kernel = 2;      // mixed precision lives in the generic MFMA kernel
   if (use_pointwise(g, g.K, force_kernel) && ((uintptr_t)w & 15) == 0 &&
       pointwise_ksplit_wanted(g.N, g.C, g.K, g.H * g.W, false))
     return pointwise_ksplit_run(x, g.x_bs, w, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream, nullptr);
@@ -819,6 +872,7 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
     return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, 0,
                        (hipStream_t)stream);
   std::vector<GatherGemm> plans{plan_conv_fwd(g, x, w, bias, y)};
+  plans[0].precision = dtype;
   // A strided-batch output view (a channel slice of a wider buffer) is zeroed with a 2-D memset when the launch
   // combines K-slices with atomics.
   const bool dense_out = g.y_bs == (int64_t)g.K * g.OH * g.OW;
@@ -843,6 +897,9 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
   SRGAN_GEOM(desc, g, "srgan_conv2d_bwd_data");
   SRGAN_REQUIRE(gy && w && gx, SRGAN_EINVAL, "srgan_conv2d_bwd_data pointers");
   SRGAN_REQUIRE(g.x_bs == (int64_t)g.C * g.H * g.W, SRGAN_EUNSUPPORTED, "srgan_conv2d_bwd_data dense gx");
+  const int dtype = desc->compute_dtype;
+  SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_bwd_data compute_dtype");
+  if (dtype) force_kernel = 2;
   if (use_pointwise(g, g.C, force_kernel))   // the data gradient of a 1x1 convolution is the 1x1 convolution with W^T
     return pointwise_run(gy, g.y_bs, w, 1, g.C, bias, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
                          (hipStream_t)stream);
@@ -850,6 +907,7 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
     return conv3x3_run(gy, g.y_bs, w, 8, 9, g.C * 9, -3, -1, bias, gx, g.x_bs, g.N, g.K, g.C, g.H, g.W, accumulate,
                        (hipStream_t)stream);
   std::vector<GatherGemm> plans = plan_conv_bwd_data(g, gy, w, bias, gx);
+  for (GatherGemm& plan : plans) plan.precision = dtype;
   return gg_run_group(plans, gx, (int64_t)g.N * g.x_bs, accumulate, force_kernel, (hipStream_t)stream);
 }
 
@@ -858,11 +916,15 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   ConvGeom g;
   SRGAN_GEOM(desc, g, "srgan_conv2d_bwd_weight");
   SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
+  const int dtype = desc->compute_dtype;
+  SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_bwd_weight compute_dtype");
+  if (dtype) force_kernel = 2;
   if (use_pointwise_wgrad(g, x, gy, force_kernel))
     return pointwise_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, accumulate, (hipStream_t)stream);
   if (use_wgrad3x3(g, x, gy, force_kernel))
     return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream);
   std::vector<GatherGemm> plans{plan_conv_bwd_weight(g, x, gy, gw)};
+  plans[0].precision = dtype;
   return gg_run_group(plans, gw, (int64_t)g.K * g.C * g.R * g.S, accumulate, force_kernel, (hipStream_t)stream);
 }
 
@@ -873,6 +935,7 @@ static bool bn_ok(const srgan_bn_relu* bn) { return bn && bn->mean && bn->inv_st
 
 int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
   ConvGeom g;
+  if (desc && desc->compute_dtype != 0) return 0;       // the fused forms are fp32 kernels
   if (!to_geom(desc, g) || geom_largest_extent(g) >= ((int64_t)1 << 31)) return 0;
   if (pass == 0) {
     if (pointwise(g)) return use_pointwise(g, g.K, 0) ? 1 : 0;
@@ -1001,6 +1064,23 @@ int srgan_profile_bytes(double* algorithmic_bytes_total) {
   return SRGAN_OK;
 }
 
+// The part of the profiled region that ran with bf16 / fp16 MFMA operands: its logical FLOPs and its summed kernel time.
+int srgan_profile_mixed(double* flops, double* kernel_ms) {
+  std::lock_guard<std::mutex> lock(g_profile.mutex);
+  double f = 0.0, total = 0.0;
+  for (size_t i = 0; i < g_profile.slots; ++i) {
+    const ProfileRecord& r = g_profile.records[i];
+    if (r.M < 0 || r.precision == 0) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_profile.events[2 * i], g_profile.events[2 * i + 1]) != hipSuccess) continue;
+    total += ms;
+    f += 2.0 * (double)r.M * (double)r.N * (double)r.K;
+  }
+  if (flops) *flops = f;
+  if (kernel_ms) *kernel_ms = total;
+  return SRGAN_OK;
+}
+
 // Per-shape breakdown of the last profiled region as text lines "M N K kind bm bn split akf bkf count ms bytes"
 // (kind: 0 direct, 1 gg_mfma, 2 conv3x3_lds, 3 pointwise, 4 conv3x3_wgrad, 5 gg_rows, 6 pointwise_wgrad,
 // 8 pointwise_ksplit, 9 gg_dot; bytes = algorithmic HBM bytes of all `count` launches; call after srgan_profile_end).
@@ -1064,7 +1144,7 @@ int srgan_capabilities(srgan_capabilities_t* out, int32_t out_bytes) {
   out->abi_version = 100;
   out->struct_bytes = (int32_t)sizeof(*out);
   snprintf(out->arch, sizeof(out->arch), "gfx950");
-  out->dtypes = 1u;
+  out->dtypes = 0x1u /* fp32 */ | 0x2u /* bf16 MFMA operands */ | 0x4u /* fp16 MFMA operands */;
   out->features = 0x1u /* fused batch-norm + relu prologues / epilogues */ | 0x2u /* split-K through a workspace */ |
                   0x4u /* live event profile of the contraction launches */;
   out->workspace_bytes = (int64_t)WORKSPACE_BYTES;
@@ -1072,10 +1152,22 @@ int srgan_capabilities(srgan_capabilities_t* out, int32_t out_bytes) {
   return SRGAN_OK;
 }
 
+int srgan_gemm(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,
+               int64_t sbk, int64_t sbj, float* C, int64_t sci, int64_t scj, const float* bias,
+               int32_t bias_on_columns, int accumulate, int force_kernel, int compute_dtype, void* stream);
+
 int srgan_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,
                    int64_t sbk, int64_t sbj, float* C, int64_t sci, int64_t scj, const float* bias,
                    int32_t bias_on_columns, int accumulate, int force_kernel, void* stream) {
+  return srgan_gemm(M, N, K, A, sai, sak, B, sbk, sbj, C, sci, scj, bias, bias_on_columns, accumulate, force_kernel, 0, stream);
+}
+
+int srgan_gemm(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai, int64_t sak, const float* B,
+               int64_t sbk, int64_t sbj, float* C, int64_t sci, int64_t scj, const float* bias,
+               int32_t bias_on_columns, int accumulate, int force_kernel, int compute_dtype, void* stream) {
   SRGAN_REQUIRE(M > 0 && N > 0 && K >= 0 && A && B && C, SRGAN_EINVAL, "srgan_gemm_f32 arguments");
+  SRGAN_REQUIRE(dtype_ok(compute_dtype), SRGAN_EINVAL, "srgan_gemm compute_dtype");
+  if (compute_dtype) force_kernel = 2;
   const int64_t lim = (int64_t)1 << 31;
   SRGAN_REQUIRE(M * sai + K * sak < lim && K * sbk + N * sbj < lim && M * sci + N * scj < lim, SRGAN_ERANGE,
                 "srgan_gemm_f32 extents");
@@ -1087,6 +1179,7 @@ int srgan_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sai,
     p = gg_transposed(p);
     choose_staging(p);
   }
+  p.precision = compute_dtype;
   std::vector<GatherGemm> plans{p};
   return gg_run_group(plans, C, (int64_t)M * N, accumulate, force_kernel, (hipStream_t)stream);
 }

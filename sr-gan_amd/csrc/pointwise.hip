@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __r
 
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
-                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
 float* partial_workspace(size_t bytes, hipStream_t stream);
 
 // g_beta[c] += sum_t partial[0][t][c];  g_gamma[c] += inv_std[c] * sum_t partial[1][t][c]   (t = workgroup tiles)

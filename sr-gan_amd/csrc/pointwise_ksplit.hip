@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
 
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
-                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
 
 bool pointwise_ksplit_enabled() {
   static const bool disabled = getenv("SRGAN_NO_PW_KSPLIT") != nullptr;

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradPa
 
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
-                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0);
+                        int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
 
 // The un-fused weight gradient stays on the generic gather-GEMM by default (measured equal: both are bound by the
 // operand stream at 64 x 64 tiles); this kernel serves the fused batch-norm form, where the generic one cannot.

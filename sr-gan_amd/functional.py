@@ -18,6 +18,29 @@ B_ADD, B_SUB, B_MUL, B_DIV, B_DIV_SAFE, B_MAX, B_LEAKY_MASK_MUL, B_AXPY = range(
 
 FORCE_KERNEL = 0   # tests set 1 (direct) / 2 (MFMA) to cross-check the two contraction kernels
 
+# MFMA operand type of the contractions launched from here on (include/srgan_hip.h SRGAN_COMPUTE_*): tensors stay fp32,
+# only the two operands of a convolution / linear pass are rounded when the matrix instruction is fed.  Read when an
+# operation LAUNCHES, so a backward pass runs in whatever mode is active while it is swept.
+COMPUTE_DTYPES = {'f32': 0, 'fp32': 0, 'bf16': 1, 'f16': 2, 'fp16': 2}
+COMPUTE_DTYPE = 0
+
+
+class compute_dtype:
+    """``with F.compute_dtype('bf16'): ...`` -- contractions launched inside use bf16 (or 'f16') MFMA operands with fp32
+    accumulation; 'f32' restores the exact path (e.g. around the gradient-penalty chain of an fp16 step)."""
+
+    def __init__(self, name):
+        self.code = COMPUTE_DTYPES[name] if isinstance(name, str) else int(name)
+
+    def __enter__(self):
+        global COMPUTE_DTYPE
+        self.previous, COMPUTE_DTYPE = COMPUTE_DTYPE, self.code
+        return self
+
+    def __exit__(self, *exc):
+        global COMPUTE_DTYPE
+        COMPUTE_DTYPE = self.previous
+
 
 # ------------------------------------------------------------------------------------------- plumbing
 def _stream():
@@ -417,7 +440,8 @@ def _conv_desc(x_shape, w_shape, stride, padding, y_shape):
     k, c2, r, s = w_shape
     if c != c2:
         raise ValueError(f'conv: input has {c} channels, weight expects {c2}')
-    return _lib.ConvDesc(n, c, h, w, k, r, s, stride[0], stride[1], padding[0], padding[1], y_shape[2], y_shape[3], 0, 0)
+    return _lib.ConvDesc(n, c, h, w, k, r, s, stride[0], stride[1], padding[0], padding[1], y_shape[2], y_shape[3], 0, 0,
+                         COMPUTE_DTYPE)
 
 
 def _pair(value):
@@ -497,8 +521,8 @@ def mm(a, b, transpose_a=False, transpose_b=False, bias=None, bias_on_columns=Tr
     sai, sak = (1, a.shape[1]) if transpose_a else (a.shape[1], 1)
     sbk, sbj = (1, b.shape[1]) if transpose_b else (b.shape[1], 1)
     data = _empty((m, n), a.data)
-    _call('srgan_gemm_f32', m, n, k, _ptr(a), sai, sak, _ptr(b), sbk, sbj, data.data_ptr(), n, 1, _ptr(bias),
-          1 if bias_on_columns else 0, 0, FORCE_KERNEL, _stream())
+    _call('srgan_gemm', m, n, k, _ptr(a), sai, sak, _ptr(b), sbk, sbj, data.data_ptr(), n, 1, _ptr(bias),
+          1 if bias_on_columns else 0, 0, FORCE_KERNEL, COMPUTE_DTYPE, _stream())
 
     def backward(g, needs):
         ga = gb = gbias = None

@@ -59,7 +59,7 @@ def _ptr(tensor, offset_elements=0):
 
 def _desc(n, c, h, w, k, r, s, stride, pad, x_bs=0, y_bs=0):
     oh, ow = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
-    return _lib.ConvDesc(n, c, h, w, k, r, s, stride, stride, pad, pad, oh, ow, x_bs, y_bs)
+    return _lib.ConvDesc(n, c, h, w, k, r, s, stride, stride, pad, pad, oh, ow, x_bs, y_bs, F.COMPUTE_DTYPE)
 
 
 def _empty(shape, device):

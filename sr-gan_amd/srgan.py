@@ -417,16 +417,38 @@ class Experiment(ABC):
             return None
         return self.dp.gradient_exchange(module._srgan_arena)
 
+    # ---- mixed precision (BASELINE.json configs 2 and 5; the reference is fp32-only) --------------------------------
+    def precision(self, phase='step'):
+        """The MFMA operand type of a phase as a context manager: ``settings.compute_dtype`` ('f32' default, 'bf16',
+        'f16') for the step, ``settings.gradient_penalty_dtype`` (default 'f32': "fp16 with fp32 GP") for the
+        gradient-penalty chain -- its forward, the recorded inner gradient and the penalty's own backward."""
+        name = getattr(self.settings, 'compute_dtype', 'f32')
+        if phase == 'penalty':
+            name = getattr(self.settings, 'gradient_penalty_dtype', 'f32')
+        return F.compute_dtype(name)
+
+    def scaled_backward(self, root, **arguments):
+        """``backward(root)`` with the root gradient set to ``settings.loss_scale`` (static loss scaling for the fp16 mode:
+        gradients of 1e-6 would otherwise reach the fp16 operands as subnormals); ``apply_update`` divides it out."""
+        scale = float(getattr(self.settings, 'loss_scale', 1.0))
+        return backward(root, grad=None if scale == 1.0 else F.full_like(root, scale), **arguments)
+
+    def apply_update(self, optimizer):
+        scale = float(getattr(self.settings, 'loss_scale', 1.0))
+        if scale != 1.0:
+            F._unary_raw(F.U_AFFINE, optimizer.arena.grad, 1.0 / scale, 0.0, out=optimizer.arena.grad)
+        optimizer.step()
+
     def start_update(self, name, optimizer, exchange):
         """The optimizer step of network ``name``: at once on a single device; under data parallelism after its gradient
         exchange, i.e. in ``finish_update`` -- the rest of the arena goes out now and the step continues meanwhile."""
         if exchange is None:
-            optimizer.step()
+            self.apply_update(optimizer)
             return
         exchange.finish()
         if not getattr(self.settings, 'overlap_gradient_exchange', True):
             exchange.wait()
-            optimizer.step()
+            self.apply_update(optimizer)
             return
         self._pending_updates[name] = (exchange, optimizer)
 
@@ -441,19 +463,20 @@ class Experiment(ABC):
             if side is not None:                    # the DNN's step and exchange live on the side stream
                 with torch.cuda.stream(side):
                     exchange.wait()
-                    optimizer.step()
+                    self.apply_update(optimizer)
             else:
                 exchange.wait()
-                optimizer.step()
+                self.apply_update(optimizer)
 
     def _dnn_training_step(self, examples, labels, step):
         self.DNN.apply(disable_batch_norm_updates)
         self.dnn_summary_writer.step = step
         self.finish_update('DNN')
         self.dnn_optimizer.zero_grad()
-        dnn_loss = self.dnn_loss_calculation(examples, labels)
         exchange = self.gradient_exchange(self.DNN)
-        backward(dnn_loss, grad_ready=exchange)
+        with self.precision():
+            dnn_loss = self.dnn_loss_calculation(examples, labels)
+            self.scaled_backward(dnn_loss, grad_ready=exchange)
         self.start_update('DNN', self.dnn_optimizer, exchange)       # finished at the end of gan_training_step
         self.last_losses['dnn_loss'] = dnn_loss
         if self.dnn_summary_writer.is_summary_step():
@@ -472,36 +495,39 @@ class Experiment(ABC):
         self.finish_update('G', 'D')         # the previous iteration's generator update (its exchange ran under the DNN step)
         self.d_optimizer.zero_grad()
         batch_size = unlabeled_examples.shape[0]
-        if getattr(settings, 'reference_schedule', False):
-            labeled_loss = self.labeled_loss_calculation(labeled_examples, labels)
-            backward(labeled_loss)
-            unlabeled_loss = self.unlabeled_loss_calculation(labeled_examples, unlabeled_examples)
-            backward(unlabeled_loss)
-            z = self.sample_discriminator_noise(batch_size)
-            with no_grad():
-                fake_examples = self.G(z)
-            fake_loss = self.fake_loss_calculation(unlabeled_examples, fake_examples)
-            backward(fake_loss)
-        else:
-            z = self.sample_discriminator_noise(batch_size)
-            with no_grad():
-                fake_examples = self.G(z)
-            labeled_loss, unlabeled_loss, fake_loss = self.discriminator_losses_shared_forwards(
-                labeled_examples, labels, unlabeled_examples, fake_examples)
-            backward(F.add(F.add(labeled_loss, unlabeled_loss), fake_loss))
-        gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
+        with self.precision():
+            if getattr(settings, 'reference_schedule', False):
+                labeled_loss = self.labeled_loss_calculation(labeled_examples, labels)
+                self.scaled_backward(labeled_loss)
+                unlabeled_loss = self.unlabeled_loss_calculation(labeled_examples, unlabeled_examples)
+                self.scaled_backward(unlabeled_loss)
+                z = self.sample_discriminator_noise(batch_size)
+                with no_grad():
+                    fake_examples = self.G(z)
+                fake_loss = self.fake_loss_calculation(unlabeled_examples, fake_examples)
+                self.scaled_backward(fake_loss)
+            else:
+                z = self.sample_discriminator_noise(batch_size)
+                with no_grad():
+                    fake_examples = self.G(z)
+                labeled_loss, unlabeled_loss, fake_loss = self.discriminator_losses_shared_forwards(
+                    labeled_examples, labels, unlabeled_examples, fake_examples)
+                self.scaled_backward(F.add(F.add(labeled_loss, unlabeled_loss), fake_loss))
         exchange = self.gradient_exchange(self.D)
-        backward(gradient_penalty, grad_ready=exchange)      # the last of the backward passes into D's arena (srgan.py:295)
+        with self.precision('penalty'):
+            gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
+            self.scaled_backward(gradient_penalty, grad_ready=exchange)   # the last backward pass into D's arena (srgan.py:295)
         self.start_update('D', self.d_optimizer, exchange)
         generator_loss = None
         if step % settings.generator_training_step_period == 0:
             self.g_optimizer.zero_grad()
             z = self.sample_generator_noise(batch_size)
-            fake_examples = self.G(z)                        # runs while D's gradients are still being exchanged
-            self.finish_update('D')
-            generator_loss = self.generator_loss_calculation(fake_examples, unlabeled_examples)
-            exchange = self.gradient_exchange(self.G)
-            backward(generator_loss, grad_ready=exchange)
+            with self.precision():
+                fake_examples = self.G(z)                        # runs while D's gradients are still being exchanged
+                self.finish_update('D')
+                generator_loss = self.generator_loss_calculation(fake_examples, unlabeled_examples)
+                exchange = self.gradient_exchange(self.G)
+                self.scaled_backward(generator_loss, grad_ready=exchange)
             self.start_update('G', self.g_optimizer, exchange)      # finished when G is next used (next iteration)
         self.finish_update('D', 'DNN')
         self.last_losses.update(labeled_loss=labeled_loss, unlabeled_loss=unlabeled_loss, fake_loss=fake_loss,
