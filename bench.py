@@ -56,7 +56,7 @@ WORKLOADS = {
                          settings=dict(compute_dtype='bf16', matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
                                        gradient_penalty_multiplier=1e2),
                          name='age SRGAN, VGG-16 D/DNN + DCGAN G on 64x64 faces (BASELINE.json configs[1]), bf16 MFMA operands'),
-    'driving-fp16': dict(application='driving', image_size=(64, 192), batch_per_gpu=128, gp_scale=2.2, dtype='f16',
+    'driving-fp16': dict(application='driving', image_size=(64, 192), batch_per_gpu=128, gp_scale=3.0, dtype='f16',
                          settings=dict(compute_dtype='f16', gradient_penalty_dtype='f32', loss_scale=256.0,
                                        matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
                                        gradient_penalty_multiplier=1e2),
