@@ -424,7 +424,9 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   if (p.epi_partial)
     bn_partial_reduce_run(p.epi_partial, p.epi_tiles, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
-  profile_bracket_end(profile_slot, stream, CO, (int64_t)N * H * W, (int64_t)CI * 9, 2, bm, th * 32, split);
+  const int64_t pixels3 = (int64_t)N * H * W;       // (+ x read by the fused batch-norm backward epilogue)
+  profile_bracket_end(profile_slot, stream, CO, pixels3, (int64_t)CI * 9, 2, bm, th * 32, split, 0, 0,
+                      (int64_t)CI * pixels3 + (epilogue ? (int64_t)CO * pixels3 : 0));
   return status;
 }
 

@@ -66,14 +66,9 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
   constexpr int EA = (AG + 255) / 256, EB = (BG + 255) / 256;     // groups per thread
   constexpr int LDA = BM + (VEC ? 4 : 1), LDB = BN + (VEC ? 4 : 1);
   static_assert(MI >= 1 && NI >= 1, "tile too small for 4 waves");
-  // Two LDS stages: the next K-slice is written into the other stage while the current one is still being read, so a
-  // K-step costs ONE barrier (the staging stores of a wave overlap the MFMAs of the waves that are still in the slice).
-  constexpr int STAGE = BK * LDA + BK * LDB;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
-  const float* As = lds;
-  const float* Bs = lds + BK * LDA;
-  float* As_w = lds;
-  float* Bs_w = lds + BK * LDA;
+  __shared__ __attribute__((aligned(16))) float lds[BK * LDA + BK * LDB];
+  float* As = lds;
+  float* Bs = lds + BK * LDA;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -156,11 +151,11 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
 #pragma unroll
       for (int i = 0; i < G; ++i) v[i] = ok ? ra[e][i] : 0.f;
       if (VEC && !AKF) {
-        *reinterpret_cast<float4*>(&As_w[a_kk[e] * LDA + a_ml[e]]) = make_float4(v[0], v[G > 1 ? 1 : 0], v[G > 2 ? 2 : 0],
+        *reinterpret_cast<float4*>(&As[a_kk[e] * LDA + a_ml[e]]) = make_float4(v[0], v[G > 1 ? 1 : 0], v[G > 2 ? 2 : 0],
                                                                                 v[G > 3 ? 3 : 0]);
       } else {
 #pragma unroll
-        for (int i = 0; i < G; ++i) As_w[(a_kk[e] + (AKF ? i : 0)) * LDA + a_ml[e] + (AKF ? 0 : i)] = v[i];
+        for (int i = 0; i < G; ++i) As[(a_kk[e] + (AKF ? i : 0)) * LDA + a_ml[e] + (AKF ? 0 : i)] = v[i];
       }
     }
 #pragma unroll
@@ -171,11 +166,11 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
 #pragma unroll
       for (int i = 0; i < G; ++i) v[i] = ok ? rb[e][i] : 0.f;
       if (VEC && !BKF) {
-        *reinterpret_cast<float4*>(&Bs_w[b_kk[e] * LDB + b_nl[e]]) = make_float4(v[0], v[G > 1 ? 1 : 0], v[G > 2 ? 2 : 0],
+        *reinterpret_cast<float4*>(&Bs[b_kk[e] * LDB + b_nl[e]]) = make_float4(v[0], v[G > 1 ? 1 : 0], v[G > 2 ? 2 : 0],
                                                                                 v[G > 3 ? 3 : 0]);
       } else {
 #pragma unroll
-        for (int i = 0; i < G; ++i) Bs_w[(b_kk[e] + (BKF ? i : 0)) * LDB + b_nl[e] + (BKF ? 0 : i)] = v[i];
+        for (int i = 0; i < G; ++i) Bs[(b_kk[e] + (BKF ? i : 0)) * LDB + b_nl[e] + (BKF ? 0 : i)] = v[i];
       }
     }
   };
@@ -240,13 +235,11 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
       }
-      if (more) {        // into the stage nobody reads during this slice (every wave left it at the previous barrier)
-        const int other = (As == lds) ? STAGE : 0;
-        As_w = lds + other; Bs_w = lds + other + BK * LDA;
-        stage();
-        As = As_w; Bs = Bs_w;
-      }
       __syncthreads();
+      if (more) {
+        stage();
+        __syncthreads();
+      }
     }
   }
 

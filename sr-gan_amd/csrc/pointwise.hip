@@ -531,7 +531,12 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   }
   if (p.epi_partial) bn_partial_reduce_run(p.epi_partial, (int)col_blocks, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
-  profile_bracket_end(profile_slot, stream, CO, (int64_t)N * HW, CI, 3, mi * 32, 128, split);
+  // algorithmic bytes of the fused epilogue: besides the operands, x is read for the mask and, in accumulate mode, the
+  // gradient buffer is read as well as written
+  const int64_t pixels = (int64_t)N * HW;
+  const int64_t b_elements = (int64_t)CI * pixels + (epilogue ? (int64_t)CO * pixels * (p.mode == 1 ? 2 : 1) : 0) +
+                             ((!epilogue && p.mode == 1) ? (int64_t)CO * pixels : 0);
+  profile_bracket_end(profile_slot, stream, CO, pixels, CI, 3, mi * 32, 128, split, 0, 0, b_elements);
   return status;
 }
 
