@@ -15,10 +15,13 @@
 // Roofline: fp32 MFMA (157.3 TF/s); algorithmic work 2 * 9 * CI * CO FLOP per output pixel.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace srgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct Conv3Params {
   const float* in;      // [N, CI, H, W] (batch stride in_bs)
@@ -49,9 +52,13 @@ constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range w
 // EPI = the backward of a frozen batch-norm + ReLU fused into the epilogue of the data gradient (reference
 // crowd/models.py:342-345 backwards: conv2 -> relu2 -> norm2): out = acc * [fma(x, a, b) > 0] * a, plus the workgroup's
 // two parameter-gradient row sums (store mode only, no split over input channels).
-template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false>
+// PREC = 1 / 2: bf16 / fp16 MFMA operands (v_mfma_f32_32x32x16_bf16 / _f16, fp32 accumulate; BASELINE.json configs 2 / 5):
+// the staged patch and weight slice stay fp32 in LDS, a 16-deep step is 16 input channels at ONE tap (CI_T = 16), and a
+// lane rounds the 8 channels of its half (8 * (lane >> 5) ... + 7) when it forms the fragments.
+template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
   static_assert(!EPI || !PRO, "the batch-norm backward epilogue pairs with the plain kernel");
+  static_assert(PREC == 0 || (CI_T % 16 == 0 && !PRO && !EPI), "mixed precision: plain kernel, 16-channel steps");
   constexpr int RPB = 32 / TW;                    // image rows per 32-lane column block
   constexpr int ROWS = TH * RPB;                  // image rows of the workgroup's tile
   constexpr int PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
@@ -149,8 +156,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
 
   // Per-lane LDS bases: the lane half selects the odd channel of a pair (constant offset), lanes 0..31 walk pixels
   // (B) or output channels (A); everything else below is a compile-time immediate.
-  const float* a_base = wt + lhi * 9 * LDW + l31;
-  const float* b_base = patch + lhi * PHPW + ((wave * NI) * RPB + l31 / TW) * PW + l31 % TW;
+  const float* a_base = wt + (PREC ? 0 : lhi * 9 * LDW) + l31;
+  const float* b_base = patch + (PREC ? 0 : lhi * PHPW) + ((wave * NI) * RPB + l31 / TW) * PW + l31 % TW;
 
   if (cbeg < cend) {
     fetch(cbeg);
@@ -169,6 +176,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
       if (more) fetch(c0 + CI_T);
       // (the channel-pair loop is kept rolled: full unrolling makes the scheduler hoist hundreds of LDS reads and
       // spill; the 9 taps x MI x NI MFMAs inside are plenty of straight-line work)
+      if constexpr (PREC != 0) {
+        using frag = typename std::conditional<PREC == 1, bf16x8, f16x8>::type;
+#pragma unroll 1
+        for (int g16 = 0; g16 < CI_T / 16; ++g16) {
+          const float* a_g = a_base + (g16 * 16 + 8 * lhi) * (9 * LDW);
+          const float* b_g = b_base + (g16 * 16 + 8 * lhi) * PHPW;
+#pragma unroll 1
+          for (int kh = 0; kh < 3; ++kh)          // rolled over the kernel rows: bounds the LDS values the scheduler hoists
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = kh * 3 + kw;
+            frag a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float v = a_g[(j * 9 + tap) * LDW + mi * 32];
+                if constexpr (PREC == 1) a[mi][j] = (__bf16)v; else a[mi][j] = (_Float16)v;
+              }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float v = b_g[j * PHPW + (ni * RPB + kh) * PW + kw];
+                if constexpr (PREC == 1) b[ni][j] = (__bf16)v; else b[ni][j] = (_Float16)v;
+              }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                if constexpr (PREC == 1) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+              }
+          }
+        }
+      } else
 #pragma unroll 1
       for (int cp = 0; cp < CI_T / 2; ++cp) {
         const float* a_cp = a_base + cp * (2 * 9 * LDW);
@@ -310,6 +353,17 @@ static void launch_conv3(const Conv3Params& p, int th, int tw, dim3 grid, hipStr
   else launch_conv3_w<BM, CI_T, 32>(p, th, grid, stream);
 }
 
+static void launch_conv3_mixed(const Conv3Params& p, int bm, int th, int tw, int precision, dim3 grid, hipStream_t stream) {
+  (void)bm; (void)th;                              // the mixed-precision plan is always 32 rows x 4 column blocks
+  if (precision == 1) {
+    if (tw == 16) hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 16, false, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 32, false, 1>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (tw == 16) hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 16, false, 2>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 32, false, 2>), grid, dim3(256), 0, stream, p);
+  }
+}
+
 // Declared in gather_gemm_kernels.hip: records a launch for the bench's live event timing.
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
@@ -325,7 +379,8 @@ bool conv3x3_enabled() {
 // into a pre-zeroed output) only as the last resort and never below two chunks per workgroup.
 struct Conv3Plan { int bm, th, tw, ci_t, tiles_x, tiles_y, tiles_m, split, chunks_per; int64_t blocks; };
 
-static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W, bool allow_split = true) {
+static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W, bool allow_split = true,
+                              int precision = 0) {
   Conv3Plan plan;
   const int tw = W <= 16 ? 16 : 32;      // 16-wide images: a 32-lane column block = two image rows (no dead columns)
   plan.tw = tw;
@@ -333,6 +388,8 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
   static const int bm_cap = getenv("SRGAN_CONV3_BM") ? atoi(getenv("SRGAN_CONV3_BM")) : 64;   // 64 rows: +0.4 % in-step over 128
   int bm = CO > 64 ? 128 : (CO > 32 ? 64 : 32);
   if (bm > bm_cap) bm = bm_cap;
+  if (precision) bm = 32;                     // mixed precision: 32-row tiles with 16-channel chunks (the staged registers of a
+                                              // 64-row tile spill under the 256-register budget of two workgroups per CU)
   static const int th_cap = getenv("SRGAN_CONV3_TH") ? atoi(getenv("SRGAN_CONV3_TH")) : 8;
   int th = (bm == 128 || tw == 16 || th_cap < 8) ? 4 : 8;   // 128 rows / 16-wide tiles always use 4 column blocks per workgroup
   auto rows = [&](int th_) { return th_ * (32 / tw); };
@@ -344,10 +401,12 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
     else if (bm > 32) { bm >>= 1; th = 4; }
     else break;
   }
+  if (precision) th = 4;
   plan.bm = bm; plan.th = th;
   static const int ci_t32 = getenv("SRGAN_CONV3_CIT32") ? atoi(getenv("SRGAN_CONV3_CIT32")) : 8;
   static const int ci_t64 = getenv("SRGAN_CONV3_CIT64") ? atoi(getenv("SRGAN_CONV3_CIT64")) : 4;
   plan.ci_t = bm == 128 ? 4 : (bm == 64 ? ci_t64 : ci_t32);     // keeps the staged registers + accumulators <= 256
+  if (precision) plan.ci_t = 16;
   plan.tiles_m = (CO + bm - 1) / bm;
   plan.tiles_y = (H + rows(th) - 1) / rows(th);
   plan.blocks = count(bm, th);
@@ -378,8 +437,11 @@ float* partial_workspace(size_t bytes, hipStream_t stream);
 // The caller guarantees dense-or-strided NCHW, 3x3 / stride 1 / pad 1.  `accumulate` adds into out.
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
-                int32_t W, int accumulate, hipStream_t stream, const float* const* bn, const BnBackwardEpilogue* epilogue) {
+                int32_t W, int accumulate, hipStream_t stream, const float* const* bn, const BnBackwardEpilogue* epilogue,
+                int precision) {
   Conv3Params p;
+  SRGAN_REQUIRE(precision == 0 || (bn == nullptr && epilogue == nullptr), SRGAN_EUNSUPPORTED,
+                "conv3x3 mixed precision: the fused batch-norm forms are fp32");
   p.in = in; p.w = w; p.out = out; p.bias = bias;
   p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
@@ -388,7 +450,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
   p.in_bs = in_bs; p.out_bs = out_bs;
   p.w_so = w_so; p.w_si = w_si; p.w_skh = w_skh; p.w_skw = w_skw; p.w_base = w_base;
-  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W, epilogue == nullptr);   // the epilogue needs whole sums per workgroup
+  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W, epilogue == nullptr, precision);   // (the epilogue needs whole sums per workgroup)
   const int bm = plan.bm, th = plan.th, tw = plan.tw, split = plan.split;
   p.tiles_x = plan.tiles_x; p.tiles_y = plan.tiles_y; p.tiles_m = plan.tiles_m;
   p.ci_per_split = plan.chunks_per * plan.ci_t;
@@ -416,7 +478,8 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);
   const int profile_slot = profile_bracket_begin(stream);
-  if (bm == 32 && plan.ci_t == 16) launch_conv3<32, 16>(p, th, tw, grid, stream);
+  if (precision) launch_conv3_mixed(p, bm, th, tw, precision, grid, stream);
+  else if (bm == 32 && plan.ci_t == 16) launch_conv3<32, 16>(p, th, tw, grid, stream);
   else if (bm == 32) launch_conv3<32, 8>(p, th, tw, grid, stream);
   else if (bm == 64 && plan.ci_t == 8) launch_conv3<64, 8>(p, th, tw, grid, stream);
   else if (bm == 64) launch_conv3<64, 4>(p, th, tw, grid, stream);
@@ -426,7 +489,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   const int status = launch_status();
   const int64_t pixels3 = (int64_t)N * H * W;       // (+ x read by the fused batch-norm backward epilogue)
   profile_bracket_end(profile_slot, stream, CO, pixels3, (int64_t)CI * 9, 2, bm, th * 32, split, 0, 0,
-                      (int64_t)CI * pixels3 + (epilogue ? (int64_t)CO * pixels3 : 0));
+                      (int64_t)CI * pixels3 + (epilogue ? (int64_t)CO * pixels3 : 0), precision);
   return status;
 }
 

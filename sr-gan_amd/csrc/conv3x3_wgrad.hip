@@ -14,10 +14,13 @@
 // the loaded value before the MFMA loop would make the compiler wait for the loads there).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace srgan {
 
 using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct Wgrad3Params {
   const float* x; const float* gy; float* gw;
@@ -34,7 +37,9 @@ constexpr int WG3_CI = 32;      // input channels per workgroup (one MFMA column
 constexpr int WG3_CO = 32;
 constexpr int WG3_THREADS = 192;
 
-template <int TH>
+// PREC = 1 / 2: bf16 / fp16 MFMA operands (v_mfma_f32_32x32x16_*): a 16-deep step is one 16-pixel tile row, a lane rounds
+// the 8 pixels of its half; the three kernel columns share one window of 10 patch values.
+template <int TH, int PREC = 0>
 __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgrad3Params p) {
   constexpr int PW = WG3_TW + 2, PH = TH + 2;
   constexpr int PATCH = PH * PW;            // halo patch of one channel
@@ -60,8 +65,8 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const float* a_base = gs + l31 * GS + lhi;
-  const float* b_base = xs + l31 * PS + kh * PW + lhi;
+  const float* a_base = gs + l31 * GS + (PREC ? 8 * lhi : lhi);
+  const float* b_base = xs + l31 * PS + kh * PW + (PREC ? 8 * lhi : lhi);
 
   // Staging ownership: thread -> (row, channel).  x: one patch row of one input channel = the 6 aligned float4 that
   // cover columns [w0 - 4, w0 + 20) (18 of the 24 floats are the halo row); gy: one tile row of one output channel =
@@ -154,6 +159,30 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
     const int next = tile + (int)gridDim.x;
     if (next < p.tiles) fetch(next);
 
+    if constexpr (PREC != 0) {
+      using frag = typename std::conditional<PREC == 1, bf16x8, f16x8>::type;
+#pragma unroll 1
+      for (int h = 0; h < TH; ++h) {
+        frag a, b[3];
+        float window[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) window[j] = b_base[h * PW + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = a_base[h * WG3_TW + j];
+          if constexpr (PREC == 1) a[j] = (__bf16)v; else a[j] = (_Float16)v;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            if constexpr (PREC == 1) b[kw][j] = (__bf16)window[j + kw]; else b[kw][j] = (_Float16)window[j + kw];
+          }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          if constexpr (PREC == 1) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[kw], acc[kw], 0, 0, 0);
+          else acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[kw], acc[kw], 0, 0, 0);
+        }
+      }
+    } else
 #pragma unroll 1
     for (int h = 0; h < TH; ++h) {          // rolled: bounds the LDS values the scheduler keeps in flight
 #pragma unroll
@@ -204,7 +233,8 @@ bool conv3x3_wgrad_enabled() {
 
 // gw (=,+=) the weight gradient; x / gy may be channel-slice views (batch strides in elements).
 int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn) {
+                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn,
+                      int precision) {
   static const int th_override = getenv("SRGAN_WGRAD3_TH") ? atoi(getenv("SRGAN_WGRAD3_TH")) : 0;
   Wgrad3Params p;
   p.x = x; p.gy = gy; p.gw = gw; p.x_bs = x_bs; p.gy_bs = gy_bs;
@@ -235,10 +265,12 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)CO * CI * 9 * sizeof(float), stream));
   dim3 grid((unsigned)walkers, (unsigned)ci_chunks, (unsigned)co_chunks);
   const int profile_slot = profile_bracket_begin(stream);
-  if (th == 4) hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WG3_THREADS), 0, stream, p);
+  if (precision == 1) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1>), grid, dim3(WG3_THREADS), 0, stream, p);
+  else if (precision == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2>), grid, dim3(WG3_THREADS), 0, stream, p);
+  else if (th == 4) hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WG3_THREADS), 0, stream, p);
   else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(WG3_THREADS), 0, stream, p);
   const int status = launch_status();
-  profile_bracket_end(profile_slot, stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers);
+  profile_bracket_end(profile_slot, stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers, 0, 0, 0, precision);
   return status;
 }
 

@@ -689,7 +689,7 @@ bool conv3x3_enabled();
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
                 int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
-                const BnBackwardEpilogue* epilogue = nullptr);
+                const BnBackwardEpilogue* epilogue = nullptr, int precision = 0);
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 
 bool pointwise_enabled();
@@ -718,7 +718,8 @@ static bool use_conv3x3(const ConvGeom& g, int out_channels, int force) {
 
 bool conv3x3_wgrad_enabled();
 int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
+                      int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
+                      int precision = 0);
 
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution with at least one wave's worth of input channels: the
 // LDS-patch kernel of conv3x3_wgrad.hip.
@@ -862,7 +863,10 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   SRGAN_REQUIRE(x && w && y, SRGAN_EINVAL, "srgan_conv2d_fwd pointers");
   const int dtype = desc->compute_dtype;
   SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_fwd compute_dtype");
-  if (dtype) force_kernel = 2;      // mixed precision lives in the generic MFMA kernel
+  if (dtype && force_kernel == 0 && use_conv3x3(g, g.K, 0))        // mixed precision: the LDS-halo 3x3 kernel, or
+    return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, 0, (hipStream_t)stream,
+                       nullptr, nullptr, dtype);
+  if (dtype) force_kernel = 2;                                      // the generic MFMA kernel for every other geometry
   if (use_pointwise(g, g.K, force_kernel) && ((uintptr_t)w & 15) == 0 &&
       pointwise_ksplit_wanted(g.N, g.C, g.K, g.H * g.W, false))
     return pointwise_ksplit_run(x, g.x_bs, w, bias, y, g.y_bs, g.N, g.C, g.K, g.H * g.W, 0, (hipStream_t)stream, nullptr);
@@ -899,6 +903,9 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
   SRGAN_REQUIRE(g.x_bs == (int64_t)g.C * g.H * g.W, SRGAN_EUNSUPPORTED, "srgan_conv2d_bwd_data dense gx");
   const int dtype = desc->compute_dtype;
   SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_bwd_data compute_dtype");
+  if (dtype && force_kernel == 0 && use_conv3x3(g, g.C, 0))
+    return conv3x3_run(gy, g.y_bs, w, 8, 9, g.C * 9, -3, -1, bias, gx, g.x_bs, g.N, g.K, g.C, g.H, g.W, accumulate,
+                       (hipStream_t)stream, nullptr, nullptr, dtype);
   if (dtype) force_kernel = 2;
   if (use_pointwise(g, g.C, force_kernel))   // the data gradient of a 1x1 convolution is the 1x1 convolution with W^T
     return pointwise_run(gy, g.y_bs, w, 1, g.C, bias, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
@@ -918,6 +925,9 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
   const int dtype = desc->compute_dtype;
   SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_bwd_weight compute_dtype");
+  if (dtype && force_kernel == 0 && use_wgrad3x3(g, x, gy, 0))
+    return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream, nullptr,
+                             dtype);
   if (dtype) force_kernel = 2;
   if (use_pointwise_wgrad(g, x, gy, force_kernel))
     return pointwise_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, accumulate, (hipStream_t)stream);
