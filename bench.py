@@ -53,9 +53,10 @@ LOW_PRECISION_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 (MI355X_MICROARCH.m
 WORKLOADS = {
     'crowd': None,
     'age-vgg-bf16': dict(application='age', architecture='vgg', image_size=64, batch_per_gpu=128, gp_scale=1.3, dtype='bf16',
-                         settings=dict(compute_dtype='bf16', matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
-                                       gradient_penalty_multiplier=1e2),
-                         name='age SRGAN, VGG-16 D/DNN + DCGAN G on 64x64 faces (BASELINE.json configs[1]), bf16 MFMA operands'),
+                         settings=dict(compute_dtype='bf16', gradient_penalty_dtype='bf16', matching_loss_multiplier=1e2,
+                                       contrasting_loss_multiplier=1e1, gradient_penalty_multiplier=1e2),
+                         name='age SRGAN, VGG-16 D/DNN + DCGAN G on 64x64 faces (BASELINE.json configs[1]), bf16 MFMA operands (gradient-penalty '
+                              'chain included)'),
     'driving-fp16': dict(application='driving', image_size=(64, 192), batch_per_gpu=128, gp_scale=3.0, dtype='f16',
                          settings=dict(compute_dtype='f16', gradient_penalty_dtype='f32', loss_scale=256.0,
                                        matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,

@@ -40,6 +40,7 @@ struct Conv3Params {
   // OUTPUT channels, see BnBackwardEpilogue); epi_partial[q][workgroup tile][CO] receives the parameter-gradient sums
   const float* epi_x; int64_t epi_x_bs;
   float* epi_partial; int32_t epi_tiles;
+  const void* w_packed;   // mixed precision: the weights repacked by conv3x3_pack_weights_kernel (16-byte operand slots)
 };
 
 constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range whose (a, b) fit the LDS table
@@ -52,13 +53,9 @@ constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range w
 // EPI = the backward of a frozen batch-norm + ReLU fused into the epilogue of the data gradient (reference
 // crowd/models.py:342-345 backwards: conv2 -> relu2 -> norm2): out = acc * [fma(x, a, b) > 0] * a, plus the workgroup's
 // two parameter-gradient row sums (store mode only, no split over input channels).
-// PREC = 1 / 2: bf16 / fp16 MFMA operands (v_mfma_f32_32x32x16_bf16 / _f16, fp32 accumulate; BASELINE.json configs 2 / 5):
-// the staged patch and weight slice stay fp32 in LDS, a 16-deep step is 16 input channels at ONE tap (CI_T = 16), and a
-// lane rounds the 8 channels of its half (8 * (lane >> 5) ... + 7) when it forms the fragments.
-template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false, int PREC = 0>
+template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
   static_assert(!EPI || !PRO, "the batch-norm backward epilogue pairs with the plain kernel");
-  static_assert(PREC == 0 || (CI_T % 16 == 0 && !PRO && !EPI), "mixed precision: plain kernel, 16-channel steps");
   constexpr int RPB = 32 / TW;                    // image rows per 32-lane column block
   constexpr int ROWS = TH * RPB;                  // image rows of the workgroup's tile
   constexpr int PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
@@ -156,8 +153,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
 
   // Per-lane LDS bases: the lane half selects the odd channel of a pair (constant offset), lanes 0..31 walk pixels
   // (B) or output channels (A); everything else below is a compile-time immediate.
-  const float* a_base = wt + (PREC ? 0 : lhi * 9 * LDW) + l31;
-  const float* b_base = patch + (PREC ? 0 : lhi * PHPW) + ((wave * NI) * RPB + l31 / TW) * PW + l31 % TW;
+  const float* a_base = wt + lhi * 9 * LDW + l31;
+  const float* b_base = patch + lhi * PHPW + ((wave * NI) * RPB + l31 / TW) * PW + l31 % TW;
 
   if (cbeg < cend) {
     fetch(cbeg);
@@ -176,42 +173,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
       if (more) fetch(c0 + CI_T);
       // (the channel-pair loop is kept rolled: full unrolling makes the scheduler hoist hundreds of LDS reads and
       // spill; the 9 taps x MI x NI MFMAs inside are plenty of straight-line work)
-      if constexpr (PREC != 0) {
-        using frag = typename std::conditional<PREC == 1, bf16x8, f16x8>::type;
-#pragma unroll 1
-        for (int g16 = 0; g16 < CI_T / 16; ++g16) {
-          const float* a_g = a_base + (g16 * 16 + 8 * lhi) * (9 * LDW);
-          const float* b_g = b_base + (g16 * 16 + 8 * lhi) * PHPW;
-#pragma unroll 1
-          for (int kh = 0; kh < 3; ++kh)          // rolled over the kernel rows: bounds the LDS values the scheduler hoists
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int tap = kh * 3 + kw;
-            frag a[MI], b[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float v = a_g[(j * 9 + tap) * LDW + mi * 32];
-                if constexpr (PREC == 1) a[mi][j] = (__bf16)v; else a[mi][j] = (_Float16)v;
-              }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float v = b_g[j * PHPW + (ni * RPB + kh) * PW + kw];
-                if constexpr (PREC == 1) b[ni][j] = (__bf16)v; else b[ni][j] = (_Float16)v;
-              }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni) {
-                if constexpr (PREC == 1) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-                else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-              }
-          }
-        }
-      } else
 #pragma unroll 1
       for (int cp = 0; cp < CI_T / 2; ++cp) {
         const float* a_cp = a_base + cp * (2 * 9 * LDW);
@@ -331,6 +292,196 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
   }
 }
 
+// ---- mixed precision (BASELINE.json configs 2 / 5: bf16, fp16) ------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 / _f16 take 8 consecutive-k values per lane (16 B).  Here k = 16 input channels at one tap and
+// the LDS tiles are stored IN THE OPERAND TYPE, grouped so that a fragment is ONE ds_read_b128:
+//   patch  [2 channel groups of 8][(TH*RPB + 2) x (TW + 2) pixels]   16 B per (group, pixel)
+//   weights[9 taps][2 channel groups][BM output channels]            16 B per (tap, group, output channel)
+// Lanes 0-31 (pixels / output channels) read consecutive 16-byte slots and the lane half selects the channel group:
+// conflict-free by construction.  Staging: a thread gathers the 8 channels of one (group, pixel) slot -- eight loads,
+// each coalesced across the lanes along the image row -- rounds them (v_cvt_pk_*) and writes one 16-byte slot; the data
+// in HBM stays fp32 and accumulation is fp32 (the C/D fragment, bias and store modes are those of the fp32 kernel).
+// Two LDS stages: the next 16-channel chunk is converted and written while the current one is in the matrix pipe.
+struct alignas(16) Half8 { uint32_t v[4]; };
+
+template <int PREC>
+__device__ __forceinline__ Half8 pack8(const float (&x)[8]) {
+  Half8 out;
+  if constexpr (PREC == 1) {
+    bf16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (__bf16)x[j];
+    out = *reinterpret_cast<Half8*>(&h);
+  } else {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)x[j];
+    out = *reinterpret_cast<Half8*>(&h);
+  }
+  return out;
+}
+
+// Weights in operand slots: packed[((chunk * 9 + tap) * 2 + group) * CO + o] = the 8 channels chunk * 16 + group * 8 ... + 7 of
+// tap `tap` of output channel o, rounded to the operand type (zero beyond CI).  One thread per slot: the gather over the
+// strided fp32 weight tensor happens ONCE per convolution call here (a few microseconds) instead of in every workgroup of
+// the convolution, whose weight staging then is a handful of coalesced 16-byte loads per chunk.
+template <int PREC>
+__global__ __launch_bounds__(256) void conv3x3_pack_weights_kernel(const Conv3Params p, Half8* __restrict__ packed, int slots) {
+  const int slot = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (slot >= slots) return;
+  const int o = slot % p.CO, rest = slot / p.CO;
+  const int g = rest & 1, ct = rest >> 1;
+  const int tap = ct % 9, chunk = ct / 9;
+  const int kh = tap / 3, kw = tap - kh * 3;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = chunk * 16 + g * 8 + j;
+    v[j] = c < p.CI ? p.w[p.w_base + o * p.w_so + c * p.w_si + kh * p.w_skh + kw * p.w_skw] : 0.f;
+  }
+  packed[slot] = pack8<PREC>(v);
+}
+
+template <int BM, int TH, int TW, int PREC>
+__global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params p) {
+  constexpr int RPB = 32 / TW, ROWS = TH * RPB, PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
+  constexpr int MI = BM / 32, NI = TH / 4;
+  constexpr int PATCH_Q = 2 * PHPW, WT_Q = 9 * 2 * BM, STAGE_Q = PATCH_Q + WT_Q;       // in 16-byte slots
+  constexpr int NP = (PATCH_Q + 255) / 256, NW = (WT_Q + 255) / 256;
+  using frag = typename std::conditional<PREC == 1, bf16x8, f16x8>::type;
+  __shared__ Half8 lds[2 * STAGE_Q];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  int block = blockIdx.x;
+  const int tm = block % p.tiles_m; block /= p.tiles_m;
+  const int tx = block % p.tiles_x; block /= p.tiles_x;
+  const int ty = block % p.tiles_y;
+  const int n = block / p.tiles_y;
+  const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
+  const int cbeg = (int)blockIdx.y * p.ci_per_split;
+  const int cend = min(p.CI, cbeg + p.ci_per_split);
+  const int HW = p.H * p.W;
+
+  // staging slots of this thread: patch (group, pixel) and weight (tap, group, output channel)
+  int poff[NP], pgrp[NP], woff[NW];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) {
+    const int flat = e * 256 + tid;
+    const int g = flat / PHPW, pix = flat - g * PHPW;
+    const int py = pix / PW, px = pix - py * PW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool ok = flat < PATCH_Q && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    poff[e] = ok ? y * p.W + x : -1;
+    pgrp[e] = g;
+  }
+#pragma unroll
+  for (int e = 0; e < NW; ++e) {
+    const int flat = e * 256 + tid;
+    const int o = flat % BM, tg = flat / BM;                 // lanes walk the output channels: consecutive slots in LDS
+    const bool ok = flat < WT_Q && (m0 + o) < p.CO;          // and in the packed tensor ((tap * 2 + group) * CO + o)
+    woff[e] = ok ? tg * p.CO + m0 + o : -1;
+  }
+  const float* in_n = p.in + (int64_t)n * p.in_bs;
+  const Half8* packed = reinterpret_cast<const Half8*>(p.w_packed);
+
+  float rp[NP][8];
+  Half8 rw[NW];
+  auto fetch = [&](int c0) {                                // raw loads only: validity is applied at stage time
+#pragma unroll
+    for (int e = 0; e < NP; ++e)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + 8 * pgrp[e] + j;
+        const bool ok = poff[e] >= 0 && c < cend;
+        rp[e][j] = in_n[ok ? (int64_t)c * HW + poff[e] : 0];
+      }
+#pragma unroll
+    for (int e = 0; e < NW; ++e) rw[e] = packed[(int64_t)(c0 / 16) * (18 * p.CO) + (woff[e] >= 0 ? woff[e] : 0)];
+  };
+  auto stage = [&](int c0, Half8* stage_base) {
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int flat = e * 256 + tid;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (poff[e] >= 0 && c0 + 8 * pgrp[e] + j < cend) ? rp[e][j] : 0.f;
+      if (flat < PATCH_Q) stage_base[flat] = pack8<PREC>(v);
+    }
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int flat = e * 256 + tid;                      // slot (tap, group, o) with o fastest: [(tap * 2 + g) * BM + o]
+      Half8 v = rw[e];
+      if (woff[e] < 0) v = Half8{{0u, 0u, 0u, 0u}};
+      if (flat < WT_Q) stage_base[PATCH_Q + flat] = v;
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int b_lane = lhi * PHPW + ((wave * NI) * RPB + l31 / TW) * PW + l31 % TW;      // + (ni * RPB + kh) * PW + kw
+  const int a_lane = PATCH_Q + lhi * BM + l31;                                            // + tap * 2 * BM + mi * 32
+
+  if (cbeg < cend) {
+    fetch(cbeg);
+    stage(cbeg, lds);
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = cbeg; c0 < cend; c0 += 16) {
+      const bool more = c0 + 16 < cend;
+      if (more) fetch(c0 + 16);
+      const Half8* st = lds + cur * STAGE_Q;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        frag a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag*>(&st[a_lane + tap * 2 * BM + mi * 32]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const frag*>(&st[b_lane + (ni * RPB + kh) * PW + kw]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (PREC == 1) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+          }
+      }
+      if (more) stage(c0 + 16, lds + (cur ^ 1) * STAGE_Q);     // the other stage: everyone left it at the previous barrier
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  const int x = x0 + l31 % TW;
+  float* out_n = p.out + (int64_t)n * p.out_bs;
+  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int y = y0 + (wave * NI + ni) * RPB + l31 / TW;
+    if (y >= p.H || x >= p.W) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (o >= p.CO) continue;
+        float v = acc[mi][ni][r];
+        if (add_bias) v += p.bias[o];
+        float* dst = out_n + (int64_t)o * HW + y * p.W + x;
+        if (p.mode == 0) __builtin_nontemporal_store(v, dst);
+        else if (p.mode == 1) *dst += v;
+        else unsafeAtomicAdd(dst, v);
+      }
+    }
+  }
+}
+
 template <int BM, int CI_T, int TW>
 static void launch_conv3_w(const Conv3Params& p, int th, dim3 grid, hipStream_t stream) {
   if (p.epi_x) {                       // (the plan admits the epilogue for 32- and 64-row tiles only)
@@ -353,14 +504,20 @@ static void launch_conv3(const Conv3Params& p, int th, int tw, dim3 grid, hipStr
   else launch_conv3_w<BM, CI_T, 32>(p, th, grid, stream);
 }
 
+template <int BM, int PREC>
+static void launch_conv3_mixed_bm(const Conv3Params& p, int th, int tw, dim3 grid, hipStream_t stream) {
+  if (tw == 16) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 16, PREC>), grid, dim3(256), 0, stream, p);
+  else if (th == 8) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 8, 32, PREC>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 32, PREC>), grid, dim3(256), 0, stream, p);
+}
+
 static void launch_conv3_mixed(const Conv3Params& p, int bm, int th, int tw, int precision, dim3 grid, hipStream_t stream) {
-  (void)bm; (void)th;                              // the mixed-precision plan is always 32 rows x 4 column blocks
   if (precision == 1) {
-    if (tw == 16) hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 16, false, 1>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 32, false, 1>), grid, dim3(256), 0, stream, p);
+    if (bm == 64) launch_conv3_mixed_bm<64, 1>(p, th, tw, grid, stream);
+    else launch_conv3_mixed_bm<32, 1>(p, th, tw, grid, stream);
   } else {
-    if (tw == 16) hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 16, false, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_lds_kernel<32, 4, 16, false, 32, false, 2>), grid, dim3(256), 0, stream, p);
+    if (bm == 64) launch_conv3_mixed_bm<64, 2>(p, th, tw, grid, stream);
+    else launch_conv3_mixed_bm<32, 2>(p, th, tw, grid, stream);
   }
 }
 
@@ -388,8 +545,7 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
   static const int bm_cap = getenv("SRGAN_CONV3_BM") ? atoi(getenv("SRGAN_CONV3_BM")) : 64;   // 64 rows: +0.4 % in-step over 128
   int bm = CO > 64 ? 128 : (CO > 32 ? 64 : 32);
   if (bm > bm_cap) bm = bm_cap;
-  if (precision) bm = 32;                     // mixed precision: 32-row tiles with 16-channel chunks (the staged registers of a
-                                              // 64-row tile spill under the 256-register budget of two workgroups per CU)
+  if (precision && bm > 64) bm = 64;          // mixed precision: 32- / 64-row tiles, 16-channel chunks
   static const int th_cap = getenv("SRGAN_CONV3_TH") ? atoi(getenv("SRGAN_CONV3_TH")) : 8;
   int th = (bm == 128 || tw == 16 || th_cap < 8) ? 4 : 8;   // 128 rows / 16-wide tiles always use 4 column blocks per workgroup
   auto rows = [&](int th_) { return th_ * (32 / tw); };
@@ -401,7 +557,6 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
     else if (bm > 32) { bm >>= 1; th = 4; }
     else break;
   }
-  if (precision) th = 4;
   plan.bm = bm; plan.th = th;
   static const int ci_t32 = getenv("SRGAN_CONV3_CIT32") ? atoi(getenv("SRGAN_CONV3_CIT32")) : 8;
   static const int ci_t64 = getenv("SRGAN_CONV3_CIT64") ? atoi(getenv("SRGAN_CONV3_CIT64")) : 4;
@@ -445,7 +600,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   p.in = in; p.w = w; p.out = out; p.bias = bias;
   p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
-  p.epi_x = nullptr; p.epi_x_bs = 0; p.epi_partial = nullptr; p.epi_tiles = 0;
+  p.epi_x = nullptr; p.epi_x_bs = 0; p.epi_partial = nullptr; p.epi_tiles = 0; p.w_packed = nullptr;
   SRGAN_REQUIRE(bn == nullptr || CI <= CONV3_PRO_MAX_CI, SRGAN_EUNSUPPORTED, "conv3x3 fused batch-norm channel count");
   p.N = N; p.CI = CI; p.CO = CO; p.H = H; p.W = W;
   p.in_bs = in_bs; p.out_bs = out_bs;
@@ -478,7 +633,17 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   }
   dim3 grid((unsigned)blocks, (unsigned)split, 1);
   const int profile_slot = profile_bracket_begin(stream);
-  if (precision) launch_conv3_mixed(p, bm, th, tw, precision, grid, stream);
+  if (precision) {
+    // the weights in operand slots, in the caller's workspace (2 bytes per weight element, padded to 16-channel chunks)
+    const int slots = ((CI + 15) / 16) * 18 * CO;
+    Half8* packed = reinterpret_cast<Half8*>(partial_workspace((size_t)slots * sizeof(Half8), stream));
+    SRGAN_REQUIRE(packed, SRGAN_EINVAL, "conv3x3 mixed precision: register a workspace for this stream first "
+                  "(srgan_set_workspace, >= srgan_workspace_bytes(); the packed weights take 2 bytes per element)");
+    if (precision == 1) hipLaunchKernelGGL(conv3x3_pack_weights_kernel<1>, dim3((slots + 255) / 256), dim3(256), 0, stream, p, packed, slots);
+    else hipLaunchKernelGGL(conv3x3_pack_weights_kernel<2>, dim3((slots + 255) / 256), dim3(256), 0, stream, p, packed, slots);
+    p.w_packed = packed;
+    launch_conv3_mixed(p, bm, th, tw, precision, grid, stream);
+  }
   else if (bm == 32 && plan.ci_t == 16) launch_conv3<32, 16>(p, th, tw, grid, stream);
   else if (bm == 32) launch_conv3<32, 8>(p, th, tw, grid, stream);
   else if (bm == 64 && plan.ci_t == 8) launch_conv3<64, 8>(p, th, tw, grid, stream);

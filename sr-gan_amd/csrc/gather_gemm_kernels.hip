@@ -723,8 +723,8 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
 
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution with at least one wave's worth of input channels: the
 // LDS-patch kernel of conv3x3_wgrad.hip.
-static bool wgrad3x3_geometry(const ConvGeom& g) {
-  return g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.W >= 16 && g.W % 4 == 0 &&
+static bool wgrad3x3_geometry(const ConvGeom& g, int min_width = 16) {
+  return g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.W >= min_width && g.W % 4 == 0 &&
          g.C >= 32 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0;
 }
 
@@ -925,7 +925,10 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   SRGAN_REQUIRE(x && gy && gw, SRGAN_EINVAL, "srgan_conv2d_bwd_weight pointers");
   const int dtype = desc->compute_dtype;
   SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_bwd_weight compute_dtype");
-  if (dtype && force_kernel == 0 && use_wgrad3x3(g, x, gy, 0))
+  // (mixed precision also takes 8-wide planes on the 16-wide tile: half of the columns are dead, but the alternative is
+  // the gather-bound generic kernel)
+  if (dtype && force_kernel == 0 && conv3x3_wgrad_enabled() && wgrad3x3_geometry(g, 8) &&
+      (((uintptr_t)x | (uintptr_t)gy) & 15) == 0)
     return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream, nullptr,
                              dtype);
   if (dtype) force_kernel = 2;

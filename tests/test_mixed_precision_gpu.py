@@ -32,9 +32,11 @@ def F():
     return functional
 
 
-CONVS = [  # (n, c, h, w, k, r, stride, pad): VGG 3x3, DCGAN k4 s2 p1, stem-like 7x7 s2, 1x1, ragged extents
+CONVS = [  # (n, c, h, w, k, r, stride, pad): VGG 3x3 (32-, 16-, 8- and 4-wide planes, channel tails), DCGAN k4 s2 p1,
+    # stem-like 7x7 s2, 1x1, ragged extents
     (2, 64, 16, 16, 64, 3, 1, 1), (3, 24, 12, 20, 40, 4, 2, 1), (2, 3, 31, 29, 16, 7, 2, 3), (2, 96, 8, 8, 48, 1, 1, 0),
-    (1, 130, 9, 7, 70, 3, 1, 1)]
+    (1, 130, 9, 7, 70, 3, 1, 1), (2, 48, 40, 36, 100, 3, 1, 1), (4, 128, 8, 8, 96, 3, 1, 1), (3, 64, 4, 4, 64, 3, 1, 1),
+    (2, 3, 64, 64, 64, 3, 1, 1)]
 
 
 def _passes(F, x, w, gy, stride, pad):
@@ -166,8 +168,10 @@ def _step_against_fp32_oracle(experiment_class, configure, oracle_networks, size
             assert np.abs(have - want).max() <= 2.2e-4 + 1e-3 * np.abs(want).max(), f'{name} {pname}'
 
 
-def test_age_vgg_step_in_bf16(monkeypatch):
-    """BASELINE.json configs[1]: age SRGAN, VGG-16 discriminator on 64 x 64 faces, bf16 MFMA operands."""
+@pytest.mark.parametrize('penalty_dtype', ['f32', 'bf16'])
+def test_age_vgg_step_in_bf16(monkeypatch, penalty_dtype):
+    """BASELINE.json configs[1]: age SRGAN, VGG-16 discriminator on 64 x 64 faces, bf16 MFMA operands -- with the
+    gradient-penalty chain in fp32 (the default) and in bf16 as well."""
     import srgan_amd.age.srgan as age
     from oracle import models as OM
     monkeypatch.setattr(age, 'model_architecture', 'vgg')
@@ -176,7 +180,8 @@ def test_age_vgg_step_in_bf16(monkeypatch):
         experiment.image_size = 64
     _step_against_fp32_oracle(age.AgeExperiment, configure,
                               lambda: (OM.DCGANGenerator(image_size=64), OM.VGG16(1, 64), OM.VGG16(1, 64)),
-                              size=64, batch=8, d_scale=1.3, settings_overrides=dict(compute_dtype='bf16'), tolerance=5e-2)
+                              size=64, batch=8, d_scale=1.3,
+                              settings_overrides=dict(compute_dtype='bf16', gradient_penalty_dtype=penalty_dtype), tolerance=5e-2)
 
 
 def test_driving_step_in_fp16_with_the_gradient_penalty_in_fp32():
