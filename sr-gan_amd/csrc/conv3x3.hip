@@ -41,9 +41,17 @@ struct Conv3Params {
   const float* epi_x; int64_t epi_x_bs;
   float* epi_partial; int32_t epi_tiles;
   const void* w_packed;   // mixed precision: the weights repacked by conv3x3_pack_weights_kernel (16-byte operand slots)
+  // Output placement: element (o, y, x) of the H x W grid the kernel walks goes to out[o * out_plane + y * out_sy +
+  // x * out_sx + out_off] (a plain convolution: H * W, W, 1, 0; a stride-2 class of a transposed convolution writes every
+  // other pixel of a 2H x 2W plane) and `taps` is the 9-bit mask of the window positions (kh * 3 + kw) that exist.
+  int32_t out_plane, out_sy, out_sx, out_off;
+  int32_t taps;
 };
 
-constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range whose (a, b) fit the LDS table
+constexpr int CONV3_PRO_MAX_CI = 512;
+
+// A stride-2 class of a k4 / s2 / p1 transposed convolution as a 2x2 sub-window of the 3x3 kernel (see conv3x3_run).
+struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off; };   // channels of one workgroup's K range whose (a, b) fit the LDS table
 
 // PRO = frozen batch-norm + ReLU fused into the patch staging (reference crowd/models.py:342-345: norm2, relu2,
 // conv2): the (a, b) of the workgroup's input channels sit in a small LDS table and every patch element goes through
@@ -53,9 +61,12 @@ constexpr int CONV3_PRO_MAX_CI = 512;   // channels of one workgroup's K range w
 // EPI = the backward of a frozen batch-norm + ReLU fused into the epilogue of the data gradient (reference
 // crowd/models.py:342-345 backwards: conv2 -> relu2 -> norm2): out = acc * [fma(x, a, b) > 0] * a, plus the workgroup's
 // two parameter-gradient row sums (store mode only, no split over input channels).
-template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false>
+// TAPS: compile-time mask of the window positions the inner loop multiplies (0x1FF = the full 3x3 window; the four
+// stride-2 classes of a k4 / s2 / p1 transposed convolution are 2x2 sub-windows: 0x01B, 0x036, 0x0D8, 0x1B0).
+template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false, int TAPS = 0x1FF>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
   static_assert(!EPI || !PRO, "the batch-norm backward epilogue pairs with the plain kernel");
+  static_assert(TAPS == 0x1FF || (!EPI && !PRO), "tap subsets pair with the plain kernel");
   constexpr int RPB = 32 / TW;                    // image rows per 32-lane column block
   constexpr int ROWS = TH * RPB;                  // image rows of the workgroup's tile
   constexpr int PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     const int o = flat / (CI_T * 9), r = flat - o * (CI_T * 9);     // r = ci_local * 9 + tap : lanes walk r
     const int ci = r / 9, tap = r - ci * 9;
     const int kh = tap / 3, kw = tap - kh * 3;
-    const bool ok = flat < WTS && (m0 + o) < p.CO;
+    const bool ok = flat < WTS && (m0 + o) < p.CO && ((p.taps >> tap) & 1);     // (a missing tap stages zeros)
     woff[e] = ok ? p.w_base + (m0 + o) * p.w_so + ci * p.w_si + kh * p.w_skh + kw * p.w_skw : -1;
   }
   const float* in_n = p.in + (int64_t)n * p.in_bs;
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
         const float* b_cp = b_base + cp * (2 * PHPW);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+          if (!((TAPS >> tap) & 1)) continue;
           const int kh = tap / 3, kw = tap % 3;
           float a[MI], b[NI];
 #pragma unroll
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
         if (o >= p.CO) continue;
         float v = acc[mi][ni][r];
         if (add_bias) v += p.bias[o];
-        float* dst = out_n + (int64_t)o * HW + y * p.W + x;
+        float* dst = out_n + (int64_t)o * p.out_plane + y * p.out_sy + x * p.out_sx + p.out_off;
         if (p.mode == 0) __builtin_nontemporal_store(v, dst);      // consumed by a later kernel, not by this one
         else if (p.mode == 1) *dst += v;
         else unsafeAtomicAdd(dst, v);
@@ -337,12 +349,12 @@ __global__ __launch_bounds__(256) void conv3x3_pack_weights_kernel(const Conv3Pa
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = chunk * 16 + g * 8 + j;
-    v[j] = c < p.CI ? p.w[p.w_base + o * p.w_so + c * p.w_si + kh * p.w_skh + kw * p.w_skw] : 0.f;
+    v[j] = (c < p.CI && ((p.taps >> tap) & 1)) ? p.w[p.w_base + o * p.w_so + c * p.w_si + kh * p.w_skh + kw * p.w_skw] : 0.f;
   }
   packed[slot] = pack8<PREC>(v);
 }
 
-template <int BM, int TH, int TW, int PREC>
+template <int BM, int TH, int TW, int PREC, int TAPS = 0x1FF>
 __global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params p) {
   constexpr int RPB = 32 / TW, ROWS = TH * RPB, PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
   constexpr int MI = BM / 32, NI = TH / 4;
@@ -438,6 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params
       const Half8* st = lds + cur * STAGE_Q;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
+        if (!((TAPS >> tap) & 1)) continue;
         const int kh = tap / 3, kw = tap % 3;
         frag a[MI], b[NI];
 #pragma unroll
@@ -473,13 +486,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params
         if (o >= p.CO) continue;
         float v = acc[mi][ni][r];
         if (add_bias) v += p.bias[o];
-        float* dst = out_n + (int64_t)o * HW + y * p.W + x;
+        float* dst = out_n + (int64_t)o * p.out_plane + y * p.out_sy + x * p.out_sx + p.out_off;
         if (p.mode == 0) __builtin_nontemporal_store(v, dst);
         else if (p.mode == 1) *dst += v;
         else unsafeAtomicAdd(dst, v);
       }
     }
   }
+}
+
+template <int BM, int CI_T, int TW, int TAPS>
+static void launch_conv3_plain(const Conv3Params& p, int th, dim3 grid, hipStream_t stream) {
+  if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, false, TW, false, TAPS>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, false, TW, false, TAPS>), grid, dim3(256), 0, stream, p);
 }
 
 template <int BM, int CI_T, int TW>
@@ -493,8 +512,13 @@ static void launch_conv3_w(const Conv3Params& p, int th, dim3 grid, hipStream_t 
     if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
   } else {
-    if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, false, TW>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, false, TW>), grid, dim3(256), 0, stream, p);
+    switch (p.taps) {            // the full window, or one of the four 2x2 sub-windows of a stride-2 transposed convolution
+      case 0x01B: launch_conv3_plain<BM, CI_T, TW, 0x01B>(p, th, grid, stream); break;
+      case 0x036: launch_conv3_plain<BM, CI_T, TW, 0x036>(p, th, grid, stream); break;
+      case 0x0D8: launch_conv3_plain<BM, CI_T, TW, 0x0D8>(p, th, grid, stream); break;
+      case 0x1B0: launch_conv3_plain<BM, CI_T, TW, 0x1B0>(p, th, grid, stream); break;
+      default: launch_conv3_plain<BM, CI_T, TW, 0x1FF>(p, th, grid, stream); break;
+    }
   }
 }
 
@@ -504,11 +528,22 @@ static void launch_conv3(const Conv3Params& p, int th, int tw, dim3 grid, hipStr
   else launch_conv3_w<BM, CI_T, 32>(p, th, grid, stream);
 }
 
+template <int BM, int PREC, int TAPS>
+static void launch_conv3_mixed_taps(const Conv3Params& p, int th, int tw, dim3 grid, hipStream_t stream) {
+  if (tw == 16) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 16, PREC, TAPS>), grid, dim3(256), 0, stream, p);
+  else if (th == 8) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 8, 32, PREC, TAPS>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 32, PREC, TAPS>), grid, dim3(256), 0, stream, p);
+}
+
 template <int BM, int PREC>
 static void launch_conv3_mixed_bm(const Conv3Params& p, int th, int tw, dim3 grid, hipStream_t stream) {
-  if (tw == 16) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 16, PREC>), grid, dim3(256), 0, stream, p);
-  else if (th == 8) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 8, 32, PREC>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 32, PREC>), grid, dim3(256), 0, stream, p);
+  switch (p.taps) {
+    case 0x01B: launch_conv3_mixed_taps<BM, PREC, 0x01B>(p, th, tw, grid, stream); break;
+    case 0x036: launch_conv3_mixed_taps<BM, PREC, 0x036>(p, th, tw, grid, stream); break;
+    case 0x0D8: launch_conv3_mixed_taps<BM, PREC, 0x0D8>(p, th, tw, grid, stream); break;
+    case 0x1B0: launch_conv3_mixed_taps<BM, PREC, 0x1B0>(p, th, tw, grid, stream); break;
+    default: launch_conv3_mixed_taps<BM, PREC, 0x1FF>(p, th, tw, grid, stream); break;
+  }
 }
 
 static void launch_conv3_mixed(const Conv3Params& p, int bm, int th, int tw, int precision, dim3 grid, hipStream_t stream) {
@@ -577,7 +612,9 @@ static Conv3Plan conv3x3_plan(int32_t N, int32_t CI, int32_t CO, int32_t H, int3
   return plan;
 }
 
-int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) { return conv3x3_plan(N, CI, CO, H, W).split; }
+int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W, int precision) {
+  return conv3x3_plan(N, CI, CO, H, W, true, precision).split;
+}
 
 // The batch-norm backward epilogue needs a 32- or 64-row tile (and whole sums in one workgroup: its plan never splits K).
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) {
@@ -593,8 +630,15 @@ float* partial_workspace(size_t bytes, hipStream_t stream);
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
                 int32_t W, int accumulate, hipStream_t stream, const float* const* bn, const BnBackwardEpilogue* epilogue,
-                int precision) {
+                int precision, const Conv3Placement* placement) {
   Conv3Params p;
+  p.taps = placement ? placement->taps : 0x1FF;
+  p.out_plane = placement ? placement->out_plane : H * W;
+  p.out_sy = placement ? placement->out_sy : W;
+  p.out_sx = placement ? placement->out_sx : 1;
+  p.out_off = placement ? placement->out_off : 0;
+  SRGAN_REQUIRE(placement == nullptr || (bn == nullptr && epilogue == nullptr), SRGAN_EUNSUPPORTED,
+                "conv3x3 tap subsets / strided output: plain kernel only");
   SRGAN_REQUIRE(precision == 0 || (bn == nullptr && epilogue == nullptr), SRGAN_EUNSUPPORTED,
                 "conv3x3 mixed precision: the fused batch-norm forms are fp32");
   p.in = in; p.w = w; p.out = out; p.bias = bias;
@@ -611,6 +655,8 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   p.ci_per_split = plan.chunks_per * plan.ci_t;
   const int64_t blocks = plan.blocks;
   SRGAN_REQUIRE(blocks < (int64_t)1 << 31 && split <= 65535, SRGAN_ERANGE, "conv3x3 grid");
+  SRGAN_REQUIRE(placement == nullptr || split == 1 || accumulate != 0, SRGAN_EUNSUPPORTED,
+                "conv3x3 strided output with a K split needs a pre-zeroed (or accumulated) output");
   if (split > 1) {                       // accumulate: 0 store, 1 add to out, 2 out is already zero
     if (accumulate == 0)
       SRGAN_HIP(hipMemset2DAsync(out, (size_t)out_bs * sizeof(float), 0, (size_t)CO * H * W * sizeof(float), (size_t)N,
@@ -653,7 +699,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
     bn_partial_reduce_run(p.epi_partial, p.epi_tiles, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
   const int64_t pixels3 = (int64_t)N * H * W;       // (+ x read by the fused batch-norm backward epilogue)
-  profile_bracket_end(profile_slot, stream, CO, pixels3, (int64_t)CI * 9, 2, bm, th * 32, split, 0, 0,
+  profile_bracket_end(profile_slot, stream, CO, pixels3, (int64_t)CI * __builtin_popcount((unsigned)p.taps), 2, bm, th * 32, split, 0, 0,
                       (int64_t)CI * pixels3 + (epilogue ? (int64_t)CO * pixels3 : 0), precision);
   return status;
 }

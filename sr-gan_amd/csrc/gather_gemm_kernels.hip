@@ -689,7 +689,8 @@ bool conv3x3_enabled();
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
                 int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
-                const BnBackwardEpilogue* epilogue = nullptr, int precision = 0);
+                const BnBackwardEpilogue* epilogue = nullptr, int precision = 0, const struct Conv3Placement* placement = nullptr);
+struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off; };
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 
 bool pointwise_enabled();
@@ -697,7 +698,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
                   int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t HW, int accumulate, hipStream_t stream,
                   const float* const* bn = nullptr, const BnBackwardEpilogue* epilogue = nullptr,
                   int* plan_only_split = nullptr);
-int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
+int conv3x3_splits(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W, int precision = 0);
 
 // 1x1 / stride 1 / unpadded: the register-streamed pointwise kernel (any plane size: an image's last 32-pixel group may
 // be ragged; planes of fewer than 32 pixels stay on the generic kernel).
@@ -906,6 +907,28 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
   if (dtype && force_kernel == 0 && use_conv3x3(g, g.C, 0))
     return conv3x3_run(gy, g.y_bs, w, 8, 9, g.C * 9, -3, -1, bias, gx, g.x_bs, g.N, g.K, g.C, g.H, g.W, accumulate,
                        (hipStream_t)stream, nullptr, nullptr, dtype);
+  // k4 / s2 / p1 (the DCGAN generators' transposed convolutions, reference crowd/models.py:132-136, age/models.py:37-41,
+  // as forward passes; the discriminators' strided convolutions as data gradients): output pixel (2q + a, 2r + b) only
+  // meets the 2x2 taps kh = 3 + a - 2i, kw = 3 + b - 2j of the input pixels (q - 1 + i, r - 1 + j), i in {a, a + 1},
+  // j in {b, b + 1} -- four 2x2 sub-windows of the LDS-halo 3x3 kernel with strided stores, instead of four gathered
+  // GEMMs on the generic kernel (50 TF/s).
+  static const bool no_k4s2 = getenv("SRGAN_NO_K4S2") != nullptr;
+  if (force_kernel == 0 && !no_k4s2 && conv3x3_enabled() && g.R == 4 && g.S == 4 && g.sh == 2 && g.sw == 2 && g.ph == 1 &&
+      g.pw == 1 && g.H == 2 * g.OH && g.W == 2 * g.OW && g.OW >= 8 && g.C >= 8 && !accumulate) {
+    // small problems split the input channels over the grid and add with atomics: the output is zeroed once for all classes
+    const bool split = conv3x3_splits(g.N, g.K, g.C, g.OH, g.OW, dtype) > 1;
+    if (split) SRGAN_HIP(hipMemsetAsync(gx, 0, (size_t)g.N * g.x_bs * sizeof(float), (hipStream_t)stream));
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        Conv3Placement placement;
+        placement.taps = (0x01B << (3 * a)) << b;
+        placement.out_plane = g.H * g.W; placement.out_sy = 2 * g.W; placement.out_sx = 2; placement.out_off = a * g.W + b;
+        const int status = conv3x3_run(gy, g.y_bs, w, (3 + a) * 4 + (3 + b), 16, g.C * 16, -8, -2, bias, gx, g.x_bs, g.N, g.K,
+                                       g.C, g.OH, g.OW, split ? 2 : 0, (hipStream_t)stream, nullptr, nullptr, dtype, &placement);
+        if (status != SRGAN_OK) return status;
+      }
+    return SRGAN_OK;
+  }
   if (dtype) force_kernel = 2;
   if (use_pointwise(g, g.C, force_kernel))   // the data gradient of a 1x1 convolution is the 1x1 convolution with W^T
     return pointwise_run(gy, g.y_bs, w, 1, g.C, bias, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
