@@ -417,7 +417,7 @@ def main():
             lib.srgan_profile_report(text, size)
             with open(args.shape_report, 'w') as handle:
                 handle.write('# M N K kind bm bn split akf bkf count ms bytes   (kind: 0 gg_direct 1 gg_mfma 2 conv3x3_lds '
-                             '3 pointwise 4 conv3x3_wgrad 5 gg_rows 6 pointwise_wgrad 8 pointwise_ksplit 9 gg_dot)\n')
+                             '3 pointwise 4 conv3x3_wgrad 5 gg_rows 6 pointwise_wgrad 8 pointwise_ksplit 9 gg_dot 10 stem7x7_fwd 11 stem7x7_wgrad)\n')
                 handle.write(text.value.decode())
         achieved = flops.value / (kernel_ms.value * 1e-3) / 1e12 if kernel_ms.value > 0 else 0.0
         traffic, traffic_source = pmc_traffic(args)

@@ -286,7 +286,7 @@ int srgan_profile_bytes(double* algorithmic_bytes_total);
 int srgan_profile_mixed(double* flops, double* kernel_ms);
 /* Per-shape text report of the last profiled region ("M N K kind bm bn split akf bkf count ms bytes" per line; kind:
  * 0 gg_direct, 1 gg_mfma, 2 conv3x3_lds, 3 pointwise, 4 conv3x3_wgrad, 5 gg_rows, 6 pointwise_wgrad,
- * 8 pointwise_ksplit, 9 gg_dot); returns the bytes needed. */
+ * 8 pointwise_ksplit, 9 gg_dot, 10 stem7x7_fwd, 11 stem7x7_wgrad); returns the bytes needed. */
 int64_t srgan_profile_report(char* buffer, int64_t capacity);
 
 #ifdef __cplusplus

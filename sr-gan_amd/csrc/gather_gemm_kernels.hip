@@ -717,6 +717,13 @@ static bool use_conv3x3(const ConvGeom& g, int out_channels, int force) {
          g.W >= min_width && out_channels >= 8;
 }
 
+bool stem7x7_enabled();
+bool stem7x7_geometry(int32_t C, int32_t K, int32_t R, int32_t S, int32_t sh, int32_t sw, int32_t ph, int32_t pw);
+int stem7x7_fwd_run(const float* x, int64_t x_bs, const float* w, float* y, int64_t y_bs, int32_t N, int32_t H, int32_t W,
+                    int32_t K, int32_t OH, int32_t OW, hipStream_t stream);
+int stem7x7_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t H, int32_t W,
+                      int32_t K, int32_t OH, int32_t OW, int accumulate, hipStream_t stream);
+
 bool conv3x3_wgrad_enabled();
 int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
                       int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
@@ -876,6 +883,9 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   if (use_conv3x3(g, g.K, force_kernel))
     return conv3x3_run(x, g.x_bs, w, 0, g.C * 9, 9, 3, 1, bias, y, g.y_bs, g.N, g.C, g.K, g.H, g.W, 0,
                        (hipStream_t)stream);
+  if (force_kernel == 0 && dtype == 0 && bias == nullptr && stem7x7_enabled() &&
+      stem7x7_geometry(g.C, g.K, g.R, g.S, g.sh, g.sw, g.ph, g.pw))
+    return stem7x7_fwd_run(x, g.x_bs, w, y, g.y_bs, g.N, g.H, g.W, g.K, g.OH, g.OW, (hipStream_t)stream);
   std::vector<GatherGemm> plans{plan_conv_fwd(g, x, w, bias, y)};
   plans[0].precision = dtype;
   // A strided-batch output view (a channel slice of a wider buffer) is zeroed with a 2-D memset when the launch
@@ -957,6 +967,8 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   if (dtype) force_kernel = 2;
   if (use_pointwise_wgrad(g, x, gy, force_kernel))
     return pointwise_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, accumulate, (hipStream_t)stream);
+  if (force_kernel == 0 && dtype == 0 && stem7x7_enabled() && stem7x7_geometry(g.C, g.K, g.R, g.S, g.sh, g.sw, g.ph, g.pw))
+    return stem7x7_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.H, g.W, g.K, g.OH, g.OW, accumulate, (hipStream_t)stream);
   if (use_wgrad3x3(g, x, gy, force_kernel))
     return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream);
   std::vector<GatherGemm> plans{plan_conv_bwd_weight(g, x, gy, gw)};
@@ -1119,7 +1131,7 @@ int srgan_profile_mixed(double* flops, double* kernel_ms) {
 
 // Per-shape breakdown of the last profiled region as text lines "M N K kind bm bn split akf bkf count ms bytes"
 // (kind: 0 direct, 1 gg_mfma, 2 conv3x3_lds, 3 pointwise, 4 conv3x3_wgrad, 5 gg_rows, 6 pointwise_wgrad,
-// 8 pointwise_ksplit, 9 gg_dot; bytes = algorithmic HBM bytes of all `count` launches; call after srgan_profile_end).
+// 8 pointwise_ksplit, 9 gg_dot, 10 stem7x7_fwd, 11 stem7x7_wgrad; bytes = algorithmic HBM bytes of all `count` launches; call after srgan_profile_end).
 // Returns the number of bytes needed.
 int64_t srgan_profile_report(char* buffer, int64_t capacity) {
   struct Key { int32_t v[9]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
