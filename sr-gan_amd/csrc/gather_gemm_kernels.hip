@@ -430,27 +430,39 @@ __global__ __launch_bounds__(256) void gg_dot_kernel(const GatherGemm p) {
   }
 }
 
-// Second stage of a split-K launch whose output is tiny (M*N of a few thousand): thousands of workgroups adding into
-// the same few cache lines serialise in L2 (measured: 310 us for a 20x16 output from 1024 K-slices), so the slices are
-// stored to a workspace and summed here -- 32 outputs x 8 slice-lanes per workgroup, no atomics, no pre-zeroing.
+// Second stage of a split-K launch whose output is small (M*N up to a few thousand): thousands of workgroups adding into
+// the same few cache lines serialise in L2 (measured: 310 us for a 20x48 output from 1024 K-slices), so the slices are
+// stored to a workspace and summed here, no atomics, no pre-zeroing.  A workgroup owns 16 consecutive outputs; its 16
+// slice-lanes per output walk the slices with four independent loads in flight each (a single dependent chain over 128
+// slices cost 64 us of pure load latency), then 16-lane shuffle reductions.
 __global__ __launch_bounds__(256) void gg_reduce_partials_kernel(const GatherGemm p, const float* __restrict__ ws) {
-  __shared__ float scratch[8][33];
-  const int o = (int)threadIdx.x & 31, lane_z = (int)threadIdx.x >> 5;
+  const int o = (int)threadIdx.x & 15, lane_z = (int)threadIdx.x >> 4;      // 16 outputs x 16 slice-lanes
   const int64_t mn = (int64_t)p.M * p.N;
-  const int64_t idx = (int64_t)blockIdx.x * 32 + o;
-  float acc = 0.f;
-  if (idx < mn)
-    for (int z = lane_z; z < p.split_k; z += 8) acc += ws[(int64_t)z * mn + idx];
-  scratch[lane_z][o] = acc;
-  __syncthreads();
-  if (lane_z != 0 || idx >= mn) return;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + o;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (idx < mn) {
+    int z = lane_z;
+    for (; z + 48 < p.split_k; z += 64) {
 #pragma unroll
-  for (int z = 1; z < 8; ++z) acc += scratch[z][o];
+      for (int u = 0; u < 4; ++u) acc[u] += ws[(int64_t)(z + 16 * u) * mn + idx];
+    }
+    for (; z < p.split_k; z += 16) acc[0] += ws[(int64_t)z * mn + idx];
+  }
+  float total = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  // lanes of one output are 16 apart (lane = lane_z * 16 + o): combine across lane_z within the wave, then across waves
+  total += __shfl_xor(total, 16, 64);
+  total += __shfl_xor(total, 32, 64);
+  __shared__ float scratch[4][16];
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  if (lane < 16) scratch[wave][lane] = total;
+  __syncthreads();
+  if (threadIdx.x >= 16 || idx >= mn) return;
+  total = (scratch[0][o] + scratch[1][o]) + (scratch[2][o] + scratch[3][o]);
   const int i = (int)(idx / p.N), j = (int)(idx - (int64_t)i * p.N);
   const Side sm = decode(p.cm, i), sn = decode(p.cn, j);
   if (!sm.valid || !sn.valid) return;
   float* dst = p.C + (uint32_t)(sm.off + sn.off);
-  *dst = p.mode == GG_ACCUMULATE ? *dst + acc : acc;
+  *dst = p.mode == GG_ACCUMULATE ? *dst + total : total;
 }
 
 // Partial sums that a second small kernel combines go through a workspace the CALLER owns (srgan_set_workspace: one
@@ -615,7 +627,8 @@ bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
   choose_split(p, c, true);
   if (out) *out = c;
   static const bool no_partial = getenv("SRGAN_NO_PARTIAL") != nullptr;
-  p.use_partial = !no_partial && c.kind == 1 && p.split_k >= 32 && (int64_t)p.M * p.N < 512 &&
+  // (up to 4096 outputs: at 960 outputs x 1024 slices the atomics still serialised -- 310 us for 36 MB of operands)
+  p.use_partial = !no_partial && c.kind == 1 && p.split_k >= 16 && (int64_t)p.M * p.N <= 4096 &&
                   (size_t)p.M * p.N * p.split_k * sizeof(float) <= WORKSPACE_BYTES;
   return p.split_k > 1 && !p.use_partial;
 }
@@ -677,7 +690,7 @@ int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int6
                                       : algorithmic_bytes((double)M, (double)N, (double)K, kind);
     g_profile.records[slot] = ProfileRecord{(int32_t)M, (int32_t)N, (int32_t)K, kind, bm, bn, split, akf, bkf, bytes, precision};
     g_profile.flops += f;
-    if (kind != 0 && kind != 5 && kind != 9) g_profile.mfma_flops += f;      // direct / few-rows / lanes-along-K: VALU
+    if (kind != 0 && kind != 5 && kind != 9 && kind != 12) g_profile.mfma_flops += f;      // direct / few-rows / lanes-along-K / stem data gradient: VALU
     g_profile.bytes += bytes;
     g_profile.launches += 1;
   }
@@ -724,6 +737,8 @@ int stem7x7_fwd_run(const float* x, int64_t x_bs, const float* w, float* y, int6
 int stem7x7_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t H, int32_t W,
                       int32_t K, int32_t OH, int32_t OW, int accumulate, hipStream_t stream);
 
+int stem7x7_bwd_data_run(const float* gy, int64_t gy_bs, const float* w, float* gx, int64_t gx_bs, int32_t N, int32_t H,
+                         int32_t W, int32_t K, int32_t OH, int32_t OW, hipStream_t stream);
 bool conv3x3_wgrad_enabled();
 int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
                       int32_t CO, int32_t H, int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
@@ -797,7 +812,7 @@ static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStrea
     q.mode = GG_PARTIAL; q.partial = ws; q.use_partial = 0;
     const int status = gg_launch_unprofiled(q, c, stream);
     if (status != SRGAN_OK) return status;
-    hipLaunchKernelGGL(gg_reduce_partials_kernel, dim3((unsigned)((mn + 31) / 32)), dim3(256), 0, stream, p, ws);
+    hipLaunchKernelGGL(gg_reduce_partials_kernel, dim3((unsigned)((mn + 15) / 16)), dim3(256), 0, stream, p, ws);
     return launch_status();
   }
   if (c.bm == 128 && c.bn == 128) launch_mfma<128, 128, 2>(p, grid, stream);
@@ -917,6 +932,9 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
   if (dtype && force_kernel == 0 && use_conv3x3(g, g.C, 0))
     return conv3x3_run(gy, g.y_bs, w, 8, 9, g.C * 9, -3, -1, bias, gx, g.x_bs, g.N, g.K, g.C, g.H, g.W, accumulate,
                        (hipStream_t)stream, nullptr, nullptr, dtype);
+  if (force_kernel == 0 && dtype == 0 && bias == nullptr && !accumulate && stem7x7_enabled() &&
+      stem7x7_geometry(g.C, g.K, g.R, g.S, g.sh, g.sw, g.ph, g.pw) && (g.W & 1) == 0 && (((uintptr_t)gx) & 7) == 0)
+    return stem7x7_bwd_data_run(gy, g.y_bs, w, gx, g.x_bs, g.N, g.H, g.W, g.K, g.OH, g.OW, (hipStream_t)stream);
   // k4 / s2 / p1 (the DCGAN generators' transposed convolutions, reference crowd/models.py:132-136, age/models.py:37-41,
   // as forward passes; the discriminators' strided convolutions as data gradients): output pixel (2q + a, 2r + b) only
   // meets the 2x2 taps kh = 3 + a - 2i, kw = 3 + b - 2j of the input pixels (q - 1 + i, r - 1 + j), i in {a, a + 1},

@@ -244,6 +244,123 @@ __global__ __launch_bounds__(256, 2) void stem7x7_wgrad_kernel(const StemParams 
   }
 }
 
+// gx[n, c, ih, iw] = sum_{co, kh, kw} gy[n, co, (ih + 3 - kh) / 2, (iw + 3 - kw) / 2] * w[co, c, kh, kw]   (exact divisions only)
+// Three output channels: the matrix pipe would be 3/32 used (the few-rows VALU kernel ran this at 16 TF/s, 1.2 ms per
+// pass).  Here a lane owns one 2x2 block of input pixels (all four stride-2 classes) x 3 channels = 12 accumulators and
+// the work is arranged so that it is VALU-bound: per output channel co the 16 shifted gy values a block needs
+// ((dh, dw) in [-1, 2]^2) are read from an LDS patch -- lanes along the row: conflict-free -- and feed all 49 x 3 taps,
+// whose weights are WAVE-UNIFORM (every lane handles the same classes) and therefore scalar operands: 16 LDS reads per
+// 147 FMAs.  A workgroup covers 4 block rows x 64 block columns (one row per wave) and walks the output channels in chunks
+// of 16 with the next chunk's patch in flight.
+constexpr int SB_CC = 16, SB_RQ = 4, SB_CQ = 64;
+constexpr int SB_PH = SB_RQ + 3, SB_PW = SB_CQ + 3, SB_PWS = SB_PW + 1;
+constexpr int SB_PATCH = SB_CC * SB_PH * SB_PWS;
+constexpr int SB_NP = (SB_CC * SB_PH * SB_PW + 255) / 256;
+
+__global__ __launch_bounds__(256, 2) void stem7x7_bwd_data_kernel(const StemParams p) {
+  __shared__ float gys[2 * SB_PATCH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int block = blockIdx.x;
+  const int tx = block % p.tiles_x; block /= p.tiles_x;
+  const int ty = block % p.tiles_y;
+  const int n = block / p.tiles_y;
+  const int qh0 = ty * SB_RQ, qw0 = tx * SB_CQ;
+  const float* gn = p.y + (int64_t)n * p.y_bs;
+  const int64_t plane = (int64_t)p.OH * p.OW;
+
+  // staging coordinates of this thread inside a chunk: (channel, patch row, patch column), lanes along the row
+  int soff[SB_NP], sdst[SB_NP];
+#pragma unroll
+  for (int e = 0; e < SB_NP; ++e) {
+    const int flat = e * 256 + tid;
+    const int c = flat / (SB_PH * SB_PW), rem = flat - c * (SB_PH * SB_PW);
+    const int ry = rem / SB_PW, rx = rem - ry * SB_PW;
+    const int oh = qh0 - 1 + ry, ow = qw0 - 1 + rx;
+    const bool ok = flat < SB_CC * SB_PH * SB_PW && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+    soff[e] = ok ? (int)(c * plane + (int64_t)oh * p.OW + ow) : -1;
+    sdst[e] = flat < SB_CC * SB_PH * SB_PW ? (c * SB_PH + ry) * SB_PWS + rx : -1;
+  }
+  float r[SB_NP];
+  auto fetch = [&](int co0) {
+#pragma unroll
+    for (int e = 0; e < SB_NP; ++e) {
+      const int c = (e * 256 + tid) / (SB_PH * SB_PW);
+      const bool ok = soff[e] >= 0 && co0 + c < p.K;
+      r[e] = gn[ok ? (int64_t)co0 * plane + soff[e] : 0];
+    }
+  };
+  auto stage = [&](int co0, float* dst) {
+#pragma unroll
+    for (int e = 0; e < SB_NP; ++e) {
+      const int c = (e * 256 + tid) / (SB_PH * SB_PW);
+      if (sdst[e] >= 0) dst[sdst[e]] = (soff[e] >= 0 && co0 + c < p.K) ? r[e] : 0.f;
+    }
+  };
+
+  float acc[2][2][3];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[a][b][c] = 0.f;
+
+  fetch(0);
+  stage(0, gys);
+  __syncthreads();
+  int cur = 0;
+  for (int co0 = 0; co0 < p.K; co0 += SB_CC) {
+    const bool more = co0 + SB_CC < p.K;
+    if (more) fetch(co0 + SB_CC);
+    const float* patch = gys + cur * SB_PATCH + wave * SB_PWS + lane;
+#pragma unroll 2
+    for (int cl = 0; cl < SB_CC; ++cl) {
+      if (co0 + cl >= p.K) break;
+      const float* __restrict__ wc = p.w + (int64_t)(co0 + cl) * 147;      // wave-uniform: scalar loads
+      float g[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[i][j] = patch[(cl * SB_PH + i) * SB_PWS + j];
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh) {
+        const int a = (kh + 1) & 1;                  // ih + 3 - kh even  <=>  ih parity = (kh + 1) & 1
+        const int dh = (a + 3 - kh) / 2;             // oh = qh + dh, dh in [-1, 2]
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+          const int b = (kw + 1) & 1;
+          const int dw = (b + 3 - kw) / 2;
+          const float v = g[dh + 1][dw + 1];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[a][b][c] = fmaf(v, wc[c * 49 + kh * 7 + kw], acc[a][b][c]);
+        }
+      }
+    }
+    if (more) stage(co0 + SB_CC, gys + (cur ^ 1) * SB_PATCH);
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int qh = qh0 + wave, qw = qw0 + lane;
+  float* xn = p.gw + (int64_t)n * p.x_bs;            // (gw carries the gx pointer in this pass)
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ih = 2 * qh + a, iw = 2 * qw;
+      if (ih >= p.H || iw >= p.W) continue;
+      float* dst = xn + (int64_t)c * p.H * p.W + (int64_t)ih * p.W + iw;
+      if (iw + 1 < p.W && (p.W & 1) == 0) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f pair; pair.x = acc[a][0][c]; pair.y = acc[a][1][c];
+        __builtin_nontemporal_store(pair, reinterpret_cast<v2f*>(dst));
+      } else {
+        dst[0] = acc[a][0][c];
+        if (iw + 1 < p.W) dst[1] = acc[a][1][c];
+      }
+    }
+}
+
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
                         int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
@@ -293,6 +410,23 @@ int stem7x7_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(grid, (K + 31) / 32), dim3(256), 0, stream, p);
   const int status = launch_status();
   profile_bracket_end(slot, stream, K, 147, (int64_t)N * OH * OW, 11, 32, 160, grid, 0, 0, (int64_t)N * 3 * H * W);
+  return status;
+}
+
+int stem7x7_bwd_data_run(const float* gy, int64_t gy_bs, const float* w, float* gx, int64_t gx_bs, int32_t N, int32_t H,
+                         int32_t W, int32_t K, int32_t OH, int32_t OW, hipStream_t stream) {
+  StemParams p;
+  stem_fill(p, nullptr, gx_bs, w, const_cast<float*>(gy), gy_bs, gx, N, H, W, K, OH, OW);
+  SRGAN_REQUIRE((gx_bs & 1) == 0 && (((uintptr_t)gx) & 7) == 0, SRGAN_EINVAL, "stem data gradient: 8-byte aligned rows");
+  p.tiles_x = ((W + 1) / 2 + SB_CQ - 1) / SB_CQ;
+  p.tiles_y = ((H + 1) / 2 + SB_RQ - 1) / SB_RQ;
+  const int64_t blocks = (int64_t)N * p.tiles_y * p.tiles_x;
+  SRGAN_REQUIRE(blocks < ((int64_t)1 << 31), SRGAN_ERANGE, "stem grid");
+  const int slot = profile_bracket_begin(stream);
+  hipLaunchKernelGGL(stem7x7_bwd_data_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  const int status = launch_status();
+  // logical work: 3 x (N * H * W) outputs, K * 49 / 4 taps each on average
+  profile_bracket_end(slot, stream, 3, (int64_t)N * H * W, (int64_t)K * 49 / 4, 12, 4, 256, 1, 0, 0, (int64_t)N * K * OH * OW);
   return status;
 }
 
