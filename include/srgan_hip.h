@@ -137,6 +137,24 @@ int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, c
                                  const float* x, float* gx, float* g_gamma, float* g_beta, int accumulate, void* stream);
 int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,
                                    float* gw, int accumulate, void* stream);
+/* Deferred parameter gradients of srgan_conv2d_bwd_data_bnrelu: the per-workgroup sums behind g_gamma / g_beta are left in
+ * a caller-owned region of 2 * srgan_conv2d_bwd_data_bnrelu_tiles(desc) * C floats instead of being reduced by a small
+ * kernel after EVERY convolution (597 launches per training step); one srgan_bn_partial_reduce_batched call then
+ * reduces the regions of many convolutions (a DenseNet block's backward pass: two per layer).  `jobs_device` is a table in
+ * DEVICE memory; partial_offset is in floats from `scratch`.  Offsets and pointers are stable from step to step, so the
+ * caller builds the table once per block. */
+typedef struct srgan_bn_reduce_job {
+  int64_t partial_offset;
+  int32_t tiles, channels;
+  const float* inv_std;
+  float* g_gamma;
+  float* g_beta;
+} srgan_bn_reduce_job;
+int64_t srgan_conv2d_bwd_data_bnrelu_tiles(const srgan_conv_desc* desc);
+int srgan_conv2d_bwd_data_bnrelu_partials(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
+                                          const float* x, float* gx, float* partials, int accumulate, void* stream);
+int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int32_t count, int32_t max_channels, int32_t max_tiles,
+                                    const float* scratch, void* stream);
 
 /* ---- strided GEMM  C[i*sci + j*scj] (=,+=) sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] + bias ----------------
  * C must be a dense M x N matrix (row- or column-major).  bias is indexed by row i, or by column j when

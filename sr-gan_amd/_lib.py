@@ -20,6 +20,11 @@ class BnRelu(ctypes.Structure):
     _fields_ = [(name, vp) for name in ('mean', 'inv_std', 'gamma', 'beta')]
 
 
+class BnReduceJob(ctypes.Structure):
+    """Mirror of ``srgan_bn_reduce_job``."""
+    _fields_ = [('partial_offset', i64), ('tiles', i32), ('channels', i32), ('inv_std', vp), ('g_gamma', vp), ('g_beta', vp)]
+
+
 class Capabilities(ctypes.Structure):
     """Mirror of ``srgan_capabilities_t``."""
     _fields_ = [('abi_version', i32), ('struct_bytes', i32), ('arch', ctypes.c_char * 16), ('dtypes', ctypes.c_uint32),
@@ -42,6 +47,10 @@ SIGNATURES = {
     'srgan_bn_conv_tangent_weights': ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], ctypes.c_int),
     'srgan_conv2d_bwd_data_bnrelu': ([ctypes.POINTER(ConvDesc), vp, vp, ctypes.POINTER(BnRelu), vp, vp, vp, vp,
                                       ctypes.c_int, vp], ctypes.c_int),
+    'srgan_conv2d_bwd_data_bnrelu_tiles': ([ctypes.POINTER(ConvDesc)], ctypes.c_int64),
+    'srgan_conv2d_bwd_data_bnrelu_partials': ([ctypes.POINTER(ConvDesc), vp, vp, ctypes.POINTER(BnRelu), vp, vp, vp,
+                                               ctypes.c_int, vp], ctypes.c_int),
+    'srgan_bn_partial_reduce_batched': ([vp, i32, i32, i32, vp, vp], ctypes.c_int),
     'srgan_conv2d_bwd_weight_bnrelu': ([ctypes.POINTER(ConvDesc), vp, ctypes.POINTER(BnRelu), vp, vp, ctypes.c_int, vp],
                                        ctypes.c_int),
     'srgan_gemm_f32': ([i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i32, ctypes.c_int, ctypes.c_int,

@@ -67,6 +67,9 @@ struct BnBackwardEpilogue {
   const float* x; int64_t x_bs;
   const float* bn[4];
   float* g_gamma; float* g_beta;
+  // Deferred form: the per-workgroup parameter sums go to this caller-owned region ([2][tiles][C] floats) and are NOT
+  // reduced by the call -- a whole dense block's convolutions are reduced by one srgan_bn_partial_reduce_batched launch.
+  float* partial_out;
 };
 
 // Grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs x 8, never more than the work.

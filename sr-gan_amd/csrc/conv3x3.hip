@@ -621,6 +621,11 @@ bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, in
   return conv3x3_plan(N, CI, CO, H, W, false).bm <= 64;      // (with the epilogue the plan does not split K)
 }
 
+int64_t conv3x3_epilogue_tiles(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W) {
+  const Conv3Plan plan = conv3x3_plan(N, CI, CO, H, W, false);
+  return plan.blocks / plan.tiles_m;
+}
+
 void bn_partial_reduce_run(const float* partial, int tiles, int CO, const float* inv_std, float* g_gamma, float* g_beta,
                            hipStream_t stream);
 float* partial_workspace(size_t bytes, hipStream_t stream);
@@ -671,7 +676,9 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
     p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
     p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
     p.epi_tiles = (int32_t)(blocks / plan.tiles_m);
-    if (epilogue->g_gamma) {
+    if (epilogue->partial_out) {
+      p.epi_partial = epilogue->partial_out;
+    } else if (epilogue->g_gamma) {
       p.epi_partial = partial_workspace((size_t)2 * p.epi_tiles * CO * sizeof(float), stream);
       SRGAN_REQUIRE(p.epi_partial, SRGAN_EINVAL, "conv3x3 batch-norm backward epilogue: register a workspace for this "
                     "stream first (srgan_set_workspace, >= srgan_workspace_bytes())");
@@ -695,7 +702,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   else if (bm == 64 && plan.ci_t == 8) launch_conv3<64, 8>(p, th, tw, grid, stream);
   else if (bm == 64) launch_conv3<64, 4>(p, th, tw, grid, stream);
   else launch_conv3<128, 4>(p, 4, tw, grid, stream);
-  if (p.epi_partial)
+  if (p.epi_partial && !epilogue->partial_out)
     bn_partial_reduce_run(p.epi_partial, p.epi_tiles, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
   const int64_t pixels3 = (int64_t)N * H * W;       // (+ x read by the fused batch-norm backward epilogue)

@@ -705,6 +705,10 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
                 const BnBackwardEpilogue* epilogue = nullptr, int precision = 0, const struct Conv3Placement* placement = nullptr);
 struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off; };
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
+int64_t conv3x3_epilogue_tiles(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
+int64_t pointwise_epilogue_tiles(int32_t N, int32_t HW);
+int bn_partial_reduce_batched_run(const void* jobs, int count, int max_channels, int max_tiles, const float* scratch,
+                                  hipStream_t stream);
 
 bool pointwise_enabled();
 int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, int32_t w_si, const float* bias, float* out,
@@ -1059,8 +1063,8 @@ int srgan_conv2d_fwd_bnrelu_splits(const srgan_conv_desc* desc) {
   return fwd_bnrelu(desc, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &split, nullptr) == SRGAN_OK ? split : -1;
 }
 
-int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
-                                 const float* x, float* gx, float* g_gamma, float* g_beta, int accumulate, void* stream) {
+static int bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn, const float* x,
+                          float* gx, float* g_gamma, float* g_beta, float* partials, int accumulate, void* stream) {
   ConvGeom g;
   SRGAN_GEOM(desc, g, "srgan_conv2d_bwd_data_bnrelu");
   SRGAN_REQUIRE(gy && w && x && gx && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_bwd_data_bnrelu pointers");
@@ -1071,13 +1075,40 @@ int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, c
   BnBackwardEpilogue epilogue;
   epilogue.x = x; epilogue.x_bs = g.x_bs;
   epilogue.bn[0] = bn->mean; epilogue.bn[1] = bn->inv_std; epilogue.bn[2] = bn->gamma; epilogue.bn[3] = bn->beta;
-  epilogue.g_gamma = g_gamma; epilogue.g_beta = g_beta;
+  epilogue.g_gamma = g_gamma; epilogue.g_beta = g_beta; epilogue.partial_out = partials;
   if (pointwise(g))
     return pointwise_run(gy, g.y_bs, w, 1, g.C, nullptr, gx, g.x_bs, g.N, g.K, g.C, g.H * g.W, accumulate,
                          (hipStream_t)stream, nullptr, &epilogue);
   SRGAN_REQUIRE(!accumulate, SRGAN_EUNSUPPORTED, "srgan_conv2d_bwd_data_bnrelu 3x3: gx is stored, not accumulated");
   return conv3x3_run(gy, g.y_bs, w, 8, 9, g.C * 9, -3, -1, nullptr, gx, g.x_bs, g.N, g.K, g.C, g.H, g.W, 0,
                      (hipStream_t)stream, nullptr, &epilogue);
+}
+
+int srgan_conv2d_bwd_data_bnrelu(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
+                                 const float* x, float* gx, float* g_gamma, float* g_beta, int accumulate, void* stream) {
+  return bwd_data_bnrelu(desc, gy, w, bn, x, gx, g_gamma, g_beta, nullptr, accumulate, stream);
+}
+
+int64_t srgan_conv2d_bwd_data_bnrelu_tiles(const srgan_conv_desc* desc) {
+  ConvGeom g;
+  if (!to_geom(desc, g) || !srgan_conv2d_bnrelu_supported(desc, 1)) return -1;
+  return pointwise(g) ? pointwise_epilogue_tiles(g.N, g.H * g.W) : conv3x3_epilogue_tiles(g.N, g.K, g.C, g.H, g.W);
+}
+
+int srgan_conv2d_bwd_data_bnrelu_partials(const srgan_conv_desc* desc, const float* gy, const float* w, const srgan_bn_relu* bn,
+                                          const float* x, float* gx, float* partials, int accumulate, void* stream) {
+  SRGAN_REQUIRE(partials != nullptr, SRGAN_EINVAL, "srgan_conv2d_bwd_data_bnrelu_partials: the partial-sum region");
+  return bwd_data_bnrelu(desc, gy, w, bn, x, gx, nullptr, nullptr, partials, accumulate, stream);
+}
+
+struct srgan_bn_reduce_job { int64_t partial_offset; int32_t tiles, channels; const float* inv_std; float* g_gamma; float* g_beta; };
+
+int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int32_t count, int32_t max_channels, int32_t max_tiles,
+                                    const float* scratch, void* stream) {
+  SRGAN_REQUIRE(jobs_device && scratch && count > 0 && max_channels > 0 && max_tiles > 0, SRGAN_EINVAL,
+                "srgan_bn_partial_reduce_batched arguments");
+  SRGAN_REQUIRE(count <= 65535, SRGAN_ERANGE, "srgan_bn_partial_reduce_batched job count");
+  return bn_partial_reduce_batched_run(jobs_device, count, max_channels, max_tiles, scratch, (hipStream_t)stream);
 }
 
 int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, const srgan_bn_relu* bn, const float* gy,

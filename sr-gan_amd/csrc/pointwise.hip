@@ -405,6 +405,56 @@ void bn_partial_reduce_run(const float* partial, int tiles, int CO, const float*
                      partial, tiles, CO, inv_std, g_gamma, g_beta, per);
 }
 
+// One launch for the deferred parameter sums of MANY convolutions (a dense block's backward: two per layer): job z of
+// the table reduces partial[q][tile][c] (q = 0 beta, 1 gamma before inv_std; at scratch + partial_offset) like the kernel
+// above.  The table lives in device memory and is built once per block by the caller (the offsets into the scratch
+// region and the arena pointers do not change between steps).
+struct BnReduceJob { int64_t partial_offset; int32_t tiles, channels; const float* inv_std; float* g_gamma; float* g_beta; };
+
+__global__ __launch_bounds__(256) void bn_partial_reduce_batched_kernel(const BnReduceJob* __restrict__ jobs,
+                                                                        const float* __restrict__ scratch) {
+  __shared__ float buffer[2][4][64];
+  const BnReduceJob job = jobs[blockIdx.z];
+  int segments = job.tiles / 32;
+  segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
+  const int per = (job.tiles + segments - 1) / segments;
+  const int first = (int)blockIdx.y * per;
+  if ((int)blockIdx.x * 64 >= job.channels || first >= job.tiles) return;        // (workgroup-uniform)
+  const int last = min(job.tiles, first + per);
+  const float* partial = scratch + job.partial_offset;
+  const int lane_c = (int)threadIdx.x & 63, rl = (int)threadIdx.x >> 6;
+  const int c = (int)blockIdx.x * 64 + lane_c;
+  float plain = 0.f, centred = 0.f;
+  if (c < job.channels)
+    for (int t = first + rl; t < last; t += 4) {
+      plain += partial[(int64_t)t * job.channels + c];
+      centred += partial[((int64_t)job.tiles + t) * job.channels + c];
+    }
+  buffer[0][rl][lane_c] = plain;
+  buffer[1][rl][lane_c] = centred;
+  __syncthreads();
+  if (rl != 0 || c >= job.channels) return;
+  plain = (buffer[0][0][lane_c] + buffer[0][1][lane_c]) + (buffer[0][2][lane_c] + buffer[0][3][lane_c]);
+  centred = (buffer[1][0][lane_c] + buffer[1][1][lane_c]) + (buffer[1][2][lane_c] + buffer[1][3][lane_c]);
+  unsafeAtomicAdd(job.g_beta + c, plain);
+  unsafeAtomicAdd(job.g_gamma + c, centred * job.inv_std[c]);
+}
+
+int bn_partial_reduce_batched_run(const void* jobs, int count, int max_channels, int max_tiles, const float* scratch,
+                                  hipStream_t stream) {
+  int segments = max_tiles / 32;
+  segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
+  hipLaunchKernelGGL(bn_partial_reduce_batched_kernel, dim3((max_channels + 63) / 64, segments, count), dim3(256), 0, stream,
+                     reinterpret_cast<const BnReduceJob*>(jobs), scratch);
+  return launch_status();
+}
+
+// Rows of the per-workgroup parameter sums the fused epilogue of this geometry produces (per quantity).
+int64_t pointwise_epilogue_tiles(int32_t N, int32_t HW) {
+  const int64_t groups = (int64_t)N * ((HW + 31) / 32);
+  return (groups + 3) / 4;
+}
+
 bool pointwise_enabled() {
   static const bool disabled = getenv("SRGAN_NO_POINTWISE") != nullptr;
   return !disabled;
@@ -503,7 +553,9 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
     p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
     p.epi_cols = (int32_t)col_blocks;
-    if (epilogue->g_gamma) {
+    if (epilogue->partial_out) {
+      p.epi_partial = epilogue->partial_out;
+    } else if (epilogue->g_gamma) {
       p.epi_partial = partial_workspace((size_t)2 * col_blocks * CO * sizeof(float), stream);
       SRGAN_REQUIRE(p.epi_partial, SRGAN_EINVAL, "pointwise batch-norm backward epilogue: register a workspace for this "
                     "stream first (srgan_set_workspace, >= srgan_workspace_bytes())");
@@ -529,7 +581,8 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     p.xcd_remap = 0;
     launch(rest_mi, dim3((unsigned)col_blocks, (unsigned)split, 1));
   }
-  if (p.epi_partial) bn_partial_reduce_run(p.epi_partial, (int)col_blocks, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
+  if (p.epi_partial && !epilogue->partial_out)
+    bn_partial_reduce_run(p.epi_partial, (int)col_blocks, CO, p.bn_inv, epilogue->g_gamma, epilogue->g_beta, stream);
   const int status = launch_status();
   // algorithmic bytes of the fused epilogue: besides the operands, x is read for the mask and, in accumulate mode, the
   // gradient buffer is read as well as written

@@ -66,6 +66,51 @@ def _empty(shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+BATCHED_REDUCE = True   # one batch-norm parameter-sum reduction per block backward instead of one per convolution
+
+
+def _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, device):
+    """Where every fused data-gradient epilogue of the block's backward leaves its per-workgroup batch-norm parameter sums
+    inside one scratch tensor, and the device-resident job table of the single reduction that follows.  Cached on the
+    block's first layer: the offsets depend only on the geometry, the pointers (frozen statistics, gradient arena) only
+    on where the parameters live."""
+    key = (n, c0, h, w, epilogue1, epilogue2, str(device),
+           layers[0].norm1.weight.grad.data_ptr(), layers[-1].norm2.weight.grad.data_ptr())
+    cached = getattr(layers[0], '_srgan_reduce_plan', None)
+    if cached is not None and cached['key'] == key:
+        return cached
+    lib = _lib.library()
+    width = layers[0].conv1.out_channels
+    jobs, offsets, total, max_channels, max_tiles = [], [], 0, 0, 0
+    for index, layer in enumerate(layers):
+        cin = c0 + index * growth
+        entry = {}
+        for which, enabled, desc, norm, channels in (
+                (2, epilogue2, _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs), layer.norm2, width),
+                (1, epilogue1, _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), layer.norm1, cin)):
+            if not enabled:
+                continue
+            tiles = int(lib.srgan_conv2d_bwd_data_bnrelu_tiles(desc))
+            if tiles <= 0:
+                return None
+            inv, _ = norm._inverse_std()
+            entry[which] = total
+            jobs.append(_lib.BnReduceJob(total, tiles, channels, inv.data.data_ptr(), norm.weight.grad.data_ptr(),
+                                         norm.bias.grad.data_ptr()))
+            total += 2 * tiles * channels
+            max_channels, max_tiles = max(max_channels, channels), max(max_tiles, tiles)
+        offsets.append(entry)
+    if not jobs:
+        return None
+    import ctypes
+    table = (_lib.BnReduceJob * len(jobs))(*jobs)
+    host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+    plan = dict(key=key, offsets=offsets, total=total, count=len(jobs), max_channels=max_channels, max_tiles=max_tiles,
+                jobs=host.to(device), keep=[norm._inverse_std() for layer in layers for norm in (layer.norm1, layer.norm2)])
+    layers[0]._srgan_reduce_plan = plan
+    return plan
+
+
 def dense_block(x, layers):
     """``layers``: the block's ``_DenseLayer`` modules (norm1, conv1, norm2, conv2)."""
     n, c0, h, w = x.shape
@@ -157,6 +202,12 @@ def dense_block(x, layers):
         gbuf = _empty(g.shape, device)            # private copy: the incoming gradient may be shared
         F._call('srgan_ew_unary', F.U_COPY, g.data.data_ptr(), gbuf.data_ptr(), gbuf.numel(), 0.0, 0.0, stream)
         kept = [None] * len(layers)               # per layer, for the double backward: (gradient at conv1's output, b1)
+        # the batch-norm parameter sums of every fused epilogue land in one scratch tensor, reduced by ONE launch at the end
+        plan = scratch = None
+        if BATCHED_REDUCE and want_params and (epilogue1 or epilogue2):
+            plan = _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, device)
+            if plan is not None:
+                scratch = _empty((plan['total'],), device)
         overlap = WGRAD_STREAM and want_params and prologue and not recorded
         if overlap:
             main, side = torch.cuda.current_stream(device), _side_stream(device)
@@ -182,7 +233,10 @@ def dense_block(x, layers):
                 F._call('srgan_conv2d_bwd_weight', desc2, t2.data_ptr(), g_new, layer.conv2.weight.grad.data_ptr(), 1, 0,
                         stream)
             g_b1 = _empty(b1.shape, device)
-            if epilogue2:
+            if epilogue2 and plan is not None:
+                F._call('srgan_conv2d_bwd_data_bnrelu_partials', desc2, g_new, layer.conv2.weight.data_ptr(),
+                        bn_struct(layer.norm2), b1.data_ptr(), g_b1.data_ptr(), _ptr(scratch, plan['offsets'][index][2]), 0, stream)
+            elif epilogue2:
                 F._call('srgan_conv2d_bwd_data_bnrelu', desc2, g_new, layer.conv2.weight.data_ptr(),
                         bn_struct(layer.norm2), b1.data_ptr(), g_b1.data_ptr(),
                         layer.norm2.weight.grad.data_ptr() if want_params else None,
@@ -206,7 +260,11 @@ def dense_block(x, layers):
             elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc1, t1.data_ptr(), g_b1.data_ptr(),
                         layer.conv1.weight.grad.data_ptr(), 1, 0, stream)
-            if epilogue1:
+            if epilogue1 and plan is not None:
+                F._call('srgan_conv2d_bwd_data_bnrelu_partials', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0),
+                        g_b1.data_ptr(), layer.conv1.weight.data_ptr(), bn_struct(layer.norm1), buffer.data_ptr(),
+                        gbuf.data_ptr(), _ptr(scratch, plan['offsets'][index][1]), 1, stream)
+            elif epilogue1:
                 F._call('srgan_conv2d_bwd_data_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0),
                         g_b1.data_ptr(), layer.conv1.weight.data_ptr(), bn_struct(layer.norm1), buffer.data_ptr(),
                         gbuf.data_ptr(), layer.norm1.weight.grad.data_ptr() if want_params else None,
@@ -228,6 +286,9 @@ def dense_block(x, layers):
                 kept[index] = (g_b1, b1)
             else:
                 saved[index] = None
+        if plan is not None:
+            F._call('srgan_bn_partial_reduce_batched', plan['jobs'].data_ptr(), plan['count'], plan['max_channels'],
+                    plan['max_tiles'], scratch.data_ptr(), stream)
         if overlap:
             main.wait_stream(side)                # the weight gradients are in the arena before anything consumes it
             del alive
