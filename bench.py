@@ -92,6 +92,9 @@ def parse():
                              'initialisation, gradient penalty inactive)')
     parser.add_argument('--no-overlap-exchange', action='store_true',
                         help='data parallel: wait for each gradient all-reduce where it is started')
+    parser.add_argument('--step-graph', action='store_true',
+                        help='capture the iteration once as a HIP graph and replay it (single device): removes the host '
+                             'enqueue time, which bounds the step at 224x224')
     parser.add_argument('--master-port', type=int, default=None, help='self-launch only: rendezvous port on 127.0.0.1')
     return parser.parse_args()
 
@@ -113,6 +116,7 @@ def build_experiment(args, dp):
     settings.reference_schedule = args.reference_schedule
     settings.overlap_dnn_step = args.overlap_dnn
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
+    settings.step_graph = bool(args.step_graph)
     if workload is None:
         experiment = CrowdExperiment(settings)
     else:
@@ -154,12 +158,15 @@ def gp_scale(args):
     return workload['gp_scale'] if workload is not None else GP_SCALE.get(args.image_size, 1.27)
 
 
-def one_step(experiment, labeled, unlabeled, step):
+def one_step(experiment, labeled, unlabeled, step, eager=False):
     batch = next(labeled)
     x, labels = (batch[0], (batch[1], batch[2])) if len(batch) == 3 else batch
     u = next(unlabeled)[0]
-    experiment.dnn_training_step(x, labels, step + 1)      # step + 1 with a huge summary period: no host sync
-    experiment.gan_training_step(x, labels, u, step + 1)
+    if eager:                                               # the event-bracketed step of the roofline leg
+        experiment.dnn_training_step(x, labels, step + 1)
+        experiment.gan_training_step(x, labels, u, step + 1)
+    else:                                                   # step + 1 with a huge summary period: no host sync
+        experiment.training_iteration(x, labels, u, step + 1)
 
 
 def pmc_traffic(args):
@@ -357,6 +364,12 @@ def main():
 
     for step in range(args.warmup):
         one_step(experiment, labeled, unlabeled, step)
+    if args.step_graph and world == 1:
+        # graph capture is set-up, not a step: make sure the timed region only replays
+        for extra in range(4):
+            if getattr(experiment, '_captured_iteration', None) is not None and experiment._captured_iteration.replays:
+                break
+            one_step(experiment, labeled, unlabeled, step=0)
     fence()
     start = time.perf_counter()
     for step in range(args.steps):
@@ -390,6 +403,9 @@ def main():
                    'gradient_penalty': 'active' if penalty > 0.0 else 'inactive', 'gradient_penalty_last': penalty,
                    'discriminator_weight_scale': gp_scale(args)},
     }
+    captured = getattr(experiment, '_captured_iteration', None)
+    result['config']['launch'] = (f'HIP graph replay ({captured.replays} replayed, {captured.eager_iterations} eager iterations)'
+                                  if captured is not None else 'eager (Python tape enqueues every kernel)')
     if dp is not None:
         result['config']['gradient_exchange'] = ('blocking' if args.no_overlap_exchange else
                                                  'asynchronous, overlapped with backward / next phase') + f' ({args.backend})'
@@ -403,7 +419,7 @@ def main():
         from srgan_amd import _lib
         lib = _lib.library()
         lib.srgan_profile_begin()
-        one_step(experiment, labeled, unlabeled, args.warmup + args.steps)
+        one_step(experiment, labeled, unlabeled, args.warmup + args.steps, eager=True)
         experiment.join_dnn_stream()
         kernel_ms, flops, mfma_flops, launches = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         _lib.check(lib.srgan_profile_end(ctypes.byref(kernel_ms), ctypes.byref(flops), ctypes.byref(mfma_flops),

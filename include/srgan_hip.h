@@ -288,6 +288,11 @@ int srgan_crowd_density_label(const float* heads_yx, int32_t M, int32_t H, int32
  * `step` is the 1-based update count. */
 int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int32_t step, void* stream);
+/* The same update with the count kept on the device: `state` = 3 x 4 bytes {int32 updates so far, float, float} owned
+ * by the caller (initialise the first word; the other two are scratch for the bias corrections).  Every call advances
+ * the count by one ON THE STREAM, so a HIP graph that captured the call replays as the next update each time. */
+int srgan_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int32_t* state, void* stream);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------
  * Between begin and end every contraction launch (conv / gemm passes) is bracketed by a pair of HIP events on

@@ -93,6 +93,7 @@ SIGNATURES = {
     'srgan_crowd_iknn_map': ([vp, i32, i32, i32, i32, f32, f32, vp, vp], ctypes.c_int),
     'srgan_crowd_extract_patches': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     'srgan_adam_step': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp], ctypes.c_int),
+    'srgan_adam_step_counted': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp], ctypes.c_int),
 }
 
 
@@ -142,18 +143,21 @@ _workspaces = {}      # (device index, stream handle) -> the torch tensor regist
 
 def stream_handle(stream=None):
     """The hipStream_t of ``stream`` (default: torch's current stream), with the caller-owned split-K workspace of
-    include/srgan_hip.h registered for it on first use (one 2 MiB block per device and stream; the library itself
-    never allocates)."""
+    include/srgan_hip.h registered for it on first use (one block of srgan_workspace_bytes() per device and stream; the
+    library itself never allocates).  Called once per launch: the raw-handle query avoids building a Stream object."""
     import torch
-    stream = torch.cuda.current_stream() if stream is None else stream
-    key = (stream.device.index, stream.cuda_stream)
-    if key not in _workspaces:
+    if stream is None:
+        device = torch._C._cuda_getDevice()
+        handle = torch._C._cuda_getCurrentRawStream(device)
+    else:
+        device, handle = stream.device.index, stream.cuda_stream
+    if (device, handle) not in _workspaces:
         lib = library()
-        block = torch.empty(lib.srgan_workspace_bytes() // 4, dtype=torch.float32, device=stream.device)
-        with torch.cuda.device(stream.device):
-            check(lib.srgan_set_workspace(block.data_ptr(), block.numel() * 4, stream.cuda_stream), 'srgan_set_workspace')
-        _workspaces[key] = block
-    return stream.cuda_stream
+        with torch.cuda.device(device):
+            block = torch.empty(lib.srgan_workspace_bytes() // 4, dtype=torch.float32, device=torch.device('cuda', device))
+            check(lib.srgan_set_workspace(block.data_ptr(), block.numel() * 4, handle), 'srgan_set_workspace')
+        _workspaces[(device, handle)] = block
+    return handle
 
 
 def check(status, what):

@@ -39,7 +39,9 @@ constexpr int WG3_THREADS = 192;
 
 // PREC = 1 / 2: bf16 / fp16 MFMA operands (v_mfma_f32_32x32x16_*): a 16-deep step is one 16-pixel tile row, a lane rounds
 // the 8 pixels of its half; the three kernel columns share one window of 10 patch values.
-template <int TH, int PREC = 0>
+// RAGGED: widths that are not a multiple of 4 or rows that are only 4-byte aligned (the 14- and 7-wide planes at the
+// reference's 224 x 224): the staging loads are single floats with per-element validity instead of aligned float4.
+template <int TH, int PREC = 0, bool RAGGED = false>
 __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgrad3Params p) {
   constexpr int PW = WG3_TW + 2, PH = TH + 2;
   constexpr int PATCH = PH * PW;            // halo patch of one channel
@@ -85,8 +87,9 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
   float* xs_row = xs + sch * PS + srow * PW;
   float* gs_row = gs + sch * GS + srow * WG3_TW;
 
-  float4 xv[6], gv[4];
-  uint32_t okbits = 0;
+  float4 xv[RAGGED ? 1 : 6], gv[RAGGED ? 1 : 4];
+  float xr[RAGGED ? PW : 1], gr[RAGGED ? WG3_TW : 1];
+  uint32_t okbits = 0, okbits_g = 0;
 
   // Issues the loads of one tile (no use of the values here) and records which of them are real.
   auto fetch = [&](int tile) {
@@ -98,6 +101,31 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
     const float* xn = p.x + (int64_t)n * p.x_bs;
     const float* gn = p.gy + (int64_t)n * p.gy_bs;
     okbits = 0;
+    if constexpr (RAGGED) {
+      okbits_g = 0;
+      if (x_owner) {
+        const int h = h0 + srow - 1;
+        const bool row_ok = x_ch_ok && (unsigned)h < (unsigned)p.H;
+        const uint32_t row_off = x_ch_off + (uint32_t)(min(max(h, 0), p.H - 1) * p.W);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+          const int col = w0 - 1 + i;
+          okbits |= (row_ok && (unsigned)col < (unsigned)p.W ? 1u : 0u) << i;
+          xr[i] = xn[row_off + (uint32_t)min(max(col, 0), p.W - 1)];
+        }
+      }
+      if (g_owner) {
+        const int h = h0 + srow;
+        const bool row_ok = g_ch_ok && h < p.H;
+        const uint32_t row_off = g_ch_off + (uint32_t)(min(h, p.H - 1) * p.W);
+#pragma unroll
+        for (int i = 0; i < WG3_TW; ++i) {
+          okbits_g |= (row_ok && w0 + i < p.W ? 1u : 0u) << i;
+          gr[i] = gn[row_off + (uint32_t)min(w0 + i, p.W - 1)];
+        }
+      }
+      return;
+    }
     if (x_owner) {
       const int h = h0 + srow - 1;
       const bool row_ok = x_ch_ok && (unsigned)h < (unsigned)p.H;
@@ -128,6 +156,20 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
   if (tile < p.tiles) fetch(tile);
   for (; tile < p.tiles; tile += (int)gridDim.x) {
     __syncthreads();                        // the previous tile's MFMA reads are done
+    if constexpr (RAGGED) {
+      if (x_owner) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+          float v = xr[i];
+          if (pro) v = fmaxf(fmaf(v, pro_a, pro_b), 0.f);
+          xs_row[i] = (okbits >> i) & 1u ? v : 0.f;
+        }
+      }
+      if (g_owner) {
+#pragma unroll
+        for (int i = 0; i < WG3_TW; ++i) gs_row[i] = (okbits_g >> i) & 1u ? gr[i] : 0.f;
+      }
+    } else {
     if (x_owner) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
@@ -154,6 +196,7 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
         gs_row[4 * q + 2] = ok ? gv[q].z : 0.f;
         gs_row[4 * q + 3] = ok ? gv[q].w : 0.f;
       }
+    }
     }
     __syncthreads();
     const int next = tile + (int)gridDim.x;
@@ -248,8 +291,8 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   p.tiles_x = (W + WG3_TW - 1) / WG3_TW;
   p.tiles_y = (H + th - 1) / th;
   const int64_t tiles = (int64_t)N * p.tiles_y * p.tiles_x;
-  SRGAN_REQUIRE(W % 4 == 0 && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0 && x_bs % 4 == 0 && gy_bs % 4 == 0, SRGAN_EINVAL,
-                "conv3x3 wgrad 16-byte rows");
+  const bool ragged = W % 4 != 0 || (((uintptr_t)x | (uintptr_t)gy) & 15) != 0 || x_bs % 4 != 0 || gy_bs % 4 != 0;
+  SRGAN_REQUIRE(!(ragged && precision), SRGAN_EUNSUPPORTED, "conv3x3 wgrad: mixed precision needs 16-byte rows");
   SRGAN_REQUIRE(tiles < (int64_t)1 << 31 && ci_chunks <= 65535 && co_chunks <= 65535, SRGAN_ERANGE, "conv3x3 wgrad grid");
   p.tiles = (int)tiles;
   // Walkers: five resident 3-wave workgroups per CU (120 VGPRs, 22 KB of LDS) over the whole grid, and at least `depth` tiles per
@@ -267,6 +310,7 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   const int profile_slot = profile_bracket_begin(stream);
   if (precision == 1) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1>), grid, dim3(WG3_THREADS), 0, stream, p);
   else if (precision == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2>), grid, dim3(WG3_THREADS), 0, stream, p);
+  else if (ragged) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 0, true>), grid, dim3(WG3_THREADS), 0, stream, p);
   else if (th == 4) hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WG3_THREADS), 0, stream, p);
   else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(WG3_THREADS), 0, stream, p);
   const int status = launch_status();

@@ -214,6 +214,38 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// The same update with the step count and its two bias corrections resident on the device, so that a HIP graph of a
+// whole training iteration replays with a different count every time: ``state`` = {int32 step, float bias_correction1,
+// float sqrt(bias_correction2)}; the first kernel advances it (in double, as the host path does), the second reads it.
+__global__ void adam_advance_kernel(int32_t* __restrict__ state, float beta1, float beta2) {
+  const int32_t step = state[0] + 1;
+  state[0] = step;
+  float* corrections = reinterpret_cast<float*>(state);
+  corrections[1] = (float)(1.0 - pow((double)beta1, (double)step));
+  corrections[2] = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+}
+
+__global__ __launch_bounds__(256) void adam_counted_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                           float lr, float beta1, float beta2, float eps,
+                                                           float weight_decay, const float* __restrict__ state) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const float bias_correction1 = state[1], bias_correction2_sqrt = state[2];
+  const float step_size = lr / bias_correction1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float grad = g[i];
+    const float param = p[i];
+    if (weight_decay != 0.f) grad = grad + weight_decay * param;
+    float mi = m[i], vi = v[i];
+    mi = mi + (grad - mi) * (1.f - beta1);
+    vi = vi * beta2 + (1.f - beta2) * grad * grad;
+    const float denom = sqrtf(vi) / bias_correction2_sqrt + eps;
+    p[i] = param - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 }  // namespace srgan
 
 using namespace srgan;
@@ -336,6 +368,16 @@ int srgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                      beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+  return launch_status();
+}
+
+int srgan_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int32_t* state, void* stream) {
+  SRGAN_REQUIRE(p && g && m && v && state && n >= 0, SRGAN_EINVAL, "srgan_adam_step_counted arguments");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+  if (n == 0) return launch_status();
+  hipLaunchKernelGGL(adam_counted_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     lr, beta1, beta2, eps, weight_decay, reinterpret_cast<const float*>(state));
   return launch_status();
 }
 

@@ -750,13 +750,18 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
 
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution with at least one wave's worth of input channels: the
 // LDS-patch kernel of conv3x3_wgrad.hip.
-static bool wgrad3x3_geometry(const ConvGeom& g, int min_width = 16) {
-  return g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.W >= min_width && g.W % 4 == 0 &&
-         g.C >= 32 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0;
+// `aligned_only`: widths that are a multiple of 4 with 16-byte aligned rows (the float4 staging; the mixed-precision
+// variants have no other); otherwise the kernel's ragged variant also takes the 14- and 7-wide planes of 224 x 224.
+static bool wgrad3x3_geometry(const ConvGeom& g, int min_width = 7, bool aligned_only = false) {
+  static const bool no_ragged = getenv("SRGAN_WGRAD3_NO_RAGGED") != nullptr;
+  const bool aligned = g.W % 4 == 0 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0;
+  if (!aligned && (aligned_only || no_ragged)) return false;
+  if (no_ragged && !aligned_only) min_width = 16;              // the selection before the ragged variant existed
+  return g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.W >= min_width && g.C >= 32;
 }
 
 static bool use_wgrad3x3(const ConvGeom& g, const float* x, const float* gy, int force) {
-  return force == 0 && conv3x3_wgrad_enabled() && wgrad3x3_geometry(g) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
+  return force == 0 && conv3x3_wgrad_enabled() && wgrad3x3_geometry(g);
 }
 
 bool pointwise_ksplit_wanted(int32_t N, int32_t K, int32_t M, int32_t HW, bool fused_bn);
@@ -769,13 +774,15 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
                         int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
 
 static bool pointwise_wgrad_geometry(const ConvGeom& g) {
-  return pointwise(g) && (g.H * g.W) % 32 == 0 && g.x_bs % 4 == 0 && g.y_bs % 4 == 0 && g.C >= 16 && g.K >= 16;
+  static const bool no_ragged = getenv("SRGAN_PWG_NO_RAGGED") != nullptr;
+  if (no_ragged && ((g.H * g.W) % 32 != 0 || g.x_bs % 4 != 0 || g.y_bs % 4 != 0)) return false;
+  return pointwise(g) && g.H * g.W >= 32 && g.C >= 16 && g.K >= 16;
 }
 
-// Weight gradient of a 1x1 / stride 1 convolution on whole 32-pixel chunks with 16-byte aligned rows: the
-// register-streamed kernel of pointwise_wgrad.hip.
+// Weight gradient of a 1x1 / stride 1 convolution: the register-streamed kernel of pointwise_wgrad.hip (whole 32-pixel
+// chunks with 16-byte aligned rows, or its ragged variant).
 static bool use_pointwise_wgrad(const ConvGeom& g, const float* x, const float* gy, int force) {
-  return force == 0 && pointwise_wgrad_enabled() && pointwise_wgrad_geometry(g) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
+  return force == 0 && pointwise_wgrad_enabled() && pointwise_wgrad_geometry(g);
 }
 
 int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
@@ -982,7 +989,7 @@ int srgan_conv2d_bwd_weight(const srgan_conv_desc* desc, const float* x, const f
   SRGAN_REQUIRE(dtype_ok(dtype), SRGAN_EINVAL, "srgan_conv2d_bwd_weight compute_dtype");
   // (mixed precision also takes 8-wide planes on the 16-wide tile: half of the columns are dead, but the alternative is
   // the gather-bound generic kernel)
-  if (dtype && force_kernel == 0 && conv3x3_wgrad_enabled() && wgrad3x3_geometry(g, 8) &&
+  if (dtype && force_kernel == 0 && conv3x3_wgrad_enabled() && wgrad3x3_geometry(g, 8, true) &&
       (((uintptr_t)x | (uintptr_t)gy) & 15) == 0)
     return conv3x3_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, accumulate, (hipStream_t)stream, nullptr,
                              dtype);
@@ -1118,7 +1125,6 @@ int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, 
   SRGAN_REQUIRE(x && gy && gw && bn_ok(bn), SRGAN_EINVAL, "srgan_conv2d_bwd_weight_bnrelu pointers");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 2), SRGAN_EUNSUPPORTED,
                 "srgan_conv2d_bwd_weight_bnrelu geometry support");
-  SRGAN_REQUIRE((((uintptr_t)x | (uintptr_t)gy) & 15) == 0, SRGAN_EINVAL, "srgan_conv2d_bwd_weight_bnrelu alignment");
   const float* const coefficients[4] = {bn->mean, bn->inv_std, bn->gamma, bn->beta};
   if (pointwise(g))
     return pointwise_wgrad_run(x, g.x_bs, gy, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, accumulate, (hipStream_t)stream,

@@ -33,7 +33,11 @@ struct PwWgradParams {
 
 constexpr int PWG_MI = 2, PWG_NI = 2;      // 64 x 64 output tile per workgroup
 
-template <bool PRO>
+// RAGGED: planes whose size is not a multiple of 32 pixels (28 x 28, 14 x 14, 7 x 7 at the reference's 224 x 224) or
+// whose rows are only 4-byte aligned.  An image is ceil(HW / 32) chunks; a float4 that would cross the end of the row
+// is loaded from the row's last four pixels instead (the SAME pixels for both operands), and the elements that repeat
+// an earlier float4 of the lane are switched off in the gy operand when it is used -- a zero times a finite value.
+template <bool PRO, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradParams p) {
   constexpr int MI = PWG_MI, NI = PWG_NI, ROWS = MI * 32, COLS = NI * 32, LDR = COLS + 1;
   __shared__ float red[2 * ROWS * LDR];
@@ -70,29 +74,44 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradPa
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   float4 a0[MI][4], b0[NI][4], a1[MI][4], b1[NI][4];
-  auto fetch = [&](int chunk, float4 (&a)[MI][4], float4 (&b)[NI][4]) {
+  uint32_t live0 = 0xFFFFu, live1 = 0xFFFFu;               // RAGGED: bit 4 * q + e = element e of float4 q is a new pixel
+  auto fetch = [&](int chunk, float4 (&a)[MI][4], float4 (&b)[NI][4], uint32_t& live) {
     chunk = min(chunk, p.chunks - 1);                      // clamped: a worker's surplus fetch is never used
     const int n = chunk / p.chunks_per_image;
     const uint32_t pix = (uint32_t)(chunk - n * p.chunks_per_image) * 32u;
-    const float* ga = p.gy + (int64_t)n * p.gy_bs + pix;
-    const float* xb = p.x + (int64_t)n * p.x_bs + pix;
+    const float* ga = p.gy + (int64_t)n * p.gy_bs + (RAGGED ? 0u : pix);
+    const float* xb = p.x + (int64_t)n * p.x_bs + (RAGGED ? 0u : pix);
+    uint32_t within[4];                                    // RAGGED: pixel offset of float4 q inside the row
+    if (RAGGED) {
+      live = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int want = (int)pix + 16 * lhi + 4 * q, last = p.HW - 4;
+        const int repeated = min(max(want - last, 0), 4);  // leading elements of the clamped float4 already seen
+        within[q] = (uint32_t)min(want, last) - 16u * lhi; // (a_row / b_row already hold the lane half's 16)
+        live |= ((0xFu << repeated) & 0xFu) << (4 * q);
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a[mi][q] = *reinterpret_cast<const float4*>(ga + a_row[mi] + 4 * q);
+      for (int q = 0; q < 4; ++q) a[mi][q] = *reinterpret_cast<const float4*>(ga + a_row[mi] + (RAGGED ? within[q] : 4u * q));
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b[ni][q] = *reinterpret_cast<const float4*>(xb + b_row[ni] + 4 * q);
+      for (int q = 0; q < 4; ++q) b[ni][q] = *reinterpret_cast<const float4*>(xb + b_row[ni] + (RAGGED ? within[q] : 4u * q));
   };
-  auto compute = [&](const float4 (&a)[MI][4], const float4 (&b)[NI][4]) {
+  auto compute = [&](const float4 (&a)[MI][4], const float4 (&b)[NI][4], const uint32_t live) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float av[MI], bv[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) av[mi] = e == 0 ? a[mi][q].x : (e == 1 ? a[mi][q].y : (e == 2 ? a[mi][q].z : a[mi][q].w));
+        for (int mi = 0; mi < MI; ++mi) {
+          av[mi] = e == 0 ? a[mi][q].x : (e == 1 ? a[mi][q].y : (e == 2 ? a[mi][q].z : a[mi][q].w));
+          if (RAGGED) av[mi] = (live >> (4 * q + e)) & 1u ? av[mi] : 0.f;
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           bv[ni] = e == 0 ? b[ni][q].x : (e == 1 ? b[ni][q].y : (e == 2 ? b[ni][q].z : b[ni][q].w));
@@ -108,13 +127,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradPa
   };
 
   if (cbeg < cend) {
-    fetch(cbeg, a0, b0);
+    fetch(cbeg, a0, b0, live0);
     for (int c = cbeg; c < cend; c += 2) {
-      fetch(c + 1, a1, b1);
-      compute(a0, b0);
+      fetch(c + 1, a1, b1, live1);
+      compute(a0, b0, live0);
       if (c + 1 < cend) {
-        fetch(c + 2, a0, b0);
-        compute(a1, b1);
+        fetch(c + 2, a0, b0, live0);
+        compute(a1, b1, live1);
       }
     }
   }
@@ -176,7 +195,7 @@ bool pointwise_wgrad_enabled() {
 }
 
 // gw (=,+=) the weight gradient of a 1x1 convolution; x / gy may be channel-slice views (batch strides in
-// elements).  Requires HW % 32 == 0 and 16-byte aligned rows (checked by the caller).
+// elements).  HW % 32 == 0 with 16-byte aligned rows takes the plain kernel, anything else with HW >= 4 the RAGGED one.
 int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
                         int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn) {
   PwWgradParams p;
@@ -187,7 +206,9 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
   const int tiles_m = (CO + PWG_MI * 32 - 1) / (PWG_MI * 32);
   p.tiles_n = (CI + PWG_NI * 32 - 1) / (PWG_NI * 32);
   const int tiles = tiles_m * p.tiles_n;
-  p.chunks_per_image = HW / 32;
+  const bool ragged = HW % 32 != 0 || x_bs % 4 != 0 || gy_bs % 4 != 0 || (((uintptr_t)x | (uintptr_t)gy) & 15) != 0;
+  SRGAN_REQUIRE(HW >= 4, SRGAN_EUNSUPPORTED, "pointwise wgrad plane of fewer than 4 pixels");
+  p.chunks_per_image = (HW + 31) / 32;
   const int64_t chunks = (int64_t)N * p.chunks_per_image;
   SRGAN_REQUIRE(chunks < ((int64_t)1 << 30) && tiles < (1 << 30), SRGAN_ERANGE, "pointwise wgrad grid");
   p.chunks = (int)chunks;
@@ -205,8 +226,10 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
   if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)CO * CI * sizeof(float), stream));
   dim3 grid((unsigned)tiles, (unsigned)split, 1);
   const int profile_slot = profile_bracket_begin(stream);
-  if (bn) hipLaunchKernelGGL(pointwise_wgrad_kernel<true>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(pointwise_wgrad_kernel<false>, grid, dim3(256), 0, stream, p);
+  if (ragged && bn) hipLaunchKernelGGL((pointwise_wgrad_kernel<true, true>), grid, dim3(256), 0, stream, p);
+  else if (ragged) hipLaunchKernelGGL((pointwise_wgrad_kernel<false, true>), grid, dim3(256), 0, stream, p);
+  else if (bn) hipLaunchKernelGGL((pointwise_wgrad_kernel<true, false>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((pointwise_wgrad_kernel<false, false>), grid, dim3(256), 0, stream, p);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, CO, CI, (int64_t)N * HW, 6, PWG_MI * 32, PWG_NI * 32, split);
   return status;

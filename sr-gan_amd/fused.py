@@ -76,9 +76,9 @@ def _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, d
     on where the parameters live."""
     key = (n, c0, h, w, epilogue1, epilogue2, str(device),
            layers[0].norm1.weight.grad.data_ptr(), layers[-1].norm2.weight.grad.data_ptr())
-    cached = getattr(layers[0], '_srgan_reduce_plan', None)
-    if cached is not None and cached['key'] == key:
-        return cached
+    plans = layers[0].__dict__.setdefault('_srgan_reduce_plans', {})      # one per batch size the block is run at
+    if key in plans:
+        return plans[key]
     lib = _lib.library()
     width = layers[0].conv1.out_channels
     jobs, offsets, total, max_channels, max_tiles = [], [], 0, 0, 0
@@ -107,8 +107,16 @@ def _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, d
     host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
     plan = dict(key=key, offsets=offsets, total=total, count=len(jobs), max_channels=max_channels, max_tiles=max_tiles,
                 jobs=host.to(device), keep=[norm._inverse_std() for layer in layers for norm in (layer.norm1, layer.norm2)])
-    layers[0]._srgan_reduce_plan = plan
+    plans[key] = plan
     return plan
+
+
+def _block_parameters(layers):
+    """The block's parameters in ``layer.parameters()`` order (the module tree is fixed: enumerated once)."""
+    cached = layers[0].__dict__.get('_srgan_block_parameters')
+    if cached is None or cached[0] != len(layers):
+        cached = layers[0].__dict__['_srgan_block_parameters'] = (len(layers), [p for layer in layers for p in layer.parameters()])
+    return cached[1]
 
 
 def dense_block(x, layers):
@@ -122,7 +130,7 @@ def dense_block(x, layers):
     buffer = _empty((n, total, h, w), device)
     buffer_bs = total * hw
     saved = []
-    parameter_vars = [parameter_var(p) for layer in layers for p in layer.parameters()]
+    parameter_vars = [parameter_var(p) for p in _block_parameters(layers)]
     requires = grad_enabled() and (x.requires_grad or any(v.requires_grad for v in parameter_vars))
     train = requires and any(v.requires_grad for v in parameter_vars)     # t1 / t2 are only read by weight gradients
     width = layers[0].conv1.out_channels

@@ -18,13 +18,29 @@ class Adam:
         self.exp_avg = torch.zeros_like(arena.data)
         self.exp_avg_sq = torch.zeros_like(arena.data)
         self.step_count = 0
+        self.device_state = None      # {int32 step, 2 floats}: set by count_on_device() for HIP-graph replay
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
+    def count_on_device(self):
+        """Keep the update count on the device from now on (``srgan_adam_step_counted``): a captured ``step()`` then
+        replays as the NEXT update every time.  ``step_count`` stays the host's mirror for checkpoints."""
+        if self.device_state is None:
+            self.device_state = torch.zeros(4, dtype=torch.int32, device=self.arena.data.device)
+        self.device_state[0] = self.step_count
+        return self
+
     def step(self):
         group = self.param_groups[0]
         self.step_count += 1
+        if self.device_state is not None:
+            _lib.check(_lib.library().srgan_adam_step_counted(
+                self.arena.data.data_ptr(), self.arena.grad.data_ptr(), self.exp_avg.data_ptr(),
+                self.exp_avg_sq.data_ptr(), self.arena.numel, group['lr'], group['betas'][0], group['betas'][1],
+                group['eps'], group['weight_decay'], self.device_state.data_ptr(), F._stream()),
+                'srgan_adam_step_counted')
+            return
         _lib.check(_lib.library().srgan_adam_step(
             self.arena.data.data_ptr(), self.arena.grad.data_ptr(), self.exp_avg.data_ptr(),
             self.exp_avg_sq.data_ptr(), self.arena.numel, group['lr'], group['betas'][0], group['betas'][1],
@@ -56,3 +72,5 @@ class Adam:
         if len(steps) > 1:
             raise ValueError('per-parameter step counts differ; the flat Adam kernel needs one step count')
         self.step_count = steps.pop() if steps else 0
+        if self.device_state is not None:
+            self.device_state[0] = self.step_count

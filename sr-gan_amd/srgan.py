@@ -194,10 +194,22 @@ class Experiment(ABC):
         for step in range(self.starting_step, self.settings.steps_to_run):
             self.adjust_learning_rate(step)
             labeled_examples, labels = self.unpack_labeled(next(train_dataset_generator))
-            self.dnn_training_step(labeled_examples, labels, step)
             unlabeled_examples = as_var(next(unlabeled_dataset_generator)[0])
-            self.gan_training_step(labeled_examples, labels, unlabeled_examples, step)
+            self.training_iteration(labeled_examples, labels, unlabeled_examples, step)
             step_time_start = self.end_of_step(step, self.gan_summary_writer, step_time_start)
+
+    def training_iteration(self, labeled_examples, labels, unlabeled_examples, step):
+        """The body of the reference's loop (srgan.py:104-118): the DNN step, then the GAN step.  With
+        ``settings.step_graph`` on a single device the iteration is captured once as a HIP graph and replayed
+        (``graph.CapturedIteration``); summary steps and the first ``settings.step_graph_warmup`` iterations run eagerly."""
+        if getattr(self.settings, 'step_graph', False) and examples_on_gpu() and \
+                (self.dp is None or self.dp.world_size == 1):
+            if getattr(self, '_captured_iteration', None) is None:
+                from .graph import CapturedIteration
+                self._captured_iteration = CapturedIteration(self)
+            return self._captured_iteration.run(labeled_examples, labels, unlabeled_examples, step)
+        self.dnn_training_step(labeled_examples, labels, step)
+        self.gan_training_step(labeled_examples, labels, unlabeled_examples, step)
 
     def prepare_optimizers(self):
         """Adam for D (with coupled L2), G and DNN (reference srgan.py:131-138) on the flat arenas."""
@@ -332,29 +344,32 @@ class Experiment(ABC):
             return draw(local_batch)
         return self.dp.shard(draw(self.dp.global_batch(local_batch)))
 
+    def draw_discriminator_noise(self, batch_size):
+        """Host tensor: float64 two-Gaussian mixture from NumPy's global stream cast to float32 (srgan.py:286-289)."""
+        offset = self.settings.mean_offset
+        return self._global_draw(batch_size, lambda count: torch.tensor(
+            MixtureModel([norm(-offset, 1), norm(offset, 1)]).rvs(size=[count, self.G.input_size]).astype(np.float32)))
+
+    def draw_generator_noise(self, batch_size):
+        """Host tensor: N(0, 1) from torch's CPU stream (srgan.py:301)."""
+        return self._global_draw(batch_size, lambda count: torch.randn(count, self.G.input_size))
+
+    def draw_interpolation_alpha(self, batch_size):
+        """Host tensor: U[0, 1) per example.  The reference draws on the device (srgan.py:364), which is not
+        reproducible across devices; here it comes from torch's CPU stream and is copied over."""
+        return self._global_draw(batch_size, lambda count: torch.rand(count))
+
     def sample_discriminator_noise(self, batch_size):
-        """float64 two-Gaussian mixture from NumPy's global stream cast to float32 (srgan.py:286-289)."""
         z = self._take_draw('z_d')
-        if z is None:
-            offset = self.settings.mean_offset
-            z = self._global_draw(batch_size, lambda count: torch.tensor(
-                MixtureModel([norm(-offset, 1), norm(offset, 1)]).rvs(size=[count, self.G.input_size]).astype(np.float32)))
-        return as_var(z)
+        return as_var(self.draw_discriminator_noise(batch_size) if z is None else z)
 
     def sample_generator_noise(self, batch_size):
-        """N(0, 1) from torch's CPU stream (srgan.py:301)."""
         z = self._take_draw('z_g')
-        if z is None:
-            z = self._global_draw(batch_size, lambda count: torch.randn(count, self.G.input_size))
-        return as_var(z)
+        return as_var(self.draw_generator_noise(batch_size) if z is None else z)
 
     def sample_interpolation_alpha(self, batch_size):
-        """U[0, 1) per example.  The reference draws on the device (srgan.py:364), which is not reproducible
-        across devices; here it comes from torch's CPU stream and is copied over."""
         alpha = self._take_draw('alpha')
-        if alpha is None:
-            alpha = self._global_draw(batch_size, lambda count: torch.rand(count))
-        return as_var(alpha.reshape(-1))
+        return as_var((self.draw_interpolation_alpha(batch_size) if alpha is None else alpha).reshape(-1))
 
     # ------------------------------------------------------------------------------------------ batch reductions
     def _global_batch(self, local):

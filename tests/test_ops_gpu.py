@@ -415,7 +415,13 @@ def test_fused_batch_norm_convolutions(F):
     gen = torch.Generator().manual_seed(23)
     for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 320, 352, 16, 16, 96, 1),
                                       (1, 512, 512, 8, 8, 40, 1), (2, 32, 32, 16, 16, 8, 3),
-                                      (2, 128, 128, 32, 32, 32, 3), (1, 70, 96, 20, 24, 40, 3)]:
+                                      (2, 128, 128, 32, 32, 32, 3), (1, 70, 96, 20, 24, 40, 3),
+                                      # the ragged planes of the reference's 224 x 224 (28 / 14 / 7 wide), dense and as
+                                      # channel slices whose rows are only 4-byte aligned
+                                      (3, 160, 200, 28, 28, 128, 1), (2, 200, 264, 14, 14, 128, 1), (5, 96, 131, 7, 7, 128, 1),
+                                      (16, 64, 64, 7, 7, 40, 1), (2, 34, 41, 9, 7, 20, 1),
+                                      (2, 128, 128, 14, 14, 32, 3), (3, 128, 128, 7, 7, 32, 3), (2, 40, 57, 7, 9, 33, 3),
+                                      (2, 128, 128, 28, 28, 32, 3)]:
         pad = r // 2
         wide = torch.randn(n, total, h, w, generator=gen)
         x = wide[:, :c]
@@ -443,11 +449,11 @@ def test_fused_batch_norm_convolutions(F):
         _lib.check(lib.srgan_conv2d_bwd_weight_bnrelu(desc, d['wide'].data_ptr(), bn, d['gy'].data_ptr(), gw.data_ptr(), 0,
                                                       stream), 'bwd_weight_bnrelu')
         close(gw, gw_ref, what=f'fused bn conv weight gradient {c}->{k} k{r}')
-    # geometries without a fused form are reported, not guessed: a plane of fewer than 32 pixels has none; a plane that
-    # is not a multiple of 32 pixels has the fused forward (ragged last pixel group) but not the fused weight gradient
+    # geometries without a fused form are reported, not guessed: a plane of fewer than 32 pixels has none; few input
+    # channels have the fused forward but not the fused weight gradient
     tiny = _lib.ConvDesc(2, 32, 5, 5, 16, 1, 1, 1, 1, 0, 0, 5, 5, 0, 0)
     assert lib.srgan_conv2d_bnrelu_supported(tiny, 0) == 0 and lib.srgan_conv2d_bnrelu_supported(tiny, 2) == 0
-    for (n, c, h, w, k) in [(2, 32, 9, 7, 16), (3, 200, 14, 14, 128), (2, 64, 7, 7, 40)]:
+    for (n, c, h, w, k) in [(2, 8, 9, 7, 16), (3, 12, 14, 14, 128), (2, 10, 7, 7, 40)]:
         x = torch.randn(n, c, h, w, generator=gen)
         mean, var = torch.randn(c, generator=gen) * 0.3, torch.rand(c, generator=gen) + 0.5
         gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.3
