@@ -37,6 +37,12 @@ inline int launch_status() {
   return SRGAN_OK;
 }
 
+// Zero-fills are kernels of this library, not hipMemsetAsync: a memset NODE of a captured HIP graph replayed wrongly for
+// sizes that are not a multiple of 16 bytes (ROCm 7.2: 400 bytes left garbage behind), and the runtime's own fill kernel
+// takes ~5 us per launch.  `count` / `width` in floats; rows `pitch` floats apart.
+int zero_floats(float* p, int64_t count, hipStream_t stream);
+int zero_rows(float* p, int64_t pitch, int64_t width, int64_t rows, hipStream_t stream);
+
 // y = fma(x, a, b) is frozen batch-norm: a = inv_std * gamma, b = beta - mean * a.  Every kernel that evaluates the
 // normalisation (forward, fused prologues, the mask recomputed in the backward) goes through this one function so
 // that the sign of y -- the ReLU mask -- is bit-identical everywhere.

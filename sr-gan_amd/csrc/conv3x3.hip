@@ -664,8 +664,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
                 "conv3x3 strided output with a K split needs a pre-zeroed (or accumulated) output");
   if (split > 1) {                       // accumulate: 0 store, 1 add to out, 2 out is already zero
     if (accumulate == 0)
-      SRGAN_HIP(hipMemset2DAsync(out, (size_t)out_bs * sizeof(float), 0, (size_t)CO * H * W * sizeof(float), (size_t)N,
-                                 stream));
+      if (const int status = zero_rows(out, out_bs, (int64_t)CO * H * W, N, stream)) return status;
     p.mode = 2;
   } else {
     p.mode = accumulate == 1 ? 1 : 0;

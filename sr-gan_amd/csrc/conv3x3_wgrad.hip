@@ -305,7 +305,7 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   int walkers = resident / (ci_chunks * co_chunks);
   if (walkers > (p.tiles + depth - 1) / depth) walkers = (p.tiles + depth - 1) / depth;
   if (walkers < 1) walkers = 1;
-  if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)CO * CI * 9 * sizeof(float), stream));
+  if (!accumulate) if (const int status = zero_floats(gw, (int64_t)CO * CI * 9, stream)) return status;
   dim3 grid((unsigned)walkers, (unsigned)ci_chunks, (unsigned)co_chunks);
   const int profile_slot = profile_bracket_begin(stream);
   if (precision == 1) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1>), grid, dim3(WG3_THREADS), 0, stream, p);

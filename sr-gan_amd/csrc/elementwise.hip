@@ -85,6 +85,45 @@ __global__ __launch_bounds__(256) void binary_kernel(const float* a, const float
   if (tail < n) y[tail] = binary<OP>(a[tail], b[tail], p0);
 }
 
+// y[i] = value, without reading y: the destination is usually fresh memory, and 0 * NaN is NaN.
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ y, int64_t n, float value) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = value;
+}
+
+// rows x width floats set to zero, rows `pitch` floats apart (pitch == width: one contiguous run).  16-byte stores
+// where the row start is aligned, single floats at the ragged ends.
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, int64_t pitch, int64_t width, int64_t rows,
+                                                        int blocks_per_row) {
+  const int64_t row = (int64_t)blockIdx.x / blocks_per_row;
+  const int part = (int)((int64_t)blockIdx.x - row * blocks_per_row);
+  if (row >= rows) return;
+  float* base = p + row * pitch;
+  const int64_t head = min(width, (int64_t)((4 - (((uintptr_t)base >> 2) & 3)) & 3));       // floats before 16-byte alignment
+  const int64_t quads = (width - head) >> 2;
+  const int64_t tid = (int64_t)part * 256 + threadIdx.x, stride = (int64_t)blocks_per_row * 256;
+  float4* aligned = reinterpret_cast<float4*>(base + head);
+  for (int64_t i = tid; i < quads; i += stride) aligned[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < head) base[tid] = 0.f;
+  const int64_t tail = head + 4 * quads;
+  if (tid < width - tail) base[tail + tid] = 0.f;
+}
+
+int zero_rows(float* p, int64_t pitch, int64_t width, int64_t rows, hipStream_t stream) {
+  if (width <= 0 || rows <= 0) return SRGAN_OK;
+  if (pitch == width) { width *= rows; rows = 1; pitch = width; }
+  int64_t per_row = (width / 4 + 255) / 256;                       // one float4 per thread, at most 2048 blocks in all
+  if (per_row < 1) per_row = 1;
+  const int64_t cap = rows >= 2048 ? 1 : 2048 / rows;
+  if (per_row > cap) per_row = cap;
+  SRGAN_REQUIRE(rows * per_row < ((int64_t)1 << 31), SRGAN_ERANGE, "zero-fill grid");
+  hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(rows * per_row)), dim3(256), 0, stream, p, pitch, width, rows,
+                     (int)per_row);
+  return launch_status();
+}
+
+int zero_floats(float* p, int64_t count, hipStream_t stream) { return zero_rows(p, count, count, 1, stream); }
+
 template <int OP>
 static int launch_unary(const float* x, float* y, int64_t n, float p0, float p1, hipStream_t s) {
   hipLaunchKernelGGL(unary_kernel<OP>, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, s, x, y, n, p0, p1);
@@ -281,8 +320,9 @@ int srgan_ew_binary(int op, const float* a, const float* b, float* y, int64_t n,
 int srgan_fill(float* y, int64_t n, float value, void* stream) {
   SRGAN_REQUIRE(y && n >= 0, SRGAN_EINVAL, "srgan_fill arguments");
   if (n == 0) return SRGAN_OK;
-  if (value == 0.f) { SRGAN_HIP(hipMemsetAsync(y, 0, (size_t)n * sizeof(float), (hipStream_t)stream)); return SRGAN_OK; }
-  return launch_unary<U_AFFINE>(y, y, n, 0.f, value, (hipStream_t)stream);
+  if (value == 0.f) return zero_floats(y, n, (hipStream_t)stream);
+  hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, y, n, value);
+  return launch_status();
 }
 
 static int chan_affine_launch(const float* x, const float* mean, const float* scale_a, const float* scale_b,

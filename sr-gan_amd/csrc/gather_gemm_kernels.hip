@@ -842,7 +842,7 @@ int gg_run_group(std::vector<GatherGemm>& plans, float* c_base, int64_t c_elems,
   std::vector<GGConfig> configs(plans.size());
   bool any_atomic = false;
   for (size_t i = 0; i < plans.size(); ++i) any_atomic |= gg_prepare(plans[i], force, &configs[i]);
-  if (any_atomic && !accumulate) SRGAN_HIP(hipMemsetAsync(c_base, 0, (size_t)c_elems * sizeof(float), stream));
+  if (any_atomic && !accumulate) if (const int status = zero_floats(c_base, c_elems, stream)) return status;
   for (size_t i = 0; i < plans.size(); ++i) {
     GatherGemm& p = plans[i];
     if (p.split_k > 1 && !p.use_partial) p.mode = GG_ATOMIC;
@@ -921,8 +921,7 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
     GGConfig c;
     const bool atomic = gg_prepare(plans[0], force_kernel, &c);
     if (atomic) {
-      SRGAN_HIP(hipMemset2DAsync(y, (size_t)g.y_bs * sizeof(float), 0, (size_t)g.K * g.OH * g.OW * sizeof(float),
-                                 (size_t)g.N, (hipStream_t)stream));
+      if (const int status = zero_rows(y, g.y_bs, (int64_t)g.K * g.OH * g.OW, g.N, (hipStream_t)stream)) return status;
       plans[0].mode = GG_ATOMIC;
     } else {
       plans[0].mode = GG_STORE;
@@ -956,7 +955,7 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
       g.pw == 1 && g.H == 2 * g.OH && g.W == 2 * g.OW && g.OW >= 8 && g.C >= 8 && !accumulate) {
     // small problems split the input channels over the grid and add with atomics: the output is zeroed once for all classes
     const bool split = conv3x3_splits(g.N, g.K, g.C, g.OH, g.OW, dtype) > 1;
-    if (split) SRGAN_HIP(hipMemsetAsync(gx, 0, (size_t)g.N * g.x_bs * sizeof(float), (hipStream_t)stream));
+    if (split) if (const int status = zero_floats(gx, (int64_t)g.N * g.x_bs, (hipStream_t)stream)) return status;
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) {
         Conv3Placement placement;
@@ -1021,7 +1020,7 @@ int srgan_conv2d_bnrelu_supported(const srgan_conv_desc* desc, int pass) {
   if (pass == 1) {
     // the epilogue's per-workgroup parameter sums must fit the caller's workspace (<= 1/32 of the gradient tensor's bytes)
     if ((size_t)g.N * g.H * g.W * g.C / 8 > WORKSPACE_BYTES) return 0;
-    if (pointwise(g)) return (use_pointwise(g, g.C, 0) && (g.H * g.W) % 4 == 0) ? 1 : 0;   // float4 rows in the epilogue
+    if (pointwise(g)) return use_pointwise(g, g.C, 0) ? 1 : 0;
     return (use_conv3x3(g, g.C, 0) && conv3x3_epilogue_supported(g.N, g.K, g.C, g.H, g.W)) ? 1 : 0;
   }
   if (pass == 2) {

@@ -48,6 +48,7 @@ struct PointwiseParams {
   // workgroup's 128 pixels are written to epi_partial[q][column block][CO] (q = 0 beta, 1 gamma before inv_std).
   const float* epi_x; int64_t epi_x_bs;
   float* epi_partial; int32_t epi_cols;
+  int32_t epi_ragged;   // epi_x / out rows are not whole aligned float4s: the RAGROW variant
 };
 
 // PRO = frozen batch-norm + ReLU fused into the B-operand stream (reference crowd/models.py:338-341: norm1, relu1,
@@ -57,7 +58,9 @@ struct PointwiseParams {
 // non-matrix instructions of a k-pair are amortised over 2*MI MFMAs.
 // EPI = the backward of a frozen batch-norm + ReLU fused into the epilogue of a data gradient (reference
 // crowd/models.py:338-341 backwards: conv1 -> relu1 -> norm1): see PointwiseParams::epi_x.
-template <int MI, int BK, bool PRO, int NI, bool EPI = false>
+// RAGROW (with EPI): planes whose size is not a multiple of 4 pixels or rows that are only 4-byte aligned (7 x 7 at the
+// reference's 224 x 224): the epilogue's float4 row accesses become predicated single floats.
+template <int MI, int BK, bool PRO, int NI, bool EPI = false, bool RAGROW = false>
 __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(const PointwiseParams p) {
   static_assert(!EPI || (!PRO && NI == 1), "the batch-norm backward epilogue pairs with the plain single-group kernel");
   constexpr int BM = MI * 32, KP = BK / 2, LDA = BM + 1;
@@ -241,6 +244,14 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     const int my_start = my_group < total ? (int)(my_group - (int64_t)my_n * p.gpi) * 32 + (q4 & 31) : 0;
     const bool my_live = my_group < total && my_start < p.HW;        // (HW % 4 == 0: a float4 is inside or outside)
     const int my_pix = my_live ? my_start : 0;
+    const int my_count = RAGROW ? (my_live ? min(4, p.HW - my_start) : 0) : 4;     // RAGROW: pixels of the float4 that exist
+    auto load4 = [&](const float* src) {
+      if constexpr (!RAGROW) return *reinterpret_cast<const float4*>(src);
+      float4 v;
+      v.x = my_count > 0 ? src[0] : 0.f; v.y = my_count > 1 ? src[1] : 0.f;
+      v.z = my_count > 2 ? src[2] : 0.f; v.w = my_count > 3 ? src[3] : 0.f;
+      return v;
+    };
     const float* x_lane = p.epi_x + (int64_t)my_n * p.epi_x_bs + my_pix;
     float* out_lane = p.out + (int64_t)my_n * p.out_bs + my_pix;
     const bool sums_wanted = p.epi_partial != nullptr;
@@ -249,8 +260,8 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
         const int o = min(m0 + half + 8 * e, p.CO - 1);
-        xs[e] = *reinterpret_cast<const float4*>(x_lane + (int64_t)o * p.HW);
-        if constexpr (decltype(accumulate)::value) olds[e] = *reinterpret_cast<const float4*>(out_lane + (int64_t)o * p.HW);
+        xs[e] = load4(x_lane + (int64_t)o * p.HW);
+        if constexpr (decltype(accumulate)::value) olds[e] = load4(out_lane + (int64_t)o * p.HW);
       }
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
@@ -260,20 +271,27 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
         const float4 t = *reinterpret_cast<const float4*>(table + row * 4);
         float4 v = *reinterpret_cast<const float4*>(tile + row * LDT + q4);
         const float4 x = xs[e];
-        v.x = (ok && fmaf(x.x, t.x, t.y) > 0.f) ? v.x : 0.f;
-        v.y = (ok && fmaf(x.y, t.x, t.y) > 0.f) ? v.y : 0.f;
-        v.z = (ok && fmaf(x.z, t.x, t.y) > 0.f) ? v.z : 0.f;
-        v.w = (ok && fmaf(x.w, t.x, t.y) > 0.f) ? v.w : 0.f;
+        v.x = (ok && my_count > 0 && fmaf(x.x, t.x, t.y) > 0.f) ? v.x : 0.f;
+        v.y = (ok && my_count > 1 && fmaf(x.y, t.x, t.y) > 0.f) ? v.y : 0.f;
+        v.z = (ok && my_count > 2 && fmaf(x.z, t.x, t.y) > 0.f) ? v.z : 0.f;
+        v.w = (ok && my_count > 3 && fmaf(x.w, t.x, t.y) > 0.f) ? v.w : 0.f;
         if (ok) {
           typedef float v4f __attribute__((ext_vector_type(4)));
           v4f result;
           result.x = v.x * t.x; result.y = v.y * t.x; result.z = v.z * t.x; result.w = v.w * t.x;
-          v4f* dst = reinterpret_cast<v4f*>(out_lane + (int64_t)o * p.HW);
           if constexpr (decltype(accumulate)::value) {
             result.x += olds[e].x; result.y += olds[e].y; result.z += olds[e].z; result.w += olds[e].w;
-            *dst = result;
+          }
+          if constexpr (RAGROW) {
+            float* dst = out_lane + (int64_t)o * p.HW;
+            if (my_count > 0) dst[0] = result.x;
+            if (my_count > 1) dst[1] = result.y;
+            if (my_count > 2) dst[2] = result.z;
+            if (my_count > 3) dst[3] = result.w;
           } else {
-            __builtin_nontemporal_store(result, dst);
+            v4f* dst = reinterpret_cast<v4f*>(out_lane + (int64_t)o * p.HW);
+            if constexpr (decltype(accumulate)::value) *dst = result;
+            else __builtin_nontemporal_store(result, dst);
           }
         }
         if (sums_wanted) {
@@ -463,8 +481,10 @@ bool pointwise_enabled() {
 template <int MI, int BK, int NI>
 static void launch_pointwise(const PointwiseParams& p, dim3 grid, hipStream_t stream) {
   if (p.epi_x) {
-    if constexpr (NI == 1 && MI <= 2)
-      hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, 1, true>), grid, dim3(256), 0, stream, p);
+    if constexpr (NI == 1 && MI <= 2) {
+      if (p.epi_ragged) hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, 1, true, true>), grid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((pointwise_kernel<MI, BK, false, 1, true>), grid, dim3(256), 0, stream, p);
+    }
     return;
   }
   if (p.bn_mean) hipLaunchKernelGGL((pointwise_kernel<MI, BK, true, NI>), grid, dim3(256), 0, stream, p);
@@ -478,7 +498,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   // accumulate: 0 store, 1 add to out, 2 out is already zero (a K split then skips its zero-fill; otherwise a store).
   // plan_only_split: when given, nothing is launched and the number of K splits this call would use is returned there.
   PointwiseParams p;
-  p.epi_x = nullptr; p.epi_x_bs = 0; p.epi_partial = nullptr; p.epi_cols = 0;
+  p.epi_x = nullptr; p.epi_x_bs = 0; p.epi_partial = nullptr; p.epi_cols = 0; p.epi_ragged = 0;
   p.in = in; p.w = w; p.out = out; p.bias = bias;
   p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
@@ -540,7 +560,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   }
   if (split > 1) {
     if (accumulate == 0)
-      SRGAN_HIP(hipMemset2DAsync(out, (size_t)out_bs * sizeof(float), 0, (size_t)CO * HW * sizeof(float), (size_t)N, stream));
+      if (const int status = zero_rows(out, out_bs, (int64_t)CO * HW, N, stream)) return status;
     p.mode = 2;
   } else {
     p.mode = accumulate == 1 ? 1 : 0;
@@ -548,8 +568,7 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
   if (epilogue) {
     SRGAN_REQUIRE(!bn && !bias, SRGAN_EINVAL, "pointwise batch-norm backward epilogue: no prologue, no bias");
     SRGAN_REQUIRE(mi <= 2 && rest == 0, SRGAN_EUNSUPPORTED, "pointwise batch-norm backward epilogue: at most 64-row tiles");
-    SRGAN_REQUIRE(((((uintptr_t)epilogue->x | (uintptr_t)out) & 15) | ((epilogue->x_bs | out_bs | HW) & 3)) == 0, SRGAN_EINVAL,
-                  "pointwise batch-norm backward epilogue: 16-byte aligned x / gx rows");
+    p.epi_ragged = ((((uintptr_t)epilogue->x | (uintptr_t)out) & 15) | ((epilogue->x_bs | out_bs | HW) & 3)) != 0 ? 1 : 0;
     p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
     p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
     p.epi_cols = (int32_t)col_blocks;

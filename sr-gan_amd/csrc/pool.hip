@@ -210,7 +210,7 @@ int srgan_pool_scatter(const float* g, const int32_t* argmax, float* out, int32_
   SRGAN_REQUIRE(g && argmax && out && planes > 0 && in_plane > 0 && out_plane > 0, SRGAN_EINVAL,
                 "srgan_pool_scatter arguments");
   hipStream_t s = (hipStream_t)stream;
-  SRGAN_HIP(hipMemsetAsync(out, 0, (size_t)planes * in_plane * sizeof(float), s));
+  if (const int status = zero_floats(out, (int64_t)planes * in_plane, s)) return status;
   const int64_t n = (int64_t)planes * out_plane;
   hipLaunchKernelGGL(pool_scatter_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, g, argmax, out, in_plane,
                      out_plane, n);

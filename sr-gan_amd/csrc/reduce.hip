@@ -309,7 +309,7 @@ int srgan_chan_reduce(const float* a, const float* b, const float* mean, const f
   }
   const int segs = (int)((HW + RED_SEG - 1) / RED_SEG);
   SRGAN_REQUIRE((int64_t)N * segs <= 65535, SRGAN_ERANGE, "srgan_chan_reduce grid");
-  if (!accumulate) SRGAN_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s));
+  if (!accumulate) if (const int status = zero_floats(out, C, s)) return status;
   hipLaunchKernelGGL(chan_reduce_rows_kernel, dim3(C, N * segs), dim3(256), 0, s, a, b, mean, scale, out, C, HW,
                      segs);
   return launch_status();
@@ -374,7 +374,7 @@ int srgan_crowd_map_l1_fwd(const float* maps, const float* target, float* rows, 
   SRGAN_REQUIRE(maps && target && rows && B > 0 && Cm > 0 && HW > 0, SRGAN_EINVAL, "srgan_crowd_map_l1_fwd arguments");
   hipStream_t s = (hipStream_t)stream;
   const int segs = (int)((HW + RED_SEG - 1) / RED_SEG);
-  SRGAN_HIP(hipMemsetAsync(rows, 0, (size_t)B * sizeof(float), s));
+  if (const int status = zero_floats(rows, B, s)) return status;
   hipLaunchKernelGGL(crowd_map_l1_kernel, dim3(B, segs), dim3(256), 0, s, maps, target, rows, Cm, HW, segs);
   return launch_status();
 }

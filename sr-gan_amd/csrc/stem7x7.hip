@@ -403,7 +403,7 @@ int stem7x7_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   StemParams p;
   stem_fill(p, x, x_bs, nullptr, const_cast<float*>(gy), gy_bs, gw, N, H, W, K, OH, OW);
   SRGAN_REQUIRE((int64_t)N * p.tiles_y * p.tiles_x < ((int64_t)1 << 31), SRGAN_ERANGE, "stem grid");
-  if (!accumulate) SRGAN_HIP(hipMemsetAsync(gw, 0, (size_t)K * 147 * sizeof(float), stream));
+  if (!accumulate) if (const int status = zero_floats(gw, (int64_t)K * 147, stream)) return status;
   static const int resident = getenv("SRGAN_STEM_WGRAD_WGS") ? atoi(getenv("SRGAN_STEM_WGRAD_WGS")) : 512;
   const int grid = p.tiles < resident ? p.tiles : resident;
   const int slot = profile_bracket_begin(stream);

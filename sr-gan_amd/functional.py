@@ -5,6 +5,7 @@ gradient penalty, reference srgan.py:360-375) come for free.  Tensors are contig
 torch is the allocator only -- no torch arithmetic is used on this path.
 """
 import math
+import os
 
 import torch
 
@@ -53,7 +54,13 @@ def _ptr(x):
     return (x.data if isinstance(x, Var) else x).data_ptr()
 
 
+POISON = bool(os.environ.get('SRGAN_POISON_EMPTY'))      # debugging aid: every fresh tensor starts as NaN, so a kernel
+                                                        # that reads memory nobody wrote shows up in the results
+
+
 def _empty(shape, like):
+    if POISON:
+        return torch.full(tuple(shape), float('nan'), dtype=torch.float32, device=like.device)
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 

@@ -63,6 +63,8 @@ def _desc(n, c, h, w, k, r, s, stride, pad, x_bs=0, y_bs=0):
 
 
 def _empty(shape, device):
+    if F.POISON:
+        return torch.full(tuple(shape), float('nan'), dtype=torch.float32, device=device)
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 

@@ -483,7 +483,12 @@ def test_fused_batch_norm_backward_in_the_data_gradient(F):
     for (n, c, total, h, w, k, r) in [(2, 48, 80, 16, 16, 32, 1), (3, 160, 160, 8, 32, 128, 1), (2, 192, 224, 32, 32, 128, 1),
                                       (1, 512, 512, 8, 8, 40, 1), (4, 96, 256, 64, 64, 128, 1), (2, 300, 300, 16, 16, 128, 1),
                                       (4, 128, 128, 32, 32, 32, 3), (16, 128, 128, 16, 16, 32, 3), (2, 128, 128, 64, 64, 32, 3),
-                                      (3, 40, 40, 20, 24, 16, 3), (16, 128, 128, 64, 64, 32, 3)]:
+                                      (3, 40, 40, 20, 24, 16, 3), (16, 128, 128, 64, 64, 32, 3),
+                                      # the planes of the reference's 224 x 224: 28 / 14 wide (whole float4s, ragged
+                                      # 32-pixel groups) and 7 x 7 (49 pixels: rows only 4-byte aligned)
+                                      (3, 160, 200, 28, 28, 128, 1), (2, 200, 264, 14, 14, 128, 1), (5, 96, 131, 7, 7, 128, 1),
+                                      (16, 64, 64, 7, 7, 128, 1), (2, 34, 41, 9, 7, 20, 1),
+                                      (2, 128, 128, 14, 14, 32, 3), (3, 128, 128, 7, 7, 32, 3)]:
         pad = r // 2
         wide = torch.randn(n, total, h, w, generator=gen)
         x = wide[:, :c].clone().requires_grad_(True)
@@ -524,8 +529,8 @@ def test_fused_batch_norm_backward_in_the_data_gradient(F):
                                                     d['wide'].data_ptr(), gx_wide.data_ptr(), None, None, 0, stream),
                    'bwd_data_bnrelu')
         close(gx_wide[:, :c], gx_ref, what=f'fused bn backward {k}->{c} k{r} (no parameter gradients)')
-    odd = _lib.ConvDesc(2, 32, 9, 7, 16, 1, 1, 1, 1, 0, 0, 9, 7, 0, 0)
-    assert lib.srgan_conv2d_bnrelu_supported(odd, 1) == 0
+    tiny = _lib.ConvDesc(2, 32, 5, 5, 16, 1, 1, 1, 1, 0, 0, 5, 5, 0, 0)       # fewer than 32 pixels: no fused form
+    assert lib.srgan_conv2d_bnrelu_supported(tiny, 1) == 0
 
 
 @gpu
