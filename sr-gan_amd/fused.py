@@ -218,7 +218,9 @@ def dense_block(x, layers):
             plan = _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, device)
             if plan is not None:
                 scratch = _empty((plan['total'],), device)
-        overlap = WGRAD_STREAM and want_params and prologue and not recorded
+        # (not while a HIP graph is being captured: a captured fork / join per layer replayed slower and, together with the
+        # DNN side stream, crashed the runtime)
+        overlap = WGRAD_STREAM and want_params and prologue and not recorded and not torch.cuda.is_current_stream_capturing()
         if overlap:
             main, side = torch.cuda.current_stream(device), _side_stream(device)
             wstream = _lib.stream_handle(side)
