@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from .tape import Var, Node, grad_enabled, no_grad
+from .tape import Var, Node, grad_enabled, no_grad, accumulates_into
 
 # op codes of srgan_ew_unary / srgan_ew_binary (include/srgan_hip.h)
 U_COPY, U_NEG, U_ABS, U_SIGN, U_SQRT, U_EXP, U_LOG, U_LOG1P, U_SQUARE, U_RECIP, U_TANH, U_RELU, U_STEP, U_AFFINE, \
@@ -336,13 +336,17 @@ def batch_norm_eval(x, mean, inv_std, gamma, beta, relu=False):
         gx = ggamma = gbeta = None
         want_params = needs[1] or needs[2]
         gx_data = _empty(x.shape, x.data) if needs[0] else None
-        both = _zeros((2, c), x.data) if want_params else None
+        # both parameter sums are ADDED by the kernel: straight into the gradient arena when the sweep accumulates there
+        direct = needs[1] and needs[2] and accumulates_into(gamma) and accumulates_into(beta)
+        both = _zeros((2, c), x.data) if want_params and not direct else None
+        into_gamma = gamma.grad_buffer.data_ptr() if direct else (both[0].data_ptr() if want_params else None)
+        into_beta = beta.grad_buffer.data_ptr() if direct else (both[1].data_ptr() if want_params else None)
         _call('srgan_bn_act_bwd', _ptr(g), _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma), _ptr(beta),
-              1 if relu else 0, gx_data.data_ptr() if needs[0] else None, both[0].data_ptr() if want_params else None,
-              both[1].data_ptr() if want_params else None, n, c, hw, 0, 0, 0, 0, 0, _stream())
+              1 if relu else 0, gx_data.data_ptr() if needs[0] else None, into_gamma, into_beta, n, c, hw, 0, 0, 0, 0, 0,
+              _stream())
         if needs[0]:
             gx = Var(gx_data)
-        if want_params:
+        if want_params and not direct:
             ggamma, gbeta = Var(both[0]), Var(both[1])
         return gx, ggamma, gbeta
     out.node.backward = backward
@@ -472,10 +476,24 @@ def conv2d(x, weight, bias=None, stride=1, padding=0):
 
     def backward(g, needs):
         gx = conv2d_backward_data(g, weight, x_shape, stride, padding) if needs[0] else None
-        gw = conv2d_backward_weight(x, g, w_shape, stride, padding) if needs[1] else None
-        gb = chan_reduce(g) if needs[2] else None
+        gw = gb = None
+        if needs[1] and accumulates_into(weight):          # straight into the gradient arena (kernel accumulate mode)
+            _call('srgan_conv2d_bwd_weight', _conv_desc(x_shape, w_shape, stride, padding, g.shape), _ptr(x), _ptr(g),
+                  weight.grad_buffer.data_ptr(), 1, FORCE_KERNEL, _stream())
+        elif needs[1]:
+            gw = conv2d_backward_weight(x, g, w_shape, stride, padding)
+        if needs[2] and accumulates_into(bias):
+            _bias_gradient_into(bias.grad_buffer, g)
+        elif needs[2]:
+            gb = chan_reduce(g)
         return gx, gw, gb
     return _out(data, (x, weight, bias), backward, 'conv2d')
+
+
+def _bias_gradient_into(buffer, g):
+    """buffer[c] += sum over batch and pixels of g[n, c, ...] (a bias gradient added straight into the arena)."""
+    n, c, hw = _dims_nchw(g.shape)
+    _call('srgan_chan_reduce', _ptr(g), None, None, None, buffer.data_ptr(), n, c, hw, 1, _stream())
 
 
 def conv2d_backward_data(gy, weight, x_shape, stride, padding, bias=None):
@@ -489,8 +507,16 @@ def conv2d_backward_data(gy, weight, x_shape, stride, padding, bias=None):
 
     def backward(g, needs):
         ggy = conv2d(g, weight, None, stride, padding) if needs[0] else None
-        gw = conv2d_backward_weight(g, gy, w_shape, stride, padding) if needs[1] else None
-        gb = chan_reduce(g) if needs[2] else None
+        gw = gb = None
+        if needs[1] and accumulates_into(weight):
+            _call('srgan_conv2d_bwd_weight', _conv_desc(g.shape, w_shape, stride, padding, gy.shape), _ptr(g), _ptr(gy),
+                  weight.grad_buffer.data_ptr(), 1, FORCE_KERNEL, _stream())
+        elif needs[1]:
+            gw = conv2d_backward_weight(g, gy, w_shape, stride, padding)
+        if needs[2] and accumulates_into(bias):
+            _bias_gradient_into(bias.grad_buffer, g)
+        elif needs[2]:
+            gb = chan_reduce(g)
         return ggy, gw, gb
     return _out(data, (gy, weight, bias), backward, 'conv2d_backward_data')
 
@@ -537,7 +563,11 @@ def mm(a, b, transpose_a=False, transpose_b=False, bias=None, bias_on_columns=Tr
             ga = mm(g, b, False, not transpose_b) if not transpose_a else mm(b, g, transpose_b, True)
         if needs[1]:
             gb = mm(a, g, not transpose_a, False) if not transpose_b else mm(g, a, True, transpose_a)
-        if needs[2]:
+        if needs[2] and accumulates_into(bias):
+            dims = (m, n, 1) if bias_on_columns else (1, m, n)
+            _call('srgan_chan_reduce', _ptr(g), None, None, None, bias.grad_buffer.data_ptr(), dims[0], dims[1], dims[2], 1,
+                  _stream())
+        elif needs[2]:
             gbias = chan_reduce(g, dims=(m, n, 1)) if bias_on_columns else chan_reduce(g, dims=(1, m, n))
         return ga, gb, gbias
     return _out(data, (a, b, bias), backward, 'mm')

@@ -149,6 +149,16 @@ def _frontiers(order, flat):
     return frontier
 
 
+_accumulating = False     # inside a plain backward sweep (no ``inputs``, not recorded)
+
+
+def accumulates_into(var):
+    """True while a plain ``backward`` sweep runs and ``var`` is a parameter leaf: the operation's backward may then add
+    its gradient straight into ``var.grad_buffer`` (the arena) with the kernel's own accumulate mode and return None for
+    it, instead of materialising a temporary that the sweep adds afterwards (one launch and one tensor per parameter)."""
+    return _accumulating and var is not None and var.node is None and var.grad_buffer is not None and var.requires_grad
+
+
 def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None, grad_ready=None):
     """Reverse sweep from ``root``.
 
@@ -178,40 +188,45 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
     results = {}
     wanted = {id(v): v for v in inputs} if inputs is not None else {}
     frontier = _frontiers(order, grad_ready.flat) if grad_ready is not None else None
-    with context:
-        if id(root) in wanted:
-            results[id(root)] = grad
-        for position, var in enumerate(order):
-            if frontier is not None:
-                grad_ready.ready_from(frontier[position])
-            g = grads.pop(id(var), None)
-            if g is None:
-                continue
-            node = var.node
-            needs = tuple(required and (relevant is None or id(p) in relevant)
-                          for p, required in zip(node.inputs, node.input_requires))
-            input_grads = node.backward(g, needs)
-            for parent, need, pg in zip(node.inputs, needs, input_grads):
-                if not need or pg is None:
+    global _accumulating
+    previous, _accumulating = _accumulating, (inputs is None and not create_graph)
+    try:
+        with context:
+            if id(root) in wanted:
+                results[id(root)] = grad
+            for position, var in enumerate(order):
+                if frontier is not None:
+                    grad_ready.ready_from(frontier[position])
+                g = grads.pop(id(var), None)
+                if g is None:
                     continue
-                if pg.shape != parent.shape:
-                    raise RuntimeError(f'{node.name}: gradient shape {pg.shape} != input shape {parent.shape}')
-                key = id(parent)
-                if parent.node is None:                      # leaf
-                    if inputs is not None:
+                node = var.node
+                needs = tuple(required and (relevant is None or id(p) in relevant)
+                              for p, required in zip(node.inputs, node.input_requires))
+                input_grads = node.backward(g, needs)
+                for parent, need, pg in zip(node.inputs, needs, input_grads):
+                    if not need or pg is None:
+                        continue
+                    if pg.shape != parent.shape:
+                        raise RuntimeError(f'{node.name}: gradient shape {pg.shape} != input shape {parent.shape}')
+                    key = id(parent)
+                    if parent.node is None:                      # leaf
+                        if inputs is not None:
+                            if key in wanted:
+                                results[key] = pg if key not in results else F.add(results[key], pg)
+                        elif parent.grad_buffer is not None:
+                            F.accumulate_(parent.grad_buffer, pg)
+                        else:
+                            parent.grad = pg if parent.grad is None else F.add(parent.grad, pg)
+                    else:
                         if key in wanted:
                             results[key] = pg if key not in results else F.add(results[key], pg)
-                    elif parent.grad_buffer is not None:
-                        F.accumulate_(parent.grad_buffer, pg)
-                    else:
-                        parent.grad = pg if parent.grad is None else F.add(parent.grad, pg)
-                else:
-                    if key in wanted:
-                        results[key] = pg if key not in results else F.add(results[key], pg)
-                    grads[key] = pg if key not in grads else F.add(grads[key], pg)
-            if not retain_graph:
-                node.backward = _released
-                node.inputs = ()
+                        grads[key] = pg if key not in grads else F.add(grads[key], pg)
+                if not retain_graph:
+                    node.backward = _released
+                    node.inputs = ()
+    finally:
+        _accumulating = previous
     if frontier is not None:
         grad_ready.ready_from(0)
     if inputs is not None:
