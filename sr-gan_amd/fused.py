@@ -33,7 +33,7 @@ import torch
 
 from . import _lib
 from . import functional as F
-from .tape import Var, Node, grad_enabled
+from .tape import Var, Node, grad_enabled, incoming_gradient_is_exclusive
 from .nn import parameter_var
 
 
@@ -209,8 +209,11 @@ def dense_block(x, layers):
                                       'gradient only; set srgan_amd.fused.ENABLED = False for parameter gradients of '
                                       'a recorded backward')
         stream = F._stream()
-        gbuf = _empty(g.shape, device)            # private copy: the incoming gradient may be shared
-        F._call('srgan_ew_unary', F.U_COPY, g.data.data_ptr(), gbuf.data_ptr(), gbuf.numel(), 0.0, 0.0, stream)
+        if not recorded and incoming_gradient_is_exclusive() and g.data.is_contiguous():
+            gbuf = g.data                         # nobody else reads it: the layers accumulate into it in place
+        else:
+            gbuf = _empty(g.shape, device)        # private copy: the incoming gradient may be shared
+            F._call('srgan_ew_unary', F.U_COPY, g.data.data_ptr(), gbuf.data_ptr(), gbuf.numel(), 0.0, 0.0, stream)
         kept = [None] * len(layers)               # per layer, for the double backward: (gradient at conv1's output, b1)
         # the batch-norm parameter sums of every fused epilogue land in one scratch tensor, reduced by ONE launch at the end
         plan = scratch = None

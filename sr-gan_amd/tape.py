@@ -150,6 +150,13 @@ def _frontiers(order, flat):
 
 
 _accumulating = False     # inside a plain backward sweep (no ``inputs``, not recorded)
+_exclusive = False        # the gradient handed to the node being swept is referenced by nobody else
+
+
+def incoming_gradient_is_exclusive():
+    """True when the ``g`` of the ``node.backward(g, needs)`` call in progress was produced for this node alone (one
+    producer slot or a fresh sum, in a sweep that does not record): the node may then overwrite it in place."""
+    return _exclusive
 
 
 def accumulates_into(var):
@@ -184,11 +191,12 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
     relevant = _relevant_set(root, inputs) if inputs is not None else None
     order = _topological_order(root, relevant)
     grads = {id(root): grad}
+    shared = set()            # ids of gradient vars that some other consumer may still read
     context = enable_grad() if create_graph else no_grad()
     results = {}
     wanted = {id(v): v for v in inputs} if inputs is not None else {}
     frontier = _frontiers(order, grad_ready.flat) if grad_ready is not None else None
-    global _accumulating
+    global _accumulating, _exclusive
     previous, _accumulating = _accumulating, (inputs is None and not create_graph)
     try:
         with context:
@@ -203,7 +211,15 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
                 node = var.node
                 needs = tuple(required and (relevant is None or id(p) in relevant)
                               for p, required in zip(node.inputs, node.input_requires))
-                input_grads = node.backward(g, needs)
+                _exclusive = not create_graph and not retain_graph and id(g) not in shared and g is not grad
+                try:
+                    input_grads = node.backward(g, needs)
+                finally:
+                    _exclusive = False
+                handed_out = [id(pg) for pg in input_grads if pg is not None]
+                for pg in input_grads:      # one var handed to several inputs (or passed through): not exclusive
+                    if pg is not None and (handed_out.count(id(pg)) > 1 or pg is g or id(g) in shared and pg.data.data_ptr() == g.data.data_ptr()):
+                        shared.add(id(pg))
                 for parent, need, pg in zip(node.inputs, needs, input_grads):
                     if not need or pg is None:
                         continue
@@ -221,6 +237,7 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
                     else:
                         if key in wanted:
                             results[key] = pg if key not in results else F.add(results[key], pg)
+                            shared.add(id(pg))                 # the caller gets it back
                         grads[key] = pg if key not in grads else F.add(grads[key], pg)
                 if not retain_graph:
                     node.backward = _released

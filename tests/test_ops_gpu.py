@@ -574,6 +574,22 @@ def test_fused_dense_block_matches_primitive_path(F):
     backward(y, grad=F.leaf(dev(cotangent)))
     close(x.grad, results[False][1], 1e-4, 'input gradient with frozen parameters')
     assert float(arena.grad.abs().sum()) == 0.0
+    # one gradient tensor fanned out to two blocks (add's backward hands the SAME var to both inputs) and a gradient that
+    # arrives exclusively through another op: the fused backward may accumulate in place only in the second case
+    shared = {}
+    for enabled in (False, True):
+        fused.ENABLED = enabled
+        try:
+            arena.zero_grad()
+            x1, x2 = F.leaf(dev(x_host), requires_grad=True), F.leaf(dev(x_host * 0.5 + 0.1), requires_grad=True)
+            total = F.add(block(x1), F.scale(block(x2), 1.5))            # scale's backward makes a fresh gradient
+            root = F.sum_all(F.mul(F.add(total, block(x2)), F.leaf(dev(cotangent))))     # a third call shares add's g
+            backward(root)
+            shared[enabled] = (x1.grad.cpu(), x2.grad.cpu(), arena.grad.detach().cpu().clone())
+        finally:
+            fused.ENABLED = True
+    for i, what in enumerate(('first input gradient', 'second input gradient', 'parameter gradients')):
+        close(shared[True][i], shared[False][i], 1e-4, 'shared / exclusive incoming gradients: ' + what)
     # second order (gradient penalty): recorded input gradient, then the parameter gradients of a function of it --
     # the fused node's linearised-forward double backward against the primitive ops (two channel widths so that the
     # block's downstream gradient itself depends on a parameter-carrying recorded op)
