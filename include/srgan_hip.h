@@ -156,6 +156,20 @@ int srgan_conv2d_bwd_data_bnrelu_partials(const srgan_conv_desc* desc, const flo
 int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int32_t count, int32_t max_channels, int32_t max_tiles,
                                     const float* scratch, void* stream);
 
+/* Grouped form of srgan_conv2d_bwd_weight_bnrelu: MANY independent weight gradients (all the 1x1, or all the 3x3,
+ * convolutions of a dense block's backward: reference crowd/models.py:335-353 through loss.backward()) in ONE launch.
+ * srgan_wgrad_group_plan fills one 128-byte table slot per problem on the host -- x / gy are ELEMENT OFFSETS from two base
+ * pointers given at launch time, gw and the batch-norm vectors are absolute, the gradient is ACCUMULATED into gw -- and
+ * returns the grid extent the problem needs and whether it needs the ragged kernel variant; the caller uploads the table
+ * once (it does not change between steps when the offsets are relative to per-step buffers) and launches with the maxima
+ * over the group.  All problems of a group share the plane size.  sum_co_ci_taps / pixels / operand_elements only feed
+ * the profile (logical FLOPs = 2 * sum_co_ci_taps * pixels; elements of x and gy read once). */
+int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
+                           void* job, int32_t* grid_x, int32_t* grid_y, int32_t* ragged);
+int srgan_wgrad_group_run(const void* jobs, int32_t count, int32_t kernel_size, int32_t grid_x, int32_t grid_y, int32_t ragged,
+                          const float* x_base, const float* gy_base, int64_t sum_co_ci_taps, int64_t pixels,
+                          int64_t operand_elements, void* stream);
+
 /* ---- strided GEMM  C[i*sci + j*scj] (=,+=) sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] + bias ----------------
  * C must be a dense M x N matrix (row- or column-major).  bias is indexed by row i, or by column j when
  * bias_on_columns != 0.  Replaces torch.nn.Linear forward/backward at reference coefficient/models.py:17-27,

@@ -14,6 +14,7 @@
 // the loaded value before the MFMA loop would make the compiler wait for the loads there).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace srgan {
@@ -41,8 +42,17 @@ constexpr int WG3_THREADS = 192;
 // the 8 pixels of its half; the three kernel columns share one window of 10 patch values.
 // RAGGED: widths that are not a multiple of 4 or rows that are only 4-byte aligned (the 14- and 7-wide planes at the
 // reference's 224 x 224): the staging loads are single floats with per-element validity instead of aligned float4.
+template <int TH, int PREC, bool RAGGED>
+struct Wgrad3Lds {
+  static constexpr int PW = WG3_TW + 2, PH = TH + 2, PATCH = PH * PW, PS = PATCH | 1, GT = TH * WG3_TW, GS = GT | 1;
+  static constexpr int OUT_ROW = WG3_CI * 9 + 1, OUT_HALF = WG3_CO / 2;
+  static constexpr int SMEM = WG3_CI * PS + WG3_CO * GS > OUT_HALF * OUT_ROW ? WG3_CI * PS + WG3_CO * GS : OUT_HALF * OUT_ROW;
+};
+
+// `first_tile` / `tile_stride`: this workgroup's walk over the pixel tiles; `ci_chunk` / `co_chunk`: its channel blocks.
 template <int TH, int PREC = 0, bool RAGGED = false>
-__global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgrad3Params p) {
+__device__ __forceinline__ void conv3x3_wgrad_body(const Wgrad3Params& p, const int first_tile, const int tile_stride,
+                                                   const int ci_chunk, const int co_chunk, float* smem) {
   constexpr int PW = WG3_TW + 2, PH = TH + 2;
   constexpr int PATCH = PH * PW;            // halo patch of one channel
   constexpr int PS = PATCH | 1;             // odd plane stride: the 32 lanes of an operand read hit 32 banks
@@ -51,14 +61,12 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
   static_assert(PH * 32 <= WG3_THREADS, "one (patch row, channel) pair per thread");
   constexpr int OUT_ROW = WG3_CI * 9 + 1;   // epilogue transpose buffer: [co][ci*9 + tap], odd row stride; the 32 output
   constexpr int OUT_HALF = WG3_CO / 2;      // rows go through it in two halves so that it fits under the staging tiles
-  constexpr int SMEM = WG3_CI * PS + WG3_CO * GS > OUT_HALF * OUT_ROW ? WG3_CI * PS + WG3_CO * GS : OUT_HALF * OUT_ROW;
-  __shared__ float smem[SMEM];
   float* xs = smem;
   float* gs = smem + WG3_CI * PS;
 
   const int tid = (int)threadIdx.x, lane = tid & 63, kh = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int ci0 = (int)blockIdx.y * WG3_CI, co0 = (int)blockIdx.z * WG3_CO;
+  const int ci0 = ci_chunk * WG3_CI, co0 = co_chunk * WG3_CO;
   const int HW = p.H * p.W;
 
   f32x16 acc[3];
@@ -152,9 +160,9 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
     }
   };
 
-  int tile = (int)blockIdx.x;
+  int tile = first_tile;
   if (tile < p.tiles) fetch(tile);
-  for (; tile < p.tiles; tile += (int)gridDim.x) {
+  for (; tile < p.tiles; tile += tile_stride) {
     __syncthreads();                        // the previous tile's MFMA reads are done
     if constexpr (RAGGED) {
       if (x_owner) {
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
     }
     }
     __syncthreads();
-    const int next = tile + (int)gridDim.x;
+    const int next = tile + tile_stride;
     if (next < p.tiles) fetch(next);
 
     if constexpr (PREC != 0) {
@@ -265,6 +273,37 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgr
   }
 }
 
+template <int TH, int PREC = 0, bool RAGGED = false>
+__global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgrad3Params p) {
+  __shared__ float smem[Wgrad3Lds<TH, PREC, RAGGED>::SMEM];
+  conv3x3_wgrad_body<TH, PREC, RAGGED>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+
+// GROUPED: blockIdx.z selects one of many independent problems (all the growth convolutions of a dense block's backward)
+// from a device-resident table; x / gy are offsets from two base pointers.  blockIdx.y = ci chunk + ci_chunks * co chunk.
+struct Wgrad3Job {
+  int64_t x_off, gy_off, x_bs, gy_bs;
+  float* gw;
+  const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
+  int32_t N, CI, CO, H, W, tiles_x, tiles_y, tiles, walkers, ci_chunks, co_chunks, pad[3];
+};
+static_assert(sizeof(Wgrad3Job) == 128, "one 128-byte table slot per job");
+
+template <bool RAGGED>
+__global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_grouped_kernel(const Wgrad3Job* __restrict__ jobs,
+                                                                               const float* x_base, const float* gy_base) {
+  __shared__ float smem[Wgrad3Lds<4, 0, RAGGED>::SMEM];
+  const Wgrad3Job job = jobs[blockIdx.z];
+  if ((int)blockIdx.x >= job.walkers || (int)blockIdx.y >= job.ci_chunks * job.co_chunks) return;   // (workgroup-uniform)
+  Wgrad3Params p;
+  p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off; p.gw = job.gw; p.x_bs = job.x_bs; p.gy_bs = job.gy_bs;
+  p.N = job.N; p.CI = job.CI; p.CO = job.CO; p.H = job.H; p.W = job.W;
+  p.tiles_x = job.tiles_x; p.tiles_y = job.tiles_y; p.tiles = job.tiles; p.debug = 0;
+  p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
+  const int co_chunk = (int)blockIdx.y / job.ci_chunks;
+  conv3x3_wgrad_body<4, 0, RAGGED>(p, (int)blockIdx.x, job.walkers, (int)blockIdx.y - co_chunk * job.ci_chunks, co_chunk, smem);
+}
+
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
                         int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
@@ -272,6 +311,19 @@ int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int6
 bool conv3x3_wgrad_enabled() {
   static const bool disabled = getenv("SRGAN_NO_WGRAD3") != nullptr;
   return !disabled;
+}
+
+// Walkers over the pixel tiles: five resident 3-wave workgroups per CU (120 VGPRs, 22 KB of LDS) over the whole grid, and
+// at least `depth` tiles per walker so that the atomic pass (32 x 288 floats per workgroup) is amortised.
+static int conv3x3_wgrad_walkers(int tiles, int ci_chunks, int co_chunks) {
+  static const int resident = getenv("SRGAN_WGRAD3_WGS") ? atoi(getenv("SRGAN_WGRAD3_WGS")) : 1280;
+  static const int depth_override = getenv("SRGAN_WGRAD3_DEPTH") ? atoi(getenv("SRGAN_WGRAD3_DEPTH")) : 0;
+  // measured on 128 -> 32 channels, batch 16: 64x64 images best at 8 tiles per walker, 32x32 at 4, 16x16 at 1 (batch
+  // 48 at 16x16 = 192 tiles: 48 us at depth 1 -- 768 workgroups x 9216 atomics -- so 4 from 128 tiles up)
+  const int depth = depth_override > 0 ? depth_override : (tiles >= 1024 ? 8 : (tiles >= 128 ? 4 : 1));
+  int walkers = resident / (ci_chunks * co_chunks);
+  if (walkers > (tiles + depth - 1) / depth) walkers = (tiles + depth - 1) / depth;
+  return walkers < 1 ? 1 : walkers;
 }
 
 // gw (=,+=) the weight gradient; x / gy may be channel-slice views (batch strides in elements).
@@ -295,16 +347,7 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   SRGAN_REQUIRE(!(ragged && precision), SRGAN_EUNSUPPORTED, "conv3x3 wgrad: mixed precision needs 16-byte rows");
   SRGAN_REQUIRE(tiles < (int64_t)1 << 31 && ci_chunks <= 65535 && co_chunks <= 65535, SRGAN_ERANGE, "conv3x3 wgrad grid");
   p.tiles = (int)tiles;
-  // Walkers: five resident 3-wave workgroups per CU (120 VGPRs, 22 KB of LDS) over the whole grid, and at least `depth` tiles per
-  // walker so that the atomic pass (32 x 288 floats per workgroup) is amortised.
-  static const int resident = getenv("SRGAN_WGRAD3_WGS") ? atoi(getenv("SRGAN_WGRAD3_WGS")) : 1280;
-  static const int depth_override = getenv("SRGAN_WGRAD3_DEPTH") ? atoi(getenv("SRGAN_WGRAD3_DEPTH")) : 0;
-  // measured on 128 -> 32 channels, batch 16: 64x64 images best at 8 tiles per walker, 32x32 at 4, 16x16 at 1 (batch
-  // 48 at 16x16 = 192 tiles: 48 us at depth 1 -- 768 workgroups x 9216 atomics -- so 4 from 128 tiles up)
-  const int depth = depth_override > 0 ? depth_override : (p.tiles >= 1024 ? 8 : (p.tiles >= 128 ? 4 : 1));
-  int walkers = resident / (ci_chunks * co_chunks);
-  if (walkers > (p.tiles + depth - 1) / depth) walkers = (p.tiles + depth - 1) / depth;
-  if (walkers < 1) walkers = 1;
+  const int walkers = conv3x3_wgrad_walkers(p.tiles, ci_chunks, co_chunks);
   if (!accumulate) if (const int status = zero_floats(gw, (int64_t)CO * CI * 9, stream)) return status;
   dim3 grid((unsigned)walkers, (unsigned)ci_chunks, (unsigned)co_chunks);
   const int profile_slot = profile_bracket_begin(stream);
@@ -315,6 +358,45 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(WG3_THREADS), 0, stream, p);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers, 0, 0, 0, precision);
+  return status;
+}
+
+// One entry of a grouped launch's table (see pointwise_wgrad_group_plan); the weight gradient is ACCUMULATED into gw.
+int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+                             int32_t CO, int32_t H, int32_t W, const float* const* bn, void* job_out, int32_t* grid_x,
+                             int32_t* grid_y, int32_t* ragged) {
+  Wgrad3Job job;
+  job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs; job.gw = gw;
+  job.bn_mean = bn[0]; job.bn_inv = bn[1]; job.bn_gamma = bn[2]; job.bn_beta = bn[3];
+  job.N = N; job.CI = CI; job.CO = CO; job.H = H; job.W = W;
+  job.ci_chunks = (CI + WG3_CI - 1) / WG3_CI; job.co_chunks = (CO + WG3_CO - 1) / WG3_CO;
+  job.tiles_x = (W + WG3_TW - 1) / WG3_TW; job.tiles_y = (H + 3) / 4;
+  const int64_t tiles = (int64_t)N * job.tiles_y * job.tiles_x;
+  SRGAN_REQUIRE(tiles < (int64_t)1 << 31 && (int64_t)job.ci_chunks * job.co_chunks <= 65535, SRGAN_ERANGE, "conv3x3 wgrad grid");
+  job.tiles = (int)tiles;
+  job.walkers = conv3x3_wgrad_walkers(job.tiles, job.ci_chunks, job.co_chunks);
+  job.pad[0] = job.pad[1] = job.pad[2] = 0;
+  static_assert(sizeof(Wgrad3Job) <= 128, "job slot");
+  memset(job_out, 0, 128);
+  memcpy(job_out, &job, sizeof(job));
+  *grid_x = job.walkers; *grid_y = job.ci_chunks * job.co_chunks;
+  *ragged = (W % 4 != 0 || x_bs % 4 != 0 || gy_bs % 4 != 0 || x_off % 4 != 0 || gy_off % 4 != 0) ? 1 : 0;
+  return SRGAN_OK;
+}
+
+int conv3x3_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
+                            const float* x_base, const float* gy_base, int64_t flops_mn, int64_t pixels, int64_t elements,
+                            hipStream_t stream) {
+  SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped conv3x3 wgrad grid");
+  const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
+  dim3 grid((unsigned)grid_x, (unsigned)grid_y, (unsigned)count);
+  const int profile_slot = profile_bracket_begin(stream);
+  if (rag) hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<true>), grid, dim3(WG3_THREADS), 0, stream,
+                              reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base);
+  else hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<false>), grid, dim3(WG3_THREADS), 0, stream,
+                          reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base);
+  const int status = launch_status();
+  profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 4, 4, WG3_TW, grid_x, 0, 0, elements > pixels ? elements - pixels : 0);
   return status;
 }
 

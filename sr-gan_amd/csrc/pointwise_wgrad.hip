@@ -15,6 +15,7 @@
 // The generic gather-GEMM staged both operands through LDS with a transpose and reached 55 TF/s on these shapes.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace srgan {
 
@@ -38,14 +39,13 @@ constexpr int PWG_MI = 2, PWG_NI = 2;      // 64 x 64 output tile per workgroup
 // is loaded from the row's last four pixels instead (the SAME pixels for both operands), and the elements that repeat
 // an earlier float4 of the lane are switched off in the gy operand when it is used -- a zero times a finite value.
 template <bool PRO, bool RAGGED>
-__global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradParams p) {
+__device__ __forceinline__ void pointwise_wgrad_body(const PwWgradParams& p, const int block_x, const int block_y, float* red) {
   constexpr int MI = PWG_MI, NI = PWG_NI, ROWS = MI * 32, COLS = NI * 32, LDR = COLS + 1;
-  __shared__ float red[2 * ROWS * LDR];
 
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int tm = (int)blockIdx.x / p.tiles_n, tn = (int)blockIdx.x - tm * p.tiles_n;
+  const int tm = block_x / p.tiles_n, tn = block_x - tm * p.tiles_n;
   const int co0 = tm * ROWS, ci0 = tn * COLS;
-  const int worker = (int)blockIdx.y * 4 + wave;
+  const int worker = block_y * 4 + wave;
   const int cbeg = worker * p.chunks_per_worker;
   const int cend = min(p.chunks, cbeg + p.chunks_per_worker);
 
@@ -183,6 +183,39 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradPa
   }
 }
 
+template <bool PRO, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradParams p) {
+  __shared__ float red[2 * PWG_MI * 32 * (PWG_NI * 32 + 1)];
+  pointwise_wgrad_body<PRO, RAGGED>(p, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+// GROUPED: blockIdx.z selects one of many independent problems (all the bottleneck convolutions of a dense block's
+// backward) from a device-resident table; x / gy are offsets from two base pointers, so the table does not change
+// between steps.  Workgroups beyond a problem's own grid leave at once.
+struct PwWgradJob {
+  int64_t x_off, gy_off, x_bs, gy_bs;
+  float* gw;
+  const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
+  int32_t N, CI, CO, HW, tiles_n, tiles, chunks, chunks_per_worker, chunks_per_image, mode, split, pad[3];
+};
+static_assert(sizeof(PwWgradJob) == 128, "one 128-byte table slot per job");
+
+template <bool RAGGED>
+__global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const PwWgradJob* __restrict__ jobs,
+                                                                         const float* x_base, const float* gy_base) {
+  __shared__ float red[2 * PWG_MI * 32 * (PWG_NI * 32 + 1)];
+  const PwWgradJob job = jobs[blockIdx.z];
+  if ((int)blockIdx.x >= job.tiles || (int)blockIdx.y >= job.split) return;       // (workgroup-uniform)
+  PwWgradParams p;
+  p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off; p.gw = job.gw;
+  p.x_bs = job.x_bs; p.gy_bs = job.gy_bs;
+  p.N = job.N; p.CI = job.CI; p.CO = job.CO; p.HW = job.HW;
+  p.tiles_n = job.tiles_n; p.chunks = job.chunks; p.chunks_per_worker = job.chunks_per_worker;
+  p.chunks_per_image = job.chunks_per_image; p.mode = job.mode;
+  p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
+  pointwise_wgrad_body<true, RAGGED>(p, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn,
                         int split, int akf = 0, int bkf = 0, int64_t b_unique = 0, int precision = 0);
@@ -194,6 +227,34 @@ bool pointwise_wgrad_enabled() {
   return enabled;
 }
 
+// Grid plan of one problem: tiles, K split over wave workers, chunks per worker.
+static int pointwise_wgrad_plan(int32_t N, int32_t CI, int32_t CO, int32_t HW, PwWgradParams& p, int& tiles, int& split) {
+  const int tiles_m = (CO + PWG_MI * 32 - 1) / (PWG_MI * 32);
+  p.tiles_n = (CI + PWG_NI * 32 - 1) / (PWG_NI * 32);
+  tiles = tiles_m * p.tiles_n;
+  SRGAN_REQUIRE(HW >= 4, SRGAN_EUNSUPPORTED, "pointwise wgrad plane of fewer than 4 pixels");
+  p.chunks_per_image = (HW + 31) / 32;
+  const int64_t chunks = (int64_t)N * p.chunks_per_image;
+  SRGAN_REQUIRE(chunks < ((int64_t)1 << 30) && tiles < (1 << 30), SRGAN_ERANGE, "pointwise wgrad grid");
+  p.chunks = (int)chunks;
+  // Three resident workgroups per CU (166 registers per lane): 768 workgroups = 3072 wave workers over the whole grid, but at least `min_chunks` chunks per worker so the LDS reduction + atomic pass is amortised.
+  static const int resident = getenv("SRGAN_PWG_WGS") ? atoi(getenv("SRGAN_PWG_WGS")) : 768;
+  static const int min_chunks = getenv("SRGAN_PWG_DEPTH") ? atoi(getenv("SRGAN_PWG_DEPTH")) : 2;   // (8 measured equal at 512 x 512, 2.5 % slower at 224 x 224)
+  split = (resident + tiles - 1) / tiles;
+  const int max_split = (int)((chunks + 4 * min_chunks - 1) / (4 * min_chunks));
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  p.chunks_per_worker = (int)((chunks + 4 * split - 1) / (4 * split));
+  split = (int)((chunks + 4 * (int64_t)p.chunks_per_worker - 1) / (4 * (int64_t)p.chunks_per_worker));
+  SRGAN_REQUIRE(split <= 65535, SRGAN_ERANGE, "pointwise wgrad split");
+  p.mode = split > 1 ? 2 : 1;
+  return SRGAN_OK;
+}
+
+static bool pointwise_wgrad_ragged(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, int32_t HW) {
+  return HW % 32 != 0 || x_bs % 4 != 0 || gy_bs % 4 != 0 || (((uintptr_t)x | (uintptr_t)gy) & 15) != 0;
+}
+
 // gw (=,+=) the weight gradient of a 1x1 convolution; x / gy may be channel-slice views (batch strides in
 // elements).  HW % 32 == 0 with 16-byte aligned rows takes the plain kernel, anything else with HW >= 4 the RAGGED one.
 int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
@@ -203,26 +264,9 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
   p.x = x; p.gy = gy; p.gw = gw; p.x_bs = x_bs; p.gy_bs = gy_bs;
   p.N = N; p.CI = CI; p.CO = CO; p.HW = HW;
-  const int tiles_m = (CO + PWG_MI * 32 - 1) / (PWG_MI * 32);
-  p.tiles_n = (CI + PWG_NI * 32 - 1) / (PWG_NI * 32);
-  const int tiles = tiles_m * p.tiles_n;
-  const bool ragged = HW % 32 != 0 || x_bs % 4 != 0 || gy_bs % 4 != 0 || (((uintptr_t)x | (uintptr_t)gy) & 15) != 0;
-  SRGAN_REQUIRE(HW >= 4, SRGAN_EUNSUPPORTED, "pointwise wgrad plane of fewer than 4 pixels");
-  p.chunks_per_image = (HW + 31) / 32;
-  const int64_t chunks = (int64_t)N * p.chunks_per_image;
-  SRGAN_REQUIRE(chunks < ((int64_t)1 << 30) && tiles < (1 << 30), SRGAN_ERANGE, "pointwise wgrad grid");
-  p.chunks = (int)chunks;
-  // Three resident workgroups per CU (166 registers per lane): 768 workgroups = 3072 wave workers over the whole grid, but at least 8 chunks per worker so the LDS reduction + atomic pass is amortised.
-  static const int resident = getenv("SRGAN_PWG_WGS") ? atoi(getenv("SRGAN_PWG_WGS")) : 768;
-  static const int min_chunks = getenv("SRGAN_PWG_DEPTH") ? atoi(getenv("SRGAN_PWG_DEPTH")) : 2;   // (8 measured equal at 512 x 512, 2.5 % slower at 224 x 224)
-  int split = (resident + tiles - 1) / tiles;
-  const int max_split = (int)((chunks + 4 * min_chunks - 1) / (4 * min_chunks));
-  if (split > max_split) split = max_split;
-  if (split < 1) split = 1;
-  p.chunks_per_worker = (int)((chunks + 4 * split - 1) / (4 * split));
-  split = (int)((chunks + 4 * (int64_t)p.chunks_per_worker - 1) / (4 * (int64_t)p.chunks_per_worker));
-  SRGAN_REQUIRE(split <= 65535, SRGAN_ERANGE, "pointwise wgrad split");
-  p.mode = split > 1 ? 2 : 1;
+  int tiles = 0, split = 1;
+  if (const int status = pointwise_wgrad_plan(N, CI, CO, HW, p, tiles, split)) return status;
+  const bool ragged = pointwise_wgrad_ragged(x, x_bs, gy, gy_bs, HW);
   if (!accumulate) if (const int status = zero_floats(gw, (int64_t)CO * CI, stream)) return status;
   dim3 grid((unsigned)tiles, (unsigned)split, 1);
   const int profile_slot = profile_bracket_begin(stream);
@@ -232,6 +276,47 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
   else hipLaunchKernelGGL((pointwise_wgrad_kernel<false, false>), grid, dim3(256), 0, stream, p);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, CO, CI, (int64_t)N * HW, 6, PWG_MI * 32, PWG_NI * 32, split);
+  return status;
+}
+
+// One entry of a grouped launch's table (host side; the caller uploads the table once).  x / gy are element offsets from
+// the two base pointers given at launch time; the weight gradient is ACCUMULATED into gw.
+int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+                               int32_t CO, int32_t HW, const float* const* bn, void* job_out, int32_t* grid_x,
+                               int32_t* grid_y, int32_t* ragged) {
+  PwWgradParams p;
+  int tiles = 0, split = 1;
+  if (const int status = pointwise_wgrad_plan(N, CI, CO, HW, p, tiles, split)) return status;
+  PwWgradJob job;
+  job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs; job.gw = gw;
+  job.bn_mean = bn[0]; job.bn_inv = bn[1]; job.bn_gamma = bn[2]; job.bn_beta = bn[3];
+  job.N = N; job.CI = CI; job.CO = CO; job.HW = HW; job.tiles_n = p.tiles_n; job.tiles = tiles; job.chunks = p.chunks;
+  job.chunks_per_worker = p.chunks_per_worker; job.chunks_per_image = p.chunks_per_image; job.mode = p.mode;
+  job.split = split; job.pad[0] = job.pad[1] = job.pad[2] = 0;
+  static_assert(sizeof(PwWgradJob) <= 128, "job slot");
+  memset(job_out, 0, 128);
+  memcpy(job_out, &job, sizeof(job));
+  *grid_x = tiles; *grid_y = split;
+  // offsets that are not multiples of 4 floats, or strides / planes that are not, need the ragged variant
+  *ragged = (HW % 32 != 0 || x_bs % 4 != 0 || gy_bs % 4 != 0 || x_off % 4 != 0 || gy_off % 4 != 0) ? 1 : 0;
+  return SRGAN_OK;
+}
+
+int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
+                              const float* x_base, const float* gy_base, int64_t flops_mn, int64_t pixels, int64_t elements,
+                              hipStream_t stream) {
+  SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped pointwise wgrad grid");
+  const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
+  dim3 grid((unsigned)grid_x, (unsigned)grid_y, (unsigned)count);
+  const int profile_slot = profile_bracket_begin(stream);
+  if (rag) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<true>), grid, dim3(256), 0, stream,
+                              reinterpret_cast<const PwWgradJob*>(jobs), x_base, gy_base);
+  else hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<false>), grid, dim3(256), 0, stream,
+                          reinterpret_cast<const PwWgradJob*>(jobs), x_base, gy_base);
+  const int status = launch_status();
+  // logical shape of the group: M x (sum of the input widths) x pixels, i.e. flops_mn = sum CO * CI
+  profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 6, PWG_MI * 32, PWG_NI * 32, grid_y, 0, 0,
+                      elements > pixels ? elements - pixels : 0);
   return status;
 }
 

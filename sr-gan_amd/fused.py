@@ -113,6 +113,58 @@ def _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, d
     return plan
 
 
+GROUPED_WGRAD = not os.environ.get('SRGAN_NO_GROUPED_WGRAD')    # all the weight gradients of a block's backward in two launches (one table per kernel size)
+IN_PLACE_GRADIENT = not os.environ.get('SRGAN_NO_IN_PLACE_GRADIENT')
+
+
+def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device):
+    """Device-resident tables of the two grouped weight-gradient launches of the block's backward (`srgan_wgrad_group_*`):
+    slot `index` of the first is layer `index`'s 1x1 convolution (x = the block buffer, gy = its slice of one tensor that
+    holds every layer's gradient at conv1's output), of the second its 3x3 convolution (x = its slice of the tensor that
+    holds every layer's conv1 output, gy = its channel slice of the gradient buffer).  Offsets are relative to those
+    per-step tensors, so the tables are built once per (block, batch size).  None when a geometry has no fused form."""
+    import ctypes
+    key = (n, c0, h, w, str(device), layers[0].conv1.weight.grad.data_ptr(), layers[-1].conv2.weight.grad.data_ptr())
+    plans = layers[0].__dict__.setdefault('_srgan_wgrad_plans', {})
+    if key in plans:
+        return plans[key]
+    lib = _lib.library()
+    width, hw = layers[0].conv1.out_channels, h * w
+    plan = {'keep': []}
+    for size in (1, 3):
+        slots = (ctypes.c_byte * (128 * len(layers)))()
+        grid_x = grid_y = ragged = 0
+        co_ci_taps = elements = 0
+        for index, layer in enumerate(layers):
+            cin = c0 + index * growth
+            if size == 1:
+                desc, norm, gw = _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), layer.norm1, layer.conv1.weight.grad
+                x_offset, gy_offset = 0, index * n * width * hw
+                co_ci_taps += width * cin
+                elements += (cin + width) * n * hw
+            else:
+                desc, norm, gw = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs), layer.norm2, layer.conv2.weight.grad
+                x_offset, gy_offset = index * n * width * hw, cin * hw
+                co_ci_taps += growth * width * 9
+                elements += (width + growth) * n * hw
+            inv, mean = norm._inverse_std()
+            plan['keep'].append((inv, mean))
+            bn = _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
+            gx, gy, rg = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            status = lib.srgan_wgrad_group_plan(desc, bn, x_offset, gy_offset, gw.data_ptr(),
+                                                ctypes.byref(slots, 128 * index), ctypes.byref(gx), ctypes.byref(gy),
+                                                ctypes.byref(rg))
+            if status != 0:
+                plans[key] = None
+                return None
+            grid_x, grid_y, ragged = max(grid_x, gx.value), max(grid_y, gy.value), max(ragged, rg.value)
+        table = torch.frombuffer(bytearray(bytes(slots)), dtype=torch.uint8).to(device)
+        plan[size] = dict(table=table, count=len(layers), grid_x=grid_x, grid_y=grid_y, ragged=ragged, co_ci_taps=co_ci_taps,
+                          pixels=n * hw, elements=elements)
+    plans[key] = plan
+    return plan
+
+
 def _block_parameters(layers):
     """The block's parameters in ``layer.parameters()`` order (the module tree is fixed: enumerated once)."""
     cached = layers[0].__dict__.get('_srgan_block_parameters')
@@ -163,12 +215,14 @@ def dense_block(x, layers):
             F._call('srgan_fill', buffer.data_ptr(), buffer.numel(), 0.0, stream)
         if zero_b1:
             b1_all = torch.zeros((len(layers), n, width, h, w), dtype=torch.float32, device=device)
+        elif requires:
+            b1_all = _empty((len(layers), n, width, h, w), device)     # one tensor: the grouped weight gradient indexes it
     F._call('srgan_copy_channels', x.data.data_ptr(), c0, 0, buffer.data_ptr(), total, 0, c0, n, hw, 0, stream)
     forward1 = 'srgan_conv2d_fwd_bnrelu_into_zeros' if zero_b1 else 'srgan_conv2d_fwd_bnrelu'
     forward2 = 'srgan_conv2d_fwd_bnrelu_into_zeros' if zero_new else 'srgan_conv2d_fwd_bnrelu'
     for index, layer in enumerate(layers):
         cin = c0 + index * growth
-        b1 = b1_all[index] if zero_b1 else _empty((n, width, h, w), device)
+        b1 = b1_all[index] if prologue and (zero_b1 or requires) else _empty((n, width, h, w), device)
         if prologue:
             F._call(forward1, _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), buffer.data_ptr(),
                     bn_struct(layer.norm1), layer.conv1.weight.data_ptr(), None, b1.data_ptr(), stream)
@@ -209,7 +263,7 @@ def dense_block(x, layers):
                                       'gradient only; set srgan_amd.fused.ENABLED = False for parameter gradients of '
                                       'a recorded backward')
         stream = F._stream()
-        if not recorded and incoming_gradient_is_exclusive() and g.data.is_contiguous():
+        if IN_PLACE_GRADIENT and not recorded and incoming_gradient_is_exclusive() and g.data.is_contiguous():
             gbuf = g.data                         # nobody else reads it: the layers accumulate into it in place
         else:
             gbuf = _empty(g.shape, device)        # private copy: the incoming gradient may be shared
@@ -224,6 +278,10 @@ def dense_block(x, layers):
         # (not while a HIP graph is being captured: a captured fork / join per layer replayed slower and, together with the
         # DNN side stream, crashed the runtime)
         overlap = WGRAD_STREAM and want_params and prologue and not recorded and not torch.cuda.is_current_stream_capturing()
+        grouped = None
+        if GROUPED_WGRAD and want_params and prologue and not recorded and not overlap:
+            grouped = _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device)
+        g_b1_all = _empty((len(layers), n, layers[0].conv1.out_channels, h, w), device) if grouped is not None else None
         if overlap:
             main, side = torch.cuda.current_stream(device), _side_stream(device)
             wstream = _lib.stream_handle(side)
@@ -241,13 +299,15 @@ def dense_block(x, layers):
             desc2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
             if overlap:
                 side.wait_stream(main)            # this layer's slice of the gradient buffer is final
-            if want_params and prologue:
+            if grouped is not None:
+                pass                              # every weight gradient of the block: two launches after the loop
+            elif want_params and prologue:
                 F._call('srgan_conv2d_bwd_weight_bnrelu', desc2, b1.data_ptr(), bn_struct(layer.norm2), g_new,
                         layer.conv2.weight.grad.data_ptr(), 1, wstream)
             elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc2, t2.data_ptr(), g_new, layer.conv2.weight.grad.data_ptr(), 1, 0,
                         stream)
-            g_b1 = _empty(b1.shape, device)
+            g_b1 = g_b1_all[index] if grouped is not None else _empty(b1.shape, device)
             if epilogue2 and plan is not None:
                 F._call('srgan_conv2d_bwd_data_bnrelu_partials', desc2, g_new, layer.conv2.weight.data_ptr(),
                         bn_struct(layer.norm2), b1.data_ptr(), g_b1.data_ptr(), _ptr(scratch, plan['offsets'][index][2]), 0, stream)
@@ -268,7 +328,9 @@ def dense_block(x, layers):
             if overlap:
                 side.wait_stream(main)            # g_b1 is complete
                 alive.extend((g_b1, b1))
-            if want_params and prologue:
+            if grouped is not None:
+                pass
+            elif want_params and prologue:
                 F._call('srgan_conv2d_bwd_weight_bnrelu', _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0),
                         buffer.data_ptr(), bn_struct(layer.norm1), g_b1.data_ptr(), layer.conv1.weight.grad.data_ptr(), 1,
                         wstream)
@@ -301,6 +363,13 @@ def dense_block(x, layers):
                 kept[index] = (g_b1, b1)
             else:
                 saved[index] = None
+        if grouped is not None:
+            # (the gradient slices of gbuf the 3x3 group reads are final: later layers only wrote channels below them)
+            for size, x_base, gy_base in ((3, b1_all, gbuf), (1, buffer, g_b1_all)):
+                group = grouped[size]
+                F._call('srgan_wgrad_group_run', group['table'].data_ptr(), group['count'], size, group['grid_x'],
+                        group['grid_y'], group['ragged'], x_base.data_ptr(), gy_base.data_ptr(), group['co_ci_taps'],
+                        group['pixels'], group['elements'], stream)
         if plan is not None:
             F._call('srgan_bn_partial_reduce_batched', plan['jobs'].data_ptr(), plan['count'], plan['max_channels'],
                     plan['max_tiles'], scratch.data_ptr(), stream)

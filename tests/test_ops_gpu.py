@@ -615,9 +615,11 @@ def test_fused_dense_block_matches_primitive_path(F):
 
 
 @gpu
-def test_fused_dense_block_with_in_kernel_batch_norm(F):
+@pytest.mark.parametrize('plane,batch', [((16, 16), 2), ((14, 14), 3), ((7, 7), 5), ((28, 28), 2), ((9, 7), 2)])
+def test_fused_dense_block_with_in_kernel_batch_norm(F, plane, batch):
     """A block geometry that takes the in-kernel batch-norm path (fused.PROLOGUE) against the materialised one:
-    forward, first-order gradients with trainable parameters, and the gradient-penalty second order."""
+    forward, first-order gradients with trainable parameters, and the gradient-penalty second order -- on whole and on
+    ragged planes (those of 224 x 224), with the block's weight gradients as two grouped launches and one by one."""
     import srgan_amd  # noqa: F401
     from srgan_amd import fused, nn
     from srgan_amd.crowd.models import _DenseBlock
@@ -632,11 +634,12 @@ def test_fused_dense_block_with_in_kernel_batch_norm(F):
             m.running_mean.data = torch.randn(m.running_mean.shape, generator=gen) * 0.2
             m.running_var.data = torch.rand(m.running_var.shape, generator=gen) + 0.5
     arena = nn.flatten_parameters(block, torch.device('cuda', 0))
-    x_host = torch.randn(2, 32, 16, 16, generator=gen)
-    cotangent = torch.randn(2, 56, 16, 16, generator=gen)
+    x_host = torch.randn(batch, 32, *plane, generator=gen)
+    cotangent = torch.randn(batch, 56, *plane, generator=gen)
     results = {}
-    for prologue in (False, True):
-        fused.PROLOGUE = prologue
+    for prologue in (False, True, 'one by one'):
+        fused.PROLOGUE = bool(prologue)
+        fused.GROUPED_WGRAD = prologue is True
         try:
             arena.zero_grad()
             x = F.leaf(dev(x_host), requires_grad=True)
@@ -652,10 +655,11 @@ def test_fused_dense_block_with_in_kernel_batch_norm(F):
             backward(penalty)
             results[prologue] = first + (gx.cpu(), arena.grad.detach().cpu().clone())
         finally:
-            fused.PROLOGUE = True
+            fused.PROLOGUE = fused.GROUPED_WGRAD = True
     for i, what in enumerate(('output', 'input gradient', 'parameter gradients', 'recorded input gradient',
                               'penalty parameter gradients')):
         close(results[True][i], results[False][i], 1e-4, 'in-kernel batch-norm: ' + what)
+        close(results['one by one'][i], results[False][i], 1e-4, 'in-kernel batch-norm, weight gradients one by one: ' + what)
 
 
 @gpu

@@ -325,7 +325,9 @@ def test_crowd_dggan(pkg):
                     assert abs(np.log(result[key]) - np.log(value)) < 1e-3 * abs(np.log(value / 1e4)), key
                 elif key in result:
                     assert_close(result[key], value, rtol=1e-2, atol=0.0, what=f'crowd dggan step 1 {key}')
-            assert_close(experiment.gradient_norm.cpu().numpy(), g['s1/gradient_norm'], rtol=2e-3, what='gn')
+            # (the weight gradients are summed with fp32 atomics in a run-dependent order: which near-zero elements flip
+            # their first Adam step differs between runs, observed 4e-4 ... 2.5e-3 on the second step's gradient norms)
+            assert_close(experiment.gradient_norm.cpu().numpy(), g['s1/gradient_norm'], rtol=5e-3, what='gn')
         assert result['gradient_penalty'] > 10.0
     for prefix, module in (('final_ck/D', experiment.D), ('final_ck/G', experiment.G)):
         for pname, p in module.named_parameters():
