@@ -162,10 +162,11 @@ int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int3
  * pointers given at launch time, gw and the batch-norm vectors are absolute, the gradient is ACCUMULATED into gw -- and
  * returns the grid extent the problem needs and whether it needs the ragged kernel variant; the caller uploads the table
  * once (it does not change between steps when the offsets are relative to per-step buffers) and launches with the maxima
- * over the group.  All problems of a group share the plane size.  sum_co_ci_taps / pixels / operand_elements only feed
+ * over the group.  All problems of a group share the plane size; group_size (the number of problems that will be launched
+ * together) lets the plan give each problem fewer workgroups of its own.  sum_co_ci_taps / pixels / operand_elements only feed
  * the profile (logical FLOPs = 2 * sum_co_ci_taps * pixels; elements of x and gy read once). */
 int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
-                           void* job, int32_t* grid_x, int32_t* grid_y, int32_t* ragged);
+                           int32_t group_size, void* job, int32_t* grid_x, int32_t* grid_y, int32_t* ragged);
 int srgan_wgrad_group_run(const void* jobs, int32_t count, int32_t kernel_size, int32_t grid_x, int32_t grid_y, int32_t ragged,
                           const float* x_base, const float* gy_base, int64_t sum_co_ci_taps, int64_t pixels,
                           int64_t operand_elements, void* stream);

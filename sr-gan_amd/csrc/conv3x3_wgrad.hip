@@ -315,13 +315,15 @@ bool conv3x3_wgrad_enabled() {
 
 // Walkers over the pixel tiles: five resident 3-wave workgroups per CU (120 VGPRs, 22 KB of LDS) over the whole grid, and
 // at least `depth` tiles per walker so that the atomic pass (32 x 288 floats per workgroup) is amortised.
-static int conv3x3_wgrad_walkers(int tiles, int ci_chunks, int co_chunks) {
+static int conv3x3_wgrad_walkers(int tiles, int ci_chunks, int co_chunks, int group = 1) {
   static const int resident = getenv("SRGAN_WGRAD3_WGS") ? atoi(getenv("SRGAN_WGRAD3_WGS")) : 1280;
   static const int depth_override = getenv("SRGAN_WGRAD3_DEPTH") ? atoi(getenv("SRGAN_WGRAD3_DEPTH")) : 0;
   // measured on 128 -> 32 channels, batch 16: 64x64 images best at 8 tiles per walker, 32x32 at 4, 16x16 at 1 (batch
   // 48 at 16x16 = 192 tiles: 48 us at depth 1 -- 768 workgroups x 9216 atomics -- so 4 from 128 tiles up)
   const int depth = depth_override > 0 ? depth_override : (tiles >= 1024 ? 8 : (tiles >= 128 ? 4 : 1));
-  int walkers = resident / (ci_chunks * co_chunks);
+  static const int oversubscription = getenv("SRGAN_GROUP_OVERSUB") ? atoi(getenv("SRGAN_GROUP_OVERSUB")) : 4;
+  const int wanted = group > 1 ? (resident * oversubscription + group - 1) / group : resident;
+  int walkers = wanted / (ci_chunks * co_chunks);
   if (walkers > (tiles + depth - 1) / depth) walkers = (tiles + depth - 1) / depth;
   return walkers < 1 ? 1 : walkers;
 }
@@ -363,7 +365,7 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
 
 // One entry of a grouped launch's table (see pointwise_wgrad_group_plan); the weight gradient is ACCUMULATED into gw.
 int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                             int32_t CO, int32_t H, int32_t W, const float* const* bn, void* job_out, int32_t* grid_x,
+                             int32_t CO, int32_t H, int32_t W, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
                              int32_t* grid_y, int32_t* ragged) {
   Wgrad3Job job;
   job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs; job.gw = gw;
@@ -374,7 +376,7 @@ int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_
   const int64_t tiles = (int64_t)N * job.tiles_y * job.tiles_x;
   SRGAN_REQUIRE(tiles < (int64_t)1 << 31 && (int64_t)job.ci_chunks * job.co_chunks <= 65535, SRGAN_ERANGE, "conv3x3 wgrad grid");
   job.tiles = (int)tiles;
-  job.walkers = conv3x3_wgrad_walkers(job.tiles, job.ci_chunks, job.co_chunks);
+  job.walkers = conv3x3_wgrad_walkers(job.tiles, job.ci_chunks, job.co_chunks, group);
   job.pad[0] = job.pad[1] = job.pad[2] = 0;
   static_assert(sizeof(Wgrad3Job) <= 128, "job slot");
   memset(job_out, 0, 128);

@@ -774,13 +774,13 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
                         int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
 
 int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                               int32_t CO, int32_t HW, const float* const* bn, void* job_out, int32_t* grid_x,
+                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
                                int32_t* grid_y, int32_t* ragged);
 int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
                               const float* x_base, const float* gy_base, int64_t flops_mn, int64_t pixels, int64_t elements,
                               hipStream_t stream);
 int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                             int32_t CO, int32_t H, int32_t W, const float* const* bn, void* job_out, int32_t* grid_x,
+                             int32_t CO, int32_t H, int32_t W, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
                              int32_t* grid_y, int32_t* ragged);
 int conv3x3_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
                             const float* x_base, const float* gy_base, int64_t flops_mn, int64_t pixels, int64_t elements,
@@ -1147,18 +1147,18 @@ int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, 
 
 // ---- grouped weight gradients: all the norm -> relu -> conv weight gradients of a dense block's backward in two launches
 int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
-                           void* job, int32_t* grid_x, int32_t* grid_y, int32_t* ragged) {
+                           int32_t group_size, void* job, int32_t* grid_x, int32_t* grid_y, int32_t* ragged) {
   ConvGeom g;
   SRGAN_GEOM(desc, g, "srgan_wgrad_group_plan");
-  SRGAN_REQUIRE(gw && job && grid_x && grid_y && ragged && bn_ok(bn) && x_offset >= 0 && gy_offset >= 0, SRGAN_EINVAL,
+  SRGAN_REQUIRE(gw && job && grid_x && grid_y && ragged && bn_ok(bn) && x_offset >= 0 && gy_offset >= 0 && group_size >= 1, SRGAN_EINVAL,
                 "srgan_wgrad_group_plan arguments");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 2), SRGAN_EUNSUPPORTED, "srgan_wgrad_group_plan geometry support");
   const float* const coefficients[4] = {bn->mean, bn->inv_std, bn->gamma, bn->beta};
   if (pointwise(g))
-    return pointwise_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, coefficients, job,
-                                      grid_x, grid_y, ragged);
-  return conv3x3_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, coefficients, job, grid_x,
-                                  grid_y, ragged);
+    return pointwise_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, g.N, g.C, g.K, g.H * g.W, coefficients, group_size,
+                                      job, grid_x, grid_y, ragged);
+  return conv3x3_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, g.N, g.C, g.K, g.H, g.W, coefficients, group_size, job,
+                                  grid_x, grid_y, ragged);
 }
 
 int srgan_wgrad_group_run(const void* jobs, int32_t count, int32_t kernel_size, int32_t grid_x, int32_t grid_y, int32_t ragged,

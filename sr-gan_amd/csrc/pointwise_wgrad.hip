@@ -228,7 +228,9 @@ bool pointwise_wgrad_enabled() {
 }
 
 // Grid plan of one problem: tiles, K split over wave workers, chunks per worker.
-static int pointwise_wgrad_plan(int32_t N, int32_t CI, int32_t CO, int32_t HW, PwWgradParams& p, int& tiles, int& split) {
+// `group`: the number of problems launched together (their workgroups share the GPU, so each needs fewer of its own).
+static int pointwise_wgrad_plan(int32_t N, int32_t CI, int32_t CO, int32_t HW, PwWgradParams& p, int& tiles, int& split,
+                                int group = 1) {
   const int tiles_m = (CO + PWG_MI * 32 - 1) / (PWG_MI * 32);
   p.tiles_n = (CI + PWG_NI * 32 - 1) / (PWG_NI * 32);
   tiles = tiles_m * p.tiles_n;
@@ -240,7 +242,9 @@ static int pointwise_wgrad_plan(int32_t N, int32_t CI, int32_t CO, int32_t HW, P
   // Three resident workgroups per CU (166 registers per lane): 768 workgroups = 3072 wave workers over the whole grid, but at least `min_chunks` chunks per worker so the LDS reduction + atomic pass is amortised.
   static const int resident = getenv("SRGAN_PWG_WGS") ? atoi(getenv("SRGAN_PWG_WGS")) : 768;
   static const int min_chunks = getenv("SRGAN_PWG_DEPTH") ? atoi(getenv("SRGAN_PWG_DEPTH")) : 2;   // (8 measured equal at 512 x 512, 2.5 % slower at 224 x 224)
-  split = (resident + tiles - 1) / tiles;
+  static const int oversubscription = getenv("SRGAN_GROUP_OVERSUB") ? atoi(getenv("SRGAN_GROUP_OVERSUB")) : 4;
+  const int wanted = group > 1 ? (resident * oversubscription + group - 1) / group : resident;
+  split = (wanted + tiles - 1) / tiles;
   const int max_split = (int)((chunks + 4 * min_chunks - 1) / (4 * min_chunks));
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -282,11 +286,11 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
 // One entry of a grouped launch's table (host side; the caller uploads the table once).  x / gy are element offsets from
 // the two base pointers given at launch time; the weight gradient is ACCUMULATED into gw.
 int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
-                               int32_t CO, int32_t HW, const float* const* bn, void* job_out, int32_t* grid_x,
+                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
                                int32_t* grid_y, int32_t* ragged) {
   PwWgradParams p;
   int tiles = 0, split = 1;
-  if (const int status = pointwise_wgrad_plan(N, CI, CO, HW, p, tiles, split)) return status;
+  if (const int status = pointwise_wgrad_plan(N, CI, CO, HW, p, tiles, split, group)) return status;
   PwWgradJob job;
   job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs; job.gw = gw;
   job.bn_mean = bn[0]; job.bn_inv = bn[1]; job.bn_gamma = bn[2]; job.bn_beta = bn[3];

@@ -151,7 +151,7 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device):
             plan['keep'].append((inv, mean))
             bn = _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
             gx, gy, rg = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-            status = lib.srgan_wgrad_group_plan(desc, bn, x_offset, gy_offset, gw.data_ptr(),
+            status = lib.srgan_wgrad_group_plan(desc, bn, x_offset, gy_offset, gw.data_ptr(), len(layers),
                                                 ctypes.byref(slots, 128 * index), ctypes.byref(gx), ctypes.byref(gy),
                                                 ctypes.byref(rg))
             if status != 0:
