@@ -224,6 +224,16 @@ int srgan_bn_conv_tangent_weights(const float* w, const float* q, const float* i
                                   float* w_scaled, float* w_grad, float* gamma_grad, int32_t CO, int32_t CI, int32_t taps,
                                   void* stream);
 
+/* The same for many convolutions in ONE launch (every layer of a dense block's double backward).  The `_job` call fills
+ * one 64-byte table slot on the host: the parameters where they live, and `offset` (elements) of this convolution's
+ * scaled weights / weight gradient q inside two per-step buffers; the caller uploads the table once.  `_grouped` with
+ * scaled_base != NULL writes every w_scaled (start of the double backward), with q_base != NULL it applies the gradient
+ * part (its end); max_inner = max CI * taps, max_co = max CO over the table. */
+int srgan_bn_conv_tangent_weights_job(const float* w, const float* inv_std, const float* gamma, float* w_grad,
+                                      float* gamma_grad, int64_t offset, int32_t CO, int32_t CI, int32_t taps, void* job);
+int srgan_bn_conv_tangent_weights_grouped(const void* jobs, int32_t count, int32_t max_inner, int32_t max_co, float* scaled_base,
+                                          const float* q_base, void* stream);
+
 /* Whole backward of frozen batch-norm (+ReLU when relu != 0) in one pass over (g, x): the activation mask is
  * recomputed from x (y = fma(x, a, b), a = inv_std*gamma, b = beta - mean*a, exactly the forward's arithmetic);
  * gx (=,+=) g*[y>0]*a (gx may be NULL; g / x / gx may be channel-slice views, batch stride 0 = dense; unscaled != 0

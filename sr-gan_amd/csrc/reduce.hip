@@ -5,6 +5,7 @@
 // workgroups combine with one hardware fp32 atomic per (channel, segment).
 // Roofline: HBM; algorithmic bytes = 4 * elements read per operand.
 #include "common.h"
+#include <string.h>
 
 namespace srgan {
 
@@ -189,12 +190,11 @@ __global__ __launch_bounds__(256) void chan_reduce_cols_kernel(const float* __re
 // Lanes along the contiguous inner index; a workgroup covers 64 inner indices x 16 rows of CO (four row-lanes x four
 // independent iterations: the chain of dependent loads, not bandwidth, bounds this tiny kernel), combined through LDS.
 constexpr int TW_ROWS = 16;
-__global__ __launch_bounds__(256) void tangent_weight_kernel(const float* __restrict__ w, const float* __restrict__ q,
-                                                             const float* __restrict__ inv_std,
-                                                             const float* __restrict__ gamma, float* __restrict__ w_scaled,
-                                                             float* __restrict__ w_grad, float* __restrict__ gamma_grad,
-                                                             int CO, int inner, int taps) {
-  __shared__ float scratch[4][64];
+__device__ __forceinline__ void tangent_weight_body(const float* __restrict__ w, const float* __restrict__ q,
+                                                    const float* __restrict__ inv_std, const float* __restrict__ gamma,
+                                                    float* __restrict__ w_scaled, float* __restrict__ w_grad,
+                                                    float* __restrict__ gamma_grad, int CO, int inner, int taps,
+                                                    float (*scratch)[64]) {
   const int jl = (int)threadIdx.x & 63, cl = (int)threadIdx.x >> 6;
   const int j = (int)blockIdx.x * 64 + jl;
   const bool live = j < inner;
@@ -229,6 +229,37 @@ __global__ __launch_bounds__(256) void tangent_weight_kernel(const float* __rest
   if (cl != 0 || !live) return;
   dot = (scratch[0][jl] + scratch[1][jl]) + (scratch[2][jl] + scratch[3][jl]);
   unsafeAtomicAdd(gamma_grad + ci, dot * inv_std[ci]);
+}
+
+__global__ __launch_bounds__(256) void tangent_weight_kernel(const float* __restrict__ w, const float* __restrict__ q,
+                                                             const float* __restrict__ inv_std,
+                                                             const float* __restrict__ gamma, float* __restrict__ w_scaled,
+                                                             float* __restrict__ w_grad, float* __restrict__ gamma_grad,
+                                                             int CO, int inner, int taps) {
+  __shared__ float scratch[4][64];
+  tangent_weight_body(w, q, inv_std, gamma, w_scaled, w_grad, gamma_grad, CO, inner, taps, scratch);
+}
+
+// The same for MANY convolutions in one launch (every norm -> relu -> conv of a dense block's double backward): job
+// blockIdx.z of a device-resident table; the scaled weights / the weight gradients q of all jobs live in two per-step
+// buffers at the job's `offset` (elements), everything else is where the parameters live.  `scaled_base` != NULL: write
+// the scaled weights (start of the double backward); `q_base` != NULL: the gradient part (its end).
+struct TangentWeightJob {
+  const float* w; const float* inv_std; const float* gamma; float* w_grad; float* gamma_grad;
+  int64_t offset;
+  int32_t CO, inner, taps, pad;
+};
+static_assert(sizeof(TangentWeightJob) == 64, "one 64-byte table slot per job");
+
+__global__ __launch_bounds__(256) void tangent_weight_grouped_kernel(const TangentWeightJob* __restrict__ jobs,
+                                                                     float* __restrict__ scaled_base,
+                                                                     const float* __restrict__ q_base) {
+  __shared__ float scratch[4][64];
+  const TangentWeightJob job = jobs[blockIdx.z];
+  if ((int64_t)blockIdx.x * 64 >= job.inner || (int)blockIdx.y * TW_ROWS >= job.CO) return;       // (workgroup-uniform)
+  tangent_weight_body(job.w, q_base ? q_base + job.offset : nullptr, job.inv_std, job.gamma,
+                      scaled_base ? scaled_base + job.offset : nullptr, job.w_grad, job.gamma_grad, job.CO, job.inner,
+                      job.taps, scratch);
 }
 
 // out[b] = max_f x[b, f]  (the stabiliser of logsumexp, reference utility.py:179); F is small (bins).
@@ -326,6 +357,30 @@ int srgan_bn_conv_tangent_weights(const float* w, const float* q, const float* i
   hipLaunchKernelGGL(tangent_weight_kernel, dim3((unsigned)((inner + 63) / 64), (unsigned)((CO + TW_ROWS - 1) / TW_ROWS)),
                      dim3(256), 0, (hipStream_t)stream, w, q, inv_std, gamma, w_scaled, w_grad, gamma_grad, CO, (int)inner,
                      taps);
+  return launch_status();
+}
+
+int srgan_bn_conv_tangent_weights_job(const float* w, const float* inv_std, const float* gamma, float* w_grad,
+                                      float* gamma_grad, int64_t offset, int32_t CO, int32_t CI, int32_t taps, void* job) {
+  SRGAN_REQUIRE(w && inv_std && gamma && job && offset >= 0 && CO > 0 && CI > 0 && taps > 0, SRGAN_EINVAL,
+                "srgan_bn_conv_tangent_weights_job arguments");
+  const int64_t inner = (int64_t)CI * taps;
+  SRGAN_REQUIRE(inner < ((int64_t)1 << 31), SRGAN_ERANGE, "srgan_bn_conv_tangent_weights_job size");
+  TangentWeightJob slot;
+  slot.w = w; slot.inv_std = inv_std; slot.gamma = gamma; slot.w_grad = w_grad; slot.gamma_grad = gamma_grad;
+  slot.offset = offset; slot.CO = CO; slot.inner = (int32_t)inner; slot.taps = taps; slot.pad = 0;
+  memcpy(job, &slot, sizeof(slot));
+  return SRGAN_OK;
+}
+
+int srgan_bn_conv_tangent_weights_grouped(const void* jobs, int32_t count, int32_t max_inner, int32_t max_co, float* scaled_base,
+                                          const float* q_base, void* stream) {
+  SRGAN_REQUIRE(jobs && count >= 1 && count <= 65535 && max_inner >= 1 && max_co >= 1 && (scaled_base || q_base), SRGAN_EINVAL,
+                "srgan_bn_conv_tangent_weights_grouped arguments");
+  const unsigned rows = (unsigned)((max_co + TW_ROWS - 1) / TW_ROWS);
+  SRGAN_REQUIRE(rows <= 65535, SRGAN_ERANGE, "srgan_bn_conv_tangent_weights_grouped grid");
+  hipLaunchKernelGGL(tangent_weight_grouped_kernel, dim3((unsigned)((max_inner + 63) / 64), rows, (unsigned)count), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const TangentWeightJob*>(jobs), scaled_base, q_base);
   return launch_status();
 }
 

@@ -165,6 +165,38 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device):
     return plan
 
 
+def _tangent_plan(layers, c0, growth, device):
+    """Device-resident table of the grouped tangent-weight launches of the block's double backward: slots 2 * index and
+    2 * index + 1 are layer `index`'s 1x1 and 3x3 convolution; `offsets` are their places inside the per-step buffers of
+    scaled weights / weight gradients q."""
+    import ctypes
+    key = (c0, str(device), layers[0].conv1.weight.data_ptr(), layers[-1].conv2.weight.grad.data_ptr())
+    plans = layers[0].__dict__.setdefault('_srgan_tangent_plans', {})
+    if key in plans:
+        return plans[key]
+    lib = _lib.library()
+    slots = (ctypes.c_byte * (64 * 2 * len(layers)))()
+    offsets, at, max_inner, max_co, keep = [], 0, 0, 0, []
+    for index, layer in enumerate(layers):
+        pair = []
+        for which, (conv, norm, taps) in enumerate(((layer.conv1, layer.norm1, 1), (layer.conv2, layer.norm2, 9))):
+            inv, _ = norm._inverse_std()
+            keep.append(inv)
+            co, ci = conv.weight.shape[0], conv.weight.shape[1]
+            _lib.check(lib.srgan_bn_conv_tangent_weights_job(conv.weight.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(),
+                                                             conv.weight.grad.data_ptr(), norm.weight.grad.data_ptr(), at, co,
+                                                             ci, taps, ctypes.byref(slots, 64 * (2 * index + which))),
+                       'srgan_bn_conv_tangent_weights_job')
+            pair.append(at)
+            at += conv.weight.numel()
+            max_inner, max_co = max(max_inner, ci * taps), max(max_co, co)
+        offsets.append(tuple(pair))
+    table = torch.frombuffer(bytearray(bytes(slots)), dtype=torch.uint8).to(device)
+    plans[key] = dict(table=table, count=2 * len(layers), offsets=offsets, total=at, max_inner=max_inner, max_co=max_co,
+                      keep=keep)
+    return plans[key]
+
+
 def _block_parameters(layers):
     """The block's parameters in ``layer.parameters()`` order (the module tree is fixed: enumerated once)."""
     cached = layers[0].__dict__.get('_srgan_block_parameters')
@@ -398,47 +430,43 @@ def dense_block(x, layers):
         F._call('srgan_copy_channels', v.data.data_ptr(), c0, 0, vbuf.data_ptr(), total, 0, c0, n, hw, 0, stream)
         # the weight gradients w.r.t. the scaled weights (q1, q2 of every layer) land in ONE pre-zeroed buffer, so the
         # weight-gradient kernels accumulate into it without a zero-fill launch of their own (2 per layer otherwise)
-        q_sizes = [(layer.conv1.weight.numel(), layer.conv2.weight.numel()) for layer in layers]
-        q_all = torch.zeros(sum(a + b for a, b in q_sizes), dtype=torch.float32, device=device) if want_params else None
-        q_at = 0
+        # Per weight element: the scaled weights of EVERY layer in one launch up front, the weight / batch-norm-scale
+        # gradients from the q of every layer in one launch at the end (`srgan_bn_conv_tangent_weights_grouped`); the
+        # weight gradients q themselves accumulate into ONE pre-zeroed buffer (no zero-fill launch of their own).
+        tangent = _tangent_plan(layers, c0, growth, device)
+        scaled_all = _empty((tangent['total'],), device)
+        q_all = torch.zeros(tangent['total'], dtype=torch.float32, device=device) if want_params else None
+        F._call('srgan_bn_conv_tangent_weights_grouped', tangent['table'].data_ptr(), tangent['count'], tangent['max_inner'],
+                tangent['max_co'], scaled_all.data_ptr(), None, stream)
         for index, layer in enumerate(layers):
             g_b1, b1 = kept[index]
             cin = c0 + index * growth
             width = layer.conv1.out_channels
             mean1, inv1, gamma1, beta1 = norm_pointers(layer.norm1)
             mean2, inv2, gamma2, beta2 = norm_pointers(layer.norm2)
-            w1, w2 = layer.conv1.weight, layer.conv2.weight
+            at1, at2 = tangent['offsets'][index]
             desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
             desc2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
-            # ---- batch-norm 1 + ReLU, linearised: masked (unscaled) tangent; the scale goes into the weights
+            # ---- batch-norm 1 + ReLU, linearised: masked (unscaled) tangent; the scale is in the weights
             u1 = _empty((n, cin, h, w), device)
             F._call('srgan_bn_act_bwd', vbuf.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, u1.data_ptr(),
                     None, None, n, cin, hw, buffer_bs, buffer_bs, 0, 0, 1, stream)
-            q1 = q2 = None
             if want_params:
-                q1, q2 = _ptr(q_all, q_at), _ptr(q_all, q_at + q_sizes[index][0])
-                q_at += sum(q_sizes[index])
-                F._call('srgan_conv2d_bwd_weight', desc1, u1.data_ptr(), g_b1.data_ptr(), q1, 1, 0, stream)
-            # w1s = W1 * a;  dL/dW1 += q1 * a;  dL/dgamma1 += inv_std * sum_co W1 * q1   (a = inv_std * gamma per ci)
-            w1s = _empty(w1.shape, device)
-            F._call('srgan_bn_conv_tangent_weights', w1.data_ptr(), q1, inv1, gamma1,
-                    w1s.data_ptr(), w1.grad.data_ptr() if want_params else None,
-                    layer.norm1.weight.grad.data_ptr() if want_params else None, width, cin, 1, stream)
+                F._call('srgan_conv2d_bwd_weight', desc1, u1.data_ptr(), g_b1.data_ptr(), _ptr(q_all, at1), 1, 0, stream)
             b1_tangent = _empty(b1.shape, device)
-            F._call('srgan_conv2d_fwd', desc1, u1.data_ptr(), w1s.data_ptr(), None, b1_tangent.data_ptr(), 0, stream)
+            F._call('srgan_conv2d_fwd', desc1, u1.data_ptr(), _ptr(scaled_all, at1), None, b1_tangent.data_ptr(), 0, stream)
             del u1
             # ---- batch-norm 2 + ReLU, linearised
             u2 = _empty(b1.shape, device)
             F._call('srgan_bn_act_bwd', b1_tangent.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1, u2.data_ptr(),
                     None, None, n, width, hw, 0, 0, 0, 0, 1, stream)
             if want_params:
-                F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), q2, 1, 0, stream)
-            w2s = _empty(w2.shape, device)
-            F._call('srgan_bn_conv_tangent_weights', w2.data_ptr(), q2, inv2, gamma2,
-                    w2s.data_ptr(), w2.grad.data_ptr() if want_params else None,
-                    layer.norm2.weight.grad.data_ptr() if want_params else None, growth, width, 9, stream)
-            F._call('srgan_conv2d_fwd', desc2, u2.data_ptr(), w2s.data_ptr(), None, _ptr(vbuf, cin * hw), 0, stream)
+                F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), _ptr(q_all, at2), 1, 0, stream)
+            F._call('srgan_conv2d_fwd', desc2, u2.data_ptr(), _ptr(scaled_all, at2), None, _ptr(vbuf, cin * hw), 0, stream)
             kept[index] = None
+        if want_params:                                 # dL/dW += q * a;  dL/dgamma += inv_std * sum_co W * q   (a = inv_std * gamma)
+            F._call('srgan_bn_conv_tangent_weights_grouped', tangent['table'].data_ptr(), tangent['count'],
+                    tangent['max_inner'], tangent['max_co'], None, q_all.data_ptr(), stream)
         return (Var(vbuf) if needs2[0] else None,) + (None,) * len(parameter_vars)
 
     out.node = Node((x,) + tuple(parameter_vars), backward, 'dense_block')
