@@ -163,13 +163,16 @@ int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int3
  * returns the grid extent the problem needs and whether it needs the ragged kernel variant; the caller uploads the table
  * once (it does not change between steps when the offsets are relative to per-step buffers) and launches with the maxima
  * over the group.  All problems of a group share the plane size; group_size (the number of problems that will be launched
- * together) lets the plan give each problem fewer workgroups of its own.  sum_co_ci_taps / pixels / operand_elements only feed
+ * together) lets the plan give each problem fewer workgroups of its own.  bn == NULL plans the plain weight gradient
+ * (x used as is; srgan_wgrad_group_run with fused_bn = 0): the double backward's gradients w.r.t. the scaled weights.
+ * gw == NULL: the gradient goes to gw_base + gw_offset of the launch (a per-step buffer) instead of a fixed address.  sum_co_ci_taps / pixels / operand_elements only feed
  * the profile (logical FLOPs = 2 * sum_co_ci_taps * pixels; elements of x and gy read once). */
 int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
-                           int32_t group_size, void* job, int32_t* grid_x, int32_t* grid_y, int32_t* ragged);
+                           int64_t gw_offset, int32_t group_size, void* job, int32_t* grid_x, int32_t* grid_y,
+                           int32_t* ragged);
 int srgan_wgrad_group_run(const void* jobs, int32_t count, int32_t kernel_size, int32_t grid_x, int32_t grid_y, int32_t ragged,
-                          const float* x_base, const float* gy_base, int64_t sum_co_ci_taps, int64_t pixels,
-                          int64_t operand_elements, void* stream);
+                          int32_t fused_bn, const float* x_base, const float* gy_base, float* gw_base, int64_t sum_co_ci_taps,
+                          int64_t pixels, int64_t operand_elements, void* stream);
 
 /* ---- strided GEMM  C[i*sci + j*scj] (=,+=) sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] + bias ----------------
  * C must be a dense M x N matrix (row- or column-major).  bias is indexed by row i, or by column j when

@@ -291,12 +291,14 @@ static_assert(sizeof(Wgrad3Job) == 128, "one 128-byte table slot per job");
 
 template <bool RAGGED>
 __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_grouped_kernel(const Wgrad3Job* __restrict__ jobs,
-                                                                               const float* x_base, const float* gy_base) {
+                                                                               const float* x_base, const float* gy_base,
+                                                                               float* gw_base) {
   __shared__ float smem[Wgrad3Lds<4, 0, RAGGED>::SMEM];
   const Wgrad3Job job = jobs[blockIdx.z];
   if ((int)blockIdx.x >= job.walkers || (int)blockIdx.y >= job.ci_chunks * job.co_chunks) return;   // (workgroup-uniform)
   Wgrad3Params p;
-  p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off; p.gw = job.gw; p.x_bs = job.x_bs; p.gy_bs = job.gy_bs;
+  p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off; p.x_bs = job.x_bs; p.gy_bs = job.gy_bs;
+  p.gw = gw_base ? gw_base + (int64_t)(intptr_t)job.gw : job.gw;      // (an element offset into the per-step buffer)
   p.N = job.N; p.CI = job.CI; p.CO = job.CO; p.H = job.H; p.W = job.W;
   p.tiles_x = job.tiles_x; p.tiles_y = job.tiles_y; p.tiles = job.tiles; p.debug = 0;
   p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
@@ -364,12 +366,14 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
 }
 
 // One entry of a grouped launch's table (see pointwise_wgrad_group_plan); the weight gradient is ACCUMULATED into gw.
-int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int64_t gw_off, int32_t N, int32_t CI,
                              int32_t CO, int32_t H, int32_t W, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
                              int32_t* grid_y, int32_t* ragged) {
   Wgrad3Job job;
-  job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs; job.gw = gw;
-  job.bn_mean = bn[0]; job.bn_inv = bn[1]; job.bn_gamma = bn[2]; job.bn_beta = bn[3];
+  job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs;
+  job.gw = gw ? gw : reinterpret_cast<float*>((intptr_t)gw_off);
+  job.bn_mean = bn ? bn[0] : nullptr; job.bn_inv = bn ? bn[1] : nullptr;
+  job.bn_gamma = bn ? bn[2] : nullptr; job.bn_beta = bn ? bn[3] : nullptr;
   job.N = N; job.CI = CI; job.CO = CO; job.H = H; job.W = W;
   job.ci_chunks = (CI + WG3_CI - 1) / WG3_CI; job.co_chunks = (CO + WG3_CO - 1) / WG3_CO;
   job.tiles_x = (W + WG3_TW - 1) / WG3_TW; job.tiles_y = (H + 3) / 4;
@@ -387,16 +391,16 @@ int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_
 }
 
 int conv3x3_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
-                            const float* x_base, const float* gy_base, int64_t flops_mn, int64_t pixels, int64_t elements,
-                            hipStream_t stream) {
+                            const float* x_base, const float* gy_base, float* gw_base, int64_t flops_mn, int64_t pixels,
+                            int64_t elements, hipStream_t stream) {
   SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped conv3x3 wgrad grid");
   const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
   dim3 grid((unsigned)grid_x, (unsigned)grid_y, (unsigned)count);
   const int profile_slot = profile_bracket_begin(stream);
   if (rag) hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<true>), grid, dim3(WG3_THREADS), 0, stream,
-                              reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base);
+                              reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base);
   else hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<false>), grid, dim3(WG3_THREADS), 0, stream,
-                          reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base);
+                          reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 4, 4, WG3_TW, grid_x, 0, 0, elements > pixels ? elements - pixels : 0);
   return status;

@@ -200,20 +200,23 @@ struct PwWgradJob {
 };
 static_assert(sizeof(PwWgradJob) == 128, "one 128-byte table slot per job");
 
-template <bool RAGGED>
+// (gw_base != NULL: the job's gw field holds an element OFFSET into that per-step buffer instead of a pointer.)
+template <bool PRO, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const PwWgradJob* __restrict__ jobs,
-                                                                         const float* x_base, const float* gy_base) {
+                                                                         const float* x_base, const float* gy_base,
+                                                                         float* gw_base) {
   __shared__ float red[2 * PWG_MI * 32 * (PWG_NI * 32 + 1)];
   const PwWgradJob job = jobs[blockIdx.z];
   if ((int)blockIdx.x >= job.tiles || (int)blockIdx.y >= job.split) return;       // (workgroup-uniform)
   PwWgradParams p;
-  p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off; p.gw = job.gw;
+  p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off;
+  p.gw = gw_base ? gw_base + (int64_t)(intptr_t)job.gw : job.gw;
   p.x_bs = job.x_bs; p.gy_bs = job.gy_bs;
   p.N = job.N; p.CI = job.CI; p.CO = job.CO; p.HW = job.HW;
   p.tiles_n = job.tiles_n; p.chunks = job.chunks; p.chunks_per_worker = job.chunks_per_worker;
   p.chunks_per_image = job.chunks_per_image; p.mode = job.mode;
   p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
-  pointwise_wgrad_body<true, RAGGED>(p, (int)blockIdx.x, (int)blockIdx.y, red);
+  pointwise_wgrad_body<PRO, RAGGED>(p, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
 int profile_bracket_begin(hipStream_t stream);
@@ -285,15 +288,17 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
 
 // One entry of a grouped launch's table (host side; the caller uploads the table once).  x / gy are element offsets from
 // the two base pointers given at launch time; the weight gradient is ACCUMULATED into gw.
-int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int32_t N, int32_t CI,
+int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int64_t gw_off, int32_t N, int32_t CI,
                                int32_t CO, int32_t HW, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
                                int32_t* grid_y, int32_t* ragged) {
   PwWgradParams p;
   int tiles = 0, split = 1;
   if (const int status = pointwise_wgrad_plan(N, CI, CO, HW, p, tiles, split, group)) return status;
   PwWgradJob job;
-  job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs; job.gw = gw;
-  job.bn_mean = bn[0]; job.bn_inv = bn[1]; job.bn_gamma = bn[2]; job.bn_beta = bn[3];
+  job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs;
+  job.gw = gw ? gw : reinterpret_cast<float*>((intptr_t)gw_off);
+  job.bn_mean = bn ? bn[0] : nullptr; job.bn_inv = bn ? bn[1] : nullptr;
+  job.bn_gamma = bn ? bn[2] : nullptr; job.bn_beta = bn ? bn[3] : nullptr;
   job.N = N; job.CI = CI; job.CO = CO; job.HW = HW; job.tiles_n = p.tiles_n; job.tiles = tiles; job.chunks = p.chunks;
   job.chunks_per_worker = p.chunks_per_worker; job.chunks_per_image = p.chunks_per_image; job.mode = p.mode;
   job.split = split; job.pad[0] = job.pad[1] = job.pad[2] = 0;
@@ -306,17 +311,18 @@ int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int6
   return SRGAN_OK;
 }
 
-int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
-                              const float* x_base, const float* gy_base, int64_t flops_mn, int64_t pixels, int64_t elements,
-                              hipStream_t stream) {
+int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged, int32_t fused_bn,
+                              const float* x_base, const float* gy_base, float* gw_base, int64_t flops_mn, int64_t pixels,
+                              int64_t elements, hipStream_t stream) {
   SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped pointwise wgrad grid");
   const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
   dim3 grid((unsigned)grid_x, (unsigned)grid_y, (unsigned)count);
+  const PwWgradJob* table = reinterpret_cast<const PwWgradJob*>(jobs);
   const int profile_slot = profile_bracket_begin(stream);
-  if (rag) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<true>), grid, dim3(256), 0, stream,
-                              reinterpret_cast<const PwWgradJob*>(jobs), x_base, gy_base);
-  else hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<false>), grid, dim3(256), 0, stream,
-                          reinterpret_cast<const PwWgradJob*>(jobs), x_base, gy_base);
+  if (fused_bn && rag) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<true, true>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
+  else if (fused_bn) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<true, false>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
+  else if (rag) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<false, true>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
+  else hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<false, false>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
   const int status = launch_status();
   // logical shape of the group: M x (sum of the input widths) x pixels, i.e. flops_mn = sum CO * CI
   profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 6, PWG_MI * 32, PWG_NI * 32, grid_y, 0, 0,

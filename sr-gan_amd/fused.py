@@ -115,22 +115,34 @@ def _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, d
 
 GROUPED_WGRAD = not os.environ.get('SRGAN_NO_GROUPED_WGRAD')    # all the weight gradients of a block's backward in two launches (one table per kernel size)
 IN_PLACE_GRADIENT = not os.environ.get('SRGAN_NO_IN_PLACE_GRADIENT')
+GROUPED_TANGENT_LIMIT = int(os.environ.get('SRGAN_GROUPED_TANGENT_LIMIT_MB', '800')) << 20   # bytes of masked tangents kept
 
 
-def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device):
+def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent=None):
     """Device-resident tables of the two grouped weight-gradient launches of the block's backward (`srgan_wgrad_group_*`):
     slot `index` of the first is layer `index`'s 1x1 convolution (x = the block buffer, gy = its slice of one tensor that
     holds every layer's gradient at conv1's output), of the second its 3x3 convolution (x = its slice of the tensor that
     holds every layer's conv1 output, gy = its channel slice of the gradient buffer).  Offsets are relative to those
-    per-step tensors, so the tables are built once per (block, batch size).  None when a geometry has no fused form."""
+    per-step tensors, so the tables are built once per (block, batch size).  None when a geometry has no fused form.
+
+    With ``tangent`` (the plan of `_tangent_plan`): the DOUBLE backward's tables instead -- plain weight gradients of the
+    masked tangents (1x1: x = layer's slice of one flat tensor of all u1, gy as above; 3x3: x = its slice of the tensor of all
+    u2, gy = its channel slice of the first backward's gradient buffer) that accumulate into the per-step buffer of q at
+    the tangent plan's offsets."""
     import ctypes
-    key = (n, c0, h, w, str(device), layers[0].conv1.weight.grad.data_ptr(), layers[-1].conv2.weight.grad.data_ptr())
+    key = (n, c0, h, w, str(device), tangent is not None, layers[0].conv1.weight.grad.data_ptr(),
+           layers[-1].conv2.weight.grad.data_ptr())
     plans = layers[0].__dict__.setdefault('_srgan_wgrad_plans', {})
     if key in plans:
         return plans[key]
     lib = _lib.library()
     width, hw = layers[0].conv1.out_channels, h * w
     plan = {'keep': []}
+    u1_offsets, u1_at = [], 0
+    for index in range(len(layers)):
+        u1_offsets.append(u1_at)
+        u1_at += n * (c0 + index * growth) * hw
+    plan['u1_offsets'], plan['u1_total'] = u1_offsets, u1_at
     for size in (1, 3):
         slots = (ctypes.c_byte * (128 * len(layers)))()
         grid_x = grid_y = ragged = 0
@@ -138,8 +150,12 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device):
         for index, layer in enumerate(layers):
             cin = c0 + index * growth
             if size == 1:
-                desc, norm, gw = _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), layer.norm1, layer.conv1.weight.grad
-                x_offset, gy_offset = 0, index * n * width * hw
+                norm, gw = layer.norm1, layer.conv1.weight.grad
+                if tangent is None:
+                    desc, x_offset = _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), 0
+                else:
+                    desc, x_offset = _desc(n, cin, h, w, width, 1, 1, 1, 0), u1_offsets[index]
+                gy_offset = index * n * width * hw
                 co_ci_taps += width * cin
                 elements += (cin + width) * n * hw
             else:
@@ -147,13 +163,16 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device):
                 x_offset, gy_offset = index * n * width * hw, cin * hw
                 co_ci_taps += growth * width * 9
                 elements += (width + growth) * n * hw
-            inv, mean = norm._inverse_std()
-            plan['keep'].append((inv, mean))
-            bn = _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
+            bn = None
+            if tangent is None:
+                inv, mean = norm._inverse_std()
+                plan['keep'].append((inv, mean))
+                bn = _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
             gx, gy, rg = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-            status = lib.srgan_wgrad_group_plan(desc, bn, x_offset, gy_offset, gw.data_ptr(), len(layers),
-                                                ctypes.byref(slots, 128 * index), ctypes.byref(gx), ctypes.byref(gy),
-                                                ctypes.byref(rg))
+            status = lib.srgan_wgrad_group_plan(desc, bn, x_offset, gy_offset, gw.data_ptr() if tangent is None else None,
+                                                0 if tangent is None else tangent['offsets'][index][0 if size == 1 else 1],
+                                                len(layers), ctypes.byref(slots, 128 * index), ctypes.byref(gx),
+                                                ctypes.byref(gy), ctypes.byref(rg))
             if status != 0:
                 plans[key] = None
                 return None
@@ -163,6 +182,12 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device):
                           pixels=n * hw, elements=elements)
     plans[key] = plan
     return plan
+
+
+def _run_wgrad_group(group, size, fused_bn, x_base, gy_base, gw_base, stream):
+    F._call('srgan_wgrad_group_run', group['table'].data_ptr(), group['count'], size, group['grid_x'], group['grid_y'],
+            group['ragged'], 1 if fused_bn else 0, x_base.data_ptr(), gy_base.data_ptr(),
+            gw_base.data_ptr() if gw_base is not None else None, group['co_ci_taps'], group['pixels'], group['elements'], stream)
 
 
 def _tangent_plan(layers, c0, growth, device):
@@ -313,7 +338,9 @@ def dense_block(x, layers):
         grouped = None
         if GROUPED_WGRAD and want_params and prologue and not recorded and not overlap:
             grouped = _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device)
-        g_b1_all = _empty((len(layers), n, layers[0].conv1.out_channels, h, w), device) if grouped is not None else None
+        # (recorded: the double backward's grouped weight gradients index the kept gradients through one tensor, too)
+        one_tensor = grouped is not None or (recorded and GROUPED_WGRAD and prologue)
+        g_b1_all = _empty((len(layers), n, layers[0].conv1.out_channels, h, w), device) if one_tensor else None
         if overlap:
             main, side = torch.cuda.current_stream(device), _side_stream(device)
             wstream = _lib.stream_handle(side)
@@ -339,7 +366,7 @@ def dense_block(x, layers):
             elif want_params:
                 F._call('srgan_conv2d_bwd_weight', desc2, t2.data_ptr(), g_new, layer.conv2.weight.grad.data_ptr(), 1, 0,
                         stream)
-            g_b1 = g_b1_all[index] if grouped is not None else _empty(b1.shape, device)
+            g_b1 = g_b1_all[index] if g_b1_all is not None else _empty(b1.shape, device)
             if epilogue2 and plan is not None:
                 F._call('srgan_conv2d_bwd_data_bnrelu_partials', desc2, g_new, layer.conv2.weight.data_ptr(),
                         bn_struct(layer.norm2), b1.data_ptr(), g_b1.data_ptr(), _ptr(scratch, plan['offsets'][index][2]), 0, stream)
@@ -397,11 +424,8 @@ def dense_block(x, layers):
                 saved[index] = None
         if grouped is not None:
             # (the gradient slices of gbuf the 3x3 group reads are final: later layers only wrote channels below them)
-            for size, x_base, gy_base in ((3, b1_all, gbuf), (1, buffer, g_b1_all)):
-                group = grouped[size]
-                F._call('srgan_wgrad_group_run', group['table'].data_ptr(), group['count'], size, group['grid_x'],
-                        group['grid_y'], group['ragged'], x_base.data_ptr(), gy_base.data_ptr(), group['co_ci_taps'],
-                        group['pixels'], group['elements'], stream)
+            _run_wgrad_group(grouped[3], 3, True, b1_all, gbuf, None, stream)
+            _run_wgrad_group(grouped[1], 1, True, buffer, g_b1_all, None, stream)
         if plan is not None:
             F._call('srgan_bn_partial_reduce_batched', plan['jobs'].data_ptr(), plan['count'], plan['max_channels'],
                     plan['max_tiles'], scratch.data_ptr(), stream)
@@ -415,11 +439,11 @@ def dense_block(x, layers):
             gx = Var(gx_data)
             if recorded:
                 gx.requires_grad = True
-                gx.node = Node((g,) + tuple(parameter_vars), lambda v, needs2: double_backward(v, needs2, gbuf, kept),
+                gx.node = Node((g,) + tuple(parameter_vars), lambda v, needs2: double_backward(v, needs2, gbuf, kept, g_b1_all),
                                'dense_block_backward')
         return (gx,) + (None,) * len(parameter_vars)
 
-    def double_backward(v, needs2, gbuf, kept):
+    def double_backward(v, needs2, gbuf, kept, g_b1_all=None):
         """Backward of the recorded backward: v = dL/d(input gradient).  Returns dL/dg (the linearised forward of the
         block applied to v) and accumulates the weight / batch-norm-scale gradients into the gradient arena."""
         if grad_enabled():
@@ -438,6 +462,17 @@ def dense_block(x, layers):
         q_all = torch.zeros(tangent['total'], dtype=torch.float32, device=device) if want_params else None
         F._call('srgan_bn_conv_tangent_weights_grouped', tangent['table'].data_ptr(), tangent['count'], tangent['max_inner'],
                 tangent['max_co'], scaled_all.data_ptr(), None, stream)
+        # the plain weight gradients q of every layer: two grouped launches at the end, reading the masked tangents of all
+        # layers from two tensors (the per-layer launches otherwise)
+        grouped = None
+        if GROUPED_WGRAD and want_params and g_b1_all is not None:
+            grouped = _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent)
+            # (keeping every layer's u1 costs a second trip through HBM for it: worth it while the launches, not the
+            # bytes, bound the pass -- measured: a gain at 224 x 224, a loss for the larger blocks of 512 x 512)
+            if grouped is not None and 4 * grouped['u1_total'] > GROUPED_TANGENT_LIMIT:
+                grouped = None
+        u1_all = _empty((grouped['u1_total'],), device) if grouped is not None else None
+        u2_all = _empty((len(layers), n, layers[0].conv1.out_channels, h, w), device) if grouped is not None else None
         for index, layer in enumerate(layers):
             g_b1, b1 = kept[index]
             cin = c0 + index * growth
@@ -448,22 +483,26 @@ def dense_block(x, layers):
             desc1 = _desc(n, cin, h, w, width, 1, 1, 1, 0)
             desc2 = _desc(n, width, h, w, growth, 3, 3, 1, 1, 0, buffer_bs)
             # ---- batch-norm 1 + ReLU, linearised: masked (unscaled) tangent; the scale is in the weights
-            u1 = _empty((n, cin, h, w), device)
-            F._call('srgan_bn_act_bwd', vbuf.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, u1.data_ptr(),
+            u1 = _empty((n, cin, h, w), device) if grouped is None else None
+            u1_ptr = u1.data_ptr() if grouped is None else _ptr(u1_all, grouped['u1_offsets'][index])
+            F._call('srgan_bn_act_bwd', vbuf.data_ptr(), buffer.data_ptr(), mean1, inv1, gamma1, beta1, 1, u1_ptr,
                     None, None, n, cin, hw, buffer_bs, buffer_bs, 0, 0, 1, stream)
-            if want_params:
-                F._call('srgan_conv2d_bwd_weight', desc1, u1.data_ptr(), g_b1.data_ptr(), _ptr(q_all, at1), 1, 0, stream)
+            if want_params and grouped is None:
+                F._call('srgan_conv2d_bwd_weight', desc1, u1_ptr, g_b1.data_ptr(), _ptr(q_all, at1), 1, 0, stream)
             b1_tangent = _empty(b1.shape, device)
-            F._call('srgan_conv2d_fwd', desc1, u1.data_ptr(), _ptr(scaled_all, at1), None, b1_tangent.data_ptr(), 0, stream)
+            F._call('srgan_conv2d_fwd', desc1, u1_ptr, _ptr(scaled_all, at1), None, b1_tangent.data_ptr(), 0, stream)
             del u1
             # ---- batch-norm 2 + ReLU, linearised
-            u2 = _empty(b1.shape, device)
+            u2 = u2_all[index] if grouped is not None else _empty(b1.shape, device)
             F._call('srgan_bn_act_bwd', b1_tangent.data_ptr(), b1.data_ptr(), mean2, inv2, gamma2, beta2, 1, u2.data_ptr(),
                     None, None, n, width, hw, 0, 0, 0, 0, 1, stream)
-            if want_params:
+            if want_params and grouped is None:
                 F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), _ptr(q_all, at2), 1, 0, stream)
             F._call('srgan_conv2d_fwd', desc2, u2.data_ptr(), _ptr(scaled_all, at2), None, _ptr(vbuf, cin * hw), 0, stream)
             kept[index] = None
+        if grouped is not None:
+            _run_wgrad_group(grouped[1], 1, False, u1_all, g_b1_all, q_all, stream)
+            _run_wgrad_group(grouped[3], 3, False, u2_all, gbuf, q_all, stream)
         if want_params:                                 # dL/dW += q * a;  dL/dgamma += inv_std * sum_co W * q   (a = inv_std * gamma)
             F._call('srgan_bn_conv_tangent_weights_grouped', tangent['table'].data_ptr(), tangent['count'],
                     tangent['max_inner'], tangent['max_co'], None, q_all.data_ptr(), stream)
