@@ -266,6 +266,18 @@ int srgan_copy_channels(const float* src, int32_t src_channels, int32_t src_firs
 
 /* ---- pooling (planes = N*C) --------------------------------------------------------------------------------
  * reference crowd/models.py:371,1075,1151; age/vgg.py:76. */
+/* The DenseNet stem's norm0 -> relu0 -> pool0 (reference crowd/models.py:1072-1076) as ONE pass each way: forward
+ * y = maxpool(relu(batch_norm_eval(x))) with the arg-max of srgan_maxpool2d_fwd; backward gx = S * [bn(x) > 0] * inv_std *
+ * gamma with S the pooled gradient gathered per input pixel, g_gamma / g_beta (both or neither) ADDED to.  The backward
+ * exists for 3 / 2 / 1 windows on rows of whole float4s (`_supported`). */
+int srgan_bn_relu_maxpool_fwd(const float* x, const float* mean, const float* inv_std, const float* gamma, const float* beta,
+                              float* y, int32_t* argmax, int32_t N, int32_t C, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p,
+                              int32_t OH, int32_t OW, void* stream);
+int srgan_bn_relu_maxpool_bwd_supported(int32_t N, int32_t C, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p);
+int srgan_bn_relu_maxpool_bwd(const float* gy, const int32_t* argmax, const float* x, const float* mean, const float* inv_std,
+                              const float* gamma, const float* beta, float* gx, float* g_gamma, float* g_beta, int32_t N,
+                              int32_t C, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p, int32_t OH, int32_t OW,
+                              void* stream);
 int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t planes, int32_t H, int32_t W, int32_t k,
                         int32_t s, int32_t p, int32_t OH, int32_t OW, void* stream);
 int srgan_maxpool2d_bwd(const float* g, const int32_t* argmax, float* gx, int32_t planes, int32_t H, int32_t W, int32_t k,

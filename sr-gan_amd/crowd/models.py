@@ -15,6 +15,9 @@ from ..age.models import Generator as _DCGANGenerator, convolution, LEAK
 from ..utility import seed_all
 
 
+FUSED_STEM_POOL = True     # norm0 -> relu0 -> pool0 of the DenseNet stem as one pass each way (functional.bn_relu_max_pool2d)
+
+
 class DCGenerator(_DCGANGenerator):
     """reference crowd/models.py:127-147 (defaults to 224x224)."""
 
@@ -240,7 +243,14 @@ class KnnDenseNetCat(nn.Module):
         vectors."""
         batch_size = x.shape[0]
         stem = self.conv_layer1
-        out = stem.pool0(stem.norm0(stem.conv0(x), relu=True))
+        out, first = None, stem.conv0(x)
+        if FUSED_STEM_POOL and isinstance(stem.pool0.kernel_size, int):
+            inv_std, mean = stem.norm0._inverse_std()
+            out = F.bn_relu_max_pool2d(first, mean, inv_std, nn.parameter_var(stem.norm0.weight),
+                                       nn.parameter_var(stem.norm0.bias), stem.pool0.kernel_size, stem.pool0.stride,
+                                       stem.pool0.padding)
+        if out is None:
+            out = stem.pool0(stem.norm0(first, relu=True))
         t1_out = self.transition_layers.transition1(self.dense_blocks.denseblock1(out))
         t2_out = self.transition_layers.transition2(self.dense_blocks.denseblock2(t1_out))
         t3_out = self.transition_layers.transition3(self.dense_blocks.denseblock3(t2_out))

@@ -109,6 +109,108 @@ __global__ __launch_bounds__(256) void maxpool_bwd_quad_kernel(const float* __re
   }
 }
 
+// DenseNet stem, norm0 -> relu0 -> pool0 (reference crowd/models.py:1072-1076) in one pass: y = maxpool(relu(fma(x, a, b)))
+// with the frozen batch-norm folded into (a, b) per channel; the activated tensor (4 x the pooled one) never exists.
+// Same scan order and tie rule as maxpool_fwd_kernel, so the arg-max equals the two-kernel form's.
+template <typename I>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                  const float* __restrict__ inv_std,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ y,
+                                                                  int32_t* __restrict__ idx, int C, int H, int W, int k, int s,
+                                                                  int p, int OH, int OW, int64_t n) {
+  const I stride = (I)gridDim.x * 256, count = (I)n, plane_out = (I)OW * OH;
+  for (I o = (I)blockIdx.x * 256 + threadIdx.x; o < count; o += stride) {
+    const I plane = o / plane_out, rest = o - plane * plane_out;
+    const int oh = (int)(rest / OW), ow = (int)(rest - (I)oh * OW);
+    const int c = (int)(plane % (I)C);
+    float a, b;
+    bn_coefficients(mean[c], inv_std[c], gamma[c], beta[c], a, b);
+    const float* src = x + (int64_t)plane * H * W;
+    const int h0 = oh * s - p, w0 = ow * s - p;
+    float best = -INFINITY;
+    int best_i = -1;
+    for (int r = 0; r < k; ++r) {
+      const int h = h0 + r;
+      if (h < 0 || h >= H) continue;
+      for (int q = 0; q < k; ++q) {
+        const int w = w0 + q;
+        if (w < 0 || w >= W) continue;
+        const float v = fmaxf(fmaf(src[h * W + w], a, b), 0.f);
+        if (v > best || best_i < 0 || v != v) { best = v; best_i = h * W + w; }
+      }
+    }
+    y[o] = best;
+    idx[o] = best_i;
+  }
+}
+
+// Its whole backward in one pass over (gy, argmax, x): the pooled gradient gathered per input pixel (as in
+// maxpool_bwd_quad_kernel), masked by the recomputed activation and scaled -- gx = S * [fma(x, a, b) > 0] * a -- and both
+// parameter sums (beta: sum of the masked S; gamma: inv_std * sum of masked S * (x - mean)) reduced per workgroup and
+// added atomically.  One workgroup = QUADS_PER_BLOCK float4 of ONE plane (blockIdx.y), so a block's sums are one channel's.
+constexpr int POOL_BWD_QUADS = 1024;
+template <int K, int S, int P>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx,
+                                                                  const float* __restrict__ x, const float* __restrict__ mean,
+                                                                  const float* __restrict__ inv_std,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ gx,
+                                                                  float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                                  int C, int H, int W, int OH, int OW) {
+  constexpr int SPAN = (3 + P) / S - (P - K + 1 > 0 ? (P - K + 1 + S - 1) / S : 0) + 2;
+  __shared__ float scratch[2][4];
+  const uint32_t plane = blockIdx.y, w4 = (uint32_t)W >> 2, plane_quads = (uint32_t)H * w4;
+  const int c = (int)(plane % (uint32_t)C);
+  float a, b;
+  const float mu = mean[c];
+  bn_coefficients(mu, inv_std[c], gamma[c], beta[c], a, b);
+  const float* src = g + (int64_t)plane * OH * OW;
+  const int32_t* chosen = idx + (int64_t)plane * OH * OW;
+  float sum_plain = 0.f, sum_centred = 0.f;
+  const uint32_t first = blockIdx.x * POOL_BWD_QUADS;
+  for (uint32_t q = first + threadIdx.x; q < min(first + POOL_BWD_QUADS, plane_quads); q += 256u) {
+    const int h = (int)(q / w4);
+    const int w0 = (int)(q - (uint32_t)h * w4) * 4;
+    int oh_lo = h + P - K + 1; oh_lo = oh_lo > 0 ? (oh_lo + S - 1) / S : 0;
+    int oh_hi = (h + P) / S; if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_lo = w0 + P - K + 1; ow_lo = ow_lo > 0 ? (ow_lo + S - 1) / S : 0;
+    int ow_hi = (w0 + 3 + P) / S; if (ow_hi > OW - 1) ow_hi = OW - 1;
+    const int32_t me = h * W + w0;
+    const int64_t at = ((int64_t)plane * H + h) * W + w0;
+    const float4 xv = *reinterpret_cast<const float4*>(x + at);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+#pragma unroll
+      for (int j = 0; j < SPAN; ++j) {
+        const int ow = ow_lo + j;
+        if (ow > ow_hi) break;
+        const int32_t d = chosen[oh * OW + ow] - me;   // 0 .. 3 when the window chose one of this thread's pixels
+        if ((uint32_t)d < 4u) {
+          const float v = src[oh * OW + ow];
+          acc[0] += d == 0 ? v : 0.f; acc[1] += d == 1 ? v : 0.f; acc[2] += d == 2 ? v : 0.f; acc[3] += d == 3 ? v : 0.f;
+        }
+      }
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = fmaf(xs[j], a, b) > 0.f ? acc[j] : 0.f;
+      sum_plain += acc[j];
+      sum_centred = fmaf(acc[j], xs[j] - mu, sum_centred);
+    }
+    *reinterpret_cast<float4*>(gx + at) = make_float4(acc[0] * a, acc[1] * a, acc[2] * a, acc[3] * a);
+  }
+  if (g_gamma == nullptr) return;
+  const float plain = wave_sum(sum_plain), centred = wave_sum(sum_centred);
+  const int wave = (int)threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { scratch[0][wave] = plain; scratch[1][wave] = centred; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(g_beta + c, (scratch[0][0] + scratch[0][1]) + (scratch[0][2] + scratch[0][3]));
+    unsafeAtomicAdd(g_gamma + c, ((scratch[1][0] + scratch[1][1]) + (scratch[1][2] + scratch[1][3])) * inv_std[c]);
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                           float* __restrict__ out, int64_t in_plane, int64_t out_plane,
                                                           int64_t n) {
@@ -174,6 +276,44 @@ int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t plane
   else
     hipLaunchKernelGGL(maxpool_fwd_kernel<int64_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                        argmax, H, W, k, s, p, OH, OW, n);
+  return launch_status();
+}
+
+int srgan_bn_relu_maxpool_fwd(const float* x, const float* mean, const float* inv_std, const float* gamma, const float* beta,
+                              float* y, int32_t* argmax, int32_t N, int32_t C, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p,
+                              int32_t OH, int32_t OW, void* stream) {
+  SRGAN_REQUIRE(x && mean && inv_std && gamma && beta && y && argmax && N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && s > 0 &&
+                p >= 0 && OH > 0 && OW > 0, SRGAN_EINVAL, "srgan_bn_relu_maxpool_fwd arguments");
+  SRGAN_REQUIRE((OH - 1) * s - p < H && (OW - 1) * s - p < W && p < k, SRGAN_EINVAL, "srgan_bn_relu_maxpool_fwd geometry");
+  const int64_t n = (int64_t)N * C * OH * OW;
+  if (n < ((int64_t)1 << 31) - ((int64_t)2048 * 256) && (int64_t)N * C * H * W < ((int64_t)1 << 31))
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<uint32_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       mean, inv_std, gamma, beta, y, argmax, C, H, W, k, s, p, OH, OW, n);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<int64_t>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       mean, inv_std, gamma, beta, y, argmax, C, H, W, k, s, p, OH, OW, n);
+  return launch_status();
+}
+
+// 1 when srgan_bn_relu_maxpool_bwd has this geometry (3 / 2 / 1 windows on rows of whole float4s)
+int srgan_bn_relu_maxpool_bwd_supported(int32_t N, int32_t C, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p) {
+  return (k == 3 && s == 2 && p == 1 && W % 4 == 0 && (int64_t)N * C <= 65535 &&
+          (int64_t)N * C * H * W < ((int64_t)1 << 31)) ? 1 : 0;
+}
+
+int srgan_bn_relu_maxpool_bwd(const float* gy, const int32_t* argmax, const float* x, const float* mean, const float* inv_std,
+                              const float* gamma, const float* beta, float* gx, float* g_gamma, float* g_beta, int32_t N,
+                              int32_t C, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p, int32_t OH, int32_t OW,
+                              void* stream) {
+  SRGAN_REQUIRE(gy && argmax && x && mean && inv_std && gamma && beta && gx && OH > 0 && OW > 0, SRGAN_EINVAL,
+                "srgan_bn_relu_maxpool_bwd arguments");
+  SRGAN_REQUIRE((g_gamma == nullptr) == (g_beta == nullptr), SRGAN_EINVAL, "srgan_bn_relu_maxpool_bwd parameter outputs");
+  SRGAN_REQUIRE(srgan_bn_relu_maxpool_bwd_supported(N, C, H, W, k, s, p) && ((((uintptr_t)x | (uintptr_t)gx) & 15) == 0),
+                SRGAN_EUNSUPPORTED, "srgan_bn_relu_maxpool_bwd geometry");
+  const uint32_t plane_quads = (uint32_t)H * ((uint32_t)W >> 2);
+  dim3 grid((plane_quads + POOL_BWD_QUADS - 1) / POOL_BWD_QUADS, (unsigned)(N * C), 1);
+  hipLaunchKernelGGL((bn_relu_maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, gy, argmax, x, mean, inv_std,
+                     gamma, beta, gx, g_gamma, g_beta, C, H, W, OH, OW);
   return launch_status();
 }
 

@@ -673,6 +673,47 @@ def max_pool2d(x, kernel_size, stride, padding=0):
     return _out(data, (x,), lambda g, needs: (_max_pool2d_backward(g, argmax, in_shape, geometry),), 'max_pool2d')
 
 
+def bn_relu_max_pool2d(x, mean, inv_std, gamma, beta, kernel_size, stride, padding=0):
+    """``max_pool2d(relu(batch_norm_eval(x)))`` as ONE pass (the DenseNet stem's norm0 -> relu0 -> pool0, reference
+    crowd/models.py:1072-1076): the activated tensor -- four times the pooled one -- is never written.  First-order
+    backward: one pass as well (`srgan_bn_relu_maxpool_bwd`: pooled gradient gathered per pixel, mask, scale, both
+    parameter sums).  A RECORDED backward (gradient penalty) re-evaluates the two-op form and differentiates that, so
+    second order costs what it did.  Returns None when the backward kernel does not have the geometry."""
+    n, c, h, w = x.shape
+    if not _lib.library().srgan_bn_relu_maxpool_bwd_supported(n, c, h, w, kernel_size, stride, padding):
+        return None
+    oh = (h + 2 * padding - kernel_size) // stride + 1
+    ow = (w + 2 * padding - kernel_size) // stride + 1
+    data = _empty((n, c, oh, ow), x.data)
+    argmax = torch.empty((n, c, oh, ow), dtype=torch.int32, device=x.data.device)
+    _call('srgan_bn_relu_maxpool_fwd', _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma), _ptr(beta), data.data_ptr(),
+          argmax.data_ptr(), n, c, h, w, kernel_size, stride, padding, oh, ow, _stream())
+    out = _out(data, (x, gamma, beta), None, 'bn_relu_max_pool2d')
+    if out.node is None:
+        return out
+
+    def backward(g, needs):
+        if grad_enabled():
+            from .tape import backward as sweep
+            pooled = max_pool2d(batch_norm_eval(x, mean, inv_std, gamma, beta, relu=True), kernel_size, stride, padding)
+            wanted = [v for v, need in zip((x, gamma, beta), needs) if need]
+            grads = iter(sweep(pooled, grad=g, inputs=wanted, create_graph=True))
+            return tuple(next(grads) if need else None for need in needs)
+        want_params = needs[1] or needs[2]
+        direct = needs[1] and needs[2] and accumulates_into(gamma) and accumulates_into(beta)
+        both = _zeros((2, c), x.data) if want_params and not direct else None
+        into_gamma = gamma.grad_buffer.data_ptr() if direct else (both[0].data_ptr() if want_params else None)
+        into_beta = beta.grad_buffer.data_ptr() if direct else (both[1].data_ptr() if want_params else None)
+        gx_data = _empty(x.shape, x.data)
+        _call('srgan_bn_relu_maxpool_bwd', _ptr(g), argmax.data_ptr(), _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma),
+              _ptr(beta), gx_data.data_ptr(), into_gamma, into_beta, n, c, h, w, kernel_size, stride, padding, oh, ow, _stream())
+        ggamma = Var(both[0]) if want_params and not direct else None
+        gbeta = Var(both[1]) if want_params and not direct else None
+        return (Var(gx_data) if needs[0] else None), ggamma, gbeta
+    out.node.backward = backward
+    return out
+
+
 def _max_pool2d_backward(g, argmax, in_shape, geometry):
     """Gather form (every input element written once: no zero-fill, no atomics); its own backward is the gather of
     the incoming tensor at the forward's arg-max, as for the scatter form."""

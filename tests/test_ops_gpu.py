@@ -777,3 +777,43 @@ def test_crowd_offline_labels(F):
     distances = torch.cdist(torch.stack([ys.reshape(-1), xs.reshape(-1)], 1).double(), heads.double())
     expected = 1 / (distances.topk(4, dim=1, largest=False).values.mean(1).reshape(96, 128) + 1)
     close(generate_iknn_map(heads.numpy(), (96, 128), number_of_neighbors=4), expected, 1e-5, 'large scene i4nn map')
+
+
+@gpu
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16), (3, 5, 10, 12), (2, 64, 56, 56)])
+def test_fused_stem_norm_relu_pool(F, shape):
+    """functional.bn_relu_max_pool2d (norm0 -> relu0 -> pool0 in one pass each way) against the two-op form: output,
+    first-order gradients of x / gamma / beta, and the recorded (gradient-penalty) route through it."""
+    from srgan_amd.tape import backward
+    gen = torch.Generator().manual_seed(41)
+    n, c, h, w = shape
+    x_host = torch.randn(n, c, h, w, generator=gen)
+    stats = dict(mean=torch.randn(c, generator=gen) * 0.3, inv=(torch.rand(c, generator=gen) + 0.5).rsqrt(),
+                 gamma=torch.rand(c, generator=gen) + 0.5, beta=torch.randn(c, generator=gen) * 0.3)
+    oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    cotangent = torch.randn(n, c, oh, ow, generator=gen)
+    results = {}
+    for fused_form in (False, True):
+        x = F.leaf(dev(x_host), requires_grad=True)
+        gamma, beta = F.leaf(dev(stats['gamma']), requires_grad=True), F.leaf(dev(stats['beta']), requires_grad=True)
+        mean, inv = F.constant(dev(stats['mean'])), F.constant(dev(stats['inv']))
+        def forward(x):
+            if fused_form:
+                y = F.bn_relu_max_pool2d(x, mean, inv, gamma, beta, 3, 2, 1)
+                assert y is not None
+                return y
+            return F.max_pool2d(F.batch_norm_eval(x, mean, inv, gamma, beta, relu=True), 3, 2, 1)
+        y = forward(x)
+        backward(y, grad=F.leaf(dev(cotangent)))
+        first = (y.cpu(), x.grad.cpu(), gamma.grad.cpu(), beta.grad.cpu())
+        # second order: a function of the recorded input gradient, back to gamma and x
+        x2 = F.leaf(dev(x_host), requires_grad=True)
+        gamma.grad = beta.grad = None
+        scalar = F.sum_all(F.mul(forward(x2), F.leaf(dev(cotangent))))
+        (gx,) = backward(scalar, inputs=[x2], create_graph=True)
+        penalty = F.mean_all(F.square(F.add_scalar(F.row_norm(F.flatten2d(gx)), -1.0)))
+        backward(penalty)
+        results[fused_form] = first + (gx.cpu(), gamma.grad.cpu())
+    for i, what in enumerate(('output', 'input gradient', 'gamma gradient', 'beta gradient', 'recorded input gradient',
+                              'penalty gamma gradient')):
+        close(results[True][i], results[False][i], 1e-5, 'fused stem pool: ' + what)
