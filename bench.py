@@ -79,6 +79,10 @@ def parse():
     parser.add_argument('--overlap-dnn', action='store_true',
                         help='enqueue the DNN step on a second stream (faster step, per-kernel timings not attributable)')
     parser.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL)')
+    parser.add_argument('--force-dp', action='store_true',
+                        help='keep the data-parallel path on at world size 1: the feature-sum all-reduce, the asynchronous '
+                             'gradient buckets and the broadcasts go through --backend on ONE rank (first contact with '
+                             'RCCL on a one-GPU box)')
     parser.add_argument('--single-device', action='store_true',
                         help='testing aid: every rank uses cuda:0 (with --backend gloo on a one-GPU box)')
     parser.add_argument('--shape-report', default=None, help='write the per-shape contraction timing table here')
@@ -145,7 +149,7 @@ def build_experiment(args, dp):
     experiment.train_mode()
     experiment.dnn_summary_writer = SummaryWriter(summary_period=10 ** 9)    # no host syncs inside timed steps
     experiment.gan_summary_writer = SummaryWriter(summary_period=10 ** 9)
-    if dp is not None and dp.world_size > 1:
+    if dp is not None and dp.active:
         for module in (experiment.D, experiment.DNN, experiment.G):
             dp.broadcast_parameters(module._srgan_arena)
     return experiment
@@ -347,10 +351,20 @@ def main():
     local_rank = 0 if args.single_device else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dp = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import srgan_amd  # noqa: F401
         from srgan_amd.parallel import DataParallel
-        dp = DataParallel.from_environment(args.backend)
+        if world == 1:                       # a world of one needs no launcher: rendezvous with ourselves on 127.0.0.1
+            import socket
+            with socket.socket() as probe:
+                probe.bind(('127.0.0.1', 0))
+                free_port = probe.getsockname()[1]
+            for key, value in (('RANK', '0'), ('WORLD_SIZE', '1'), ('LOCAL_RANK', '0'), ('MASTER_ADDR', '127.0.0.1'),
+                               ('MASTER_PORT', str(args.master_port or free_port))):
+                os.environ.setdefault(key, value)
+        dp = DataParallel.from_environment(args.backend, force=args.force_dp)
+        if args.force_dp:
+            dp.broadcast_object({'hello': args.backend})     # the object broadcast of Experiment.train(), through the backend
     rank = dp.rank if dp else 0
     experiment = build_experiment(args, dp)
     labeled = experiment.infinite_iter(experiment.train_dataset_loader)
@@ -399,7 +413,7 @@ def main():
                                f'batch {args.batch_per_gpu}/GPU, dnn_training_step + gan_training_step per step',
                    'global_batch': global_batch, 'image_size': args.image_size,
                    'schedule': 'reference' if args.reference_schedule else 'shared-forwards',
-                   'parallelism': f'dp{world}', 'random_init_weights': True,
+                   'parallelism': f'dp{world}' + (' (data-parallel exchanges forced on)' if args.force_dp else ''), 'random_init_weights': True,
                    'gradient_penalty': 'active' if penalty > 0.0 else 'inactive', 'gradient_penalty_last': penalty,
                    'discriminator_weight_scale': gp_scale(args)},
     }

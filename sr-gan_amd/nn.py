@@ -51,8 +51,16 @@ class BatchNorm2d(nn.BatchNorm2d):
         cached = getattr(self, '_inv_std_cache', None)
         if cached is None or cached[0] != key:
             variance = self.running_var.detach().contiguous()
-            inv = F._unary_raw(F.U_RSQRT, F._unary_raw(F.U_AFFINE, variance, 1.0, self.eps))
-            cached = (key, Var(inv), Var(self.running_mean.detach().contiguous()))
+            if cached is not None and cached[1].data.shape == variance.shape and cached[1].data.device == variance.device:
+                # New statistics (load_state_dict, load_models): refreshed IN PLACE.  The grouped launch tables of
+                # fused.py and a captured HIP graph hold the raw device pointers of these two tensors.
+                inv, mean = cached[1], cached[2]
+                F._unary_raw(F.U_RSQRT, F._unary_raw(F.U_AFFINE, variance, 1.0, self.eps, out=inv.data), out=inv.data)
+                mean.data.copy_(self.running_mean.detach())
+            else:
+                inv = Var(F._unary_raw(F.U_RSQRT, F._unary_raw(F.U_AFFINE, variance, 1.0, self.eps)))
+                mean = Var(self.running_mean.detach().clone().contiguous())      # a copy we own: its address never moves
+            cached = (key, inv, mean)
             self._inv_std_cache = cached
         return cached[1], cached[2]
 

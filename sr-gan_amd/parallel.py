@@ -83,15 +83,25 @@ class _AllReduceSum(torch.autograd.Function):
 
 
 class DataParallel:
-    def __init__(self, group=None):
+    force = False
+
+    def __init__(self, group=None, force=None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        # ``force``: run every exchange even on a world of one (SRGAN_FORCE_DP=1, ``bench.py --force-dp``).  Two ranks
+        # cannot share a device under RCCL, one rank can: this is how a one-GPU box pushes the feature-sum all-reduce, the
+        # asynchronous gradient buckets, their stream-side ``wait()`` and the broadcasts through the nccl backend.
+        self.force = bool(int(os.environ.get('SRGAN_FORCE_DP', '0'))) if force is None else bool(force)
+
+    @property
+    def active(self):
+        return self.world_size > 1 or self.force
 
     @classmethod
-    def from_environment(cls, backend=None):
+    def from_environment(cls, backend=None, force=None):
         """Initialise from RANK / WORLD_SIZE / MASTER_* (torchrun); ``nccl`` (= RCCL) when a GPU is present."""
         if not dist.is_initialized():
             if backend is None:
@@ -99,7 +109,7 @@ class DataParallel:
             if backend == 'nccl' and 'LOCAL_RANK' in os.environ and torch.cuda.device_count() > 1:
                 torch.cuda.set_device(int(os.environ['LOCAL_RANK']))
             dist.init_process_group(backend=backend)
-        return cls()
+        return cls(force=force)
 
     # ---- batch bookkeeping -----------------------------------------------------------------------------
     def global_batch(self, local_batch):

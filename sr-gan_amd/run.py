@@ -94,7 +94,11 @@ def main():
     method_name = MethodName(os.environ.get('SRGAN_METHOD', 'srgan'))
     experiment_class, settings_ = build_settings(application_name, method_name)
     dp = None
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    force_dp = bool(int(os.environ.get('SRGAN_FORCE_DP', '0')))       # the collective path on a world of one
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or force_dp:
+        if force_dp:
+            for key, value in (('RANK', '0'), ('WORLD_SIZE', '1'), ('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533')):
+                os.environ.setdefault(key, value)
         from .parallel import DataParallel
         dp = DataParallel.from_environment()
     settings_list = convert_to_settings_list(settings_, shuffle=dp is None)   # ranks must agree on the order

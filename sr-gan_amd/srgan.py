@@ -86,6 +86,13 @@ class Experiment(ABC):
         self.injected_draws = None     # tests: dict with 'z_d', 'z_g', 'alpha' device/CPU tensors, used once
         self.last_losses = {}          # device scalars of the latest step (no host sync)
 
+    @property
+    def parallel(self):
+        """True when the data-parallel exchanges run: more than one rank, or one rank with ``dp.force`` (the whole
+        collective path -- feature sums, bucketed gradient exchange, broadcasts -- on a world of one: how the RCCL
+        backend is exercised on a one-GPU box, ``bench.py --force-dp``)."""
+        return self.dp is not None and self.dp.active
+
     # ------------------------------------------------------------------------------------------ lifecycle
     def _trial_decision(self):
         """What reference srgan.py:54-70 decides from the file system before a trial starts: skip it, its (unique)
@@ -114,7 +121,7 @@ class Experiment(ABC):
     def train(self):
         """Run the SRGAN training for the experiment (reference srgan.py:52-86)."""
         settings = self.settings
-        parallel = self.dp is not None and self.dp.world_size > 1
+        parallel = self.parallel
         if parallel and settings.batch_size % self.dp.world_size:
             raise ValueError(f'batch_size {settings.batch_size} is the GLOBAL batch and must be divisible by the '
                              f'{self.dp.world_size} data-parallel ranks')
@@ -203,7 +210,7 @@ class Experiment(ABC):
         ``settings.step_graph`` on a single device the iteration is captured once as a HIP graph and replayed
         (``graph.CapturedIteration``); summary steps and the first ``settings.step_graph_warmup`` iterations run eagerly."""
         if getattr(self.settings, 'step_graph', False) and examples_on_gpu() and \
-                (self.dp is None or self.dp.world_size == 1):
+                not self.parallel:
             if getattr(self, '_captured_iteration', None) is None:
                 from .graph import CapturedIteration
                 self._captured_iteration = CapturedIteration(self)
@@ -255,7 +262,7 @@ class Experiment(ABC):
         """Acts on 'save' / 'quit' (reference srgan.py:149-163).  Under data parallelism rank 0 reads stdin and the ranks
         exchange what it saw every ``USER_INPUT_EXCHANGE_PERIOD`` steps, so that all of them save / stop together
         (one rank leaving the loop alone would leave the others hanging in their next collective)."""
-        parallel = self.dp is not None and self.dp.world_size > 1
+        parallel = self.parallel
         if not parallel:
             commands = self._poll_stdin()
         else:
@@ -340,7 +347,7 @@ class Experiment(ABC):
         """Under data parallelism every rank draws the tensor for the GLOBAL batch from its (identically seeded) host
         stream and keeps its own shard: the ranks' examples differ, and together they are exactly what the
         single-device reference draws at the global batch size."""
-        if self.dp is None or self.dp.world_size == 1:
+        if not self.parallel:
             return draw(local_batch)
         return self.dp.shard(draw(self.dp.global_batch(local_batch)))
 
@@ -378,7 +385,7 @@ class Experiment(ABC):
     def batch_mean_of_features(self, features):
         """Mean over the (global) batch -> shape features.shape[1:] (the ``mean(0)`` of srgan.py:442-443)."""
         sums = F.col_sum(features)
-        if self.dp is not None and self.dp.world_size > 1:
+        if self.parallel:
             sums = self.dp.all_reduce_sum_var(sums)
         return F.scale(sums, 1.0 / self._global_batch(features.shape[0]))
 
@@ -428,7 +435,7 @@ class Experiment(ABC):
     def gradient_exchange(self, module):
         """The asynchronous all-reduce of ``module``'s gradient arena for the LAST backward pass into it (handed to
         ``tape.backward(grad_ready=...)``); None on a single device."""
-        if self.dp is None or self.dp.world_size == 1:
+        if not self.parallel:
             return None
         return self.dp.gradient_exchange(module._srgan_arena)
 
@@ -567,13 +574,13 @@ class Experiment(ABC):
     def loss_value(self, loss, partial=False):
         """Host value of a device scalar; ``partial`` scalars are per-rank partial sums under data parallelism."""
         value = float(loss.item())
-        if partial and self.dp is not None and self.dp.world_size > 1:
+        if partial and self.parallel:
             value = self.dp.all_reduce_sum_float(value)
         return value
 
     def synchronize_gradients(self, module):
         """Blocking form of the gradient exchange (methods that do not overlap it: the DNN-only experiment)."""
-        if self.dp is not None and self.dp.world_size > 1:
+        if self.parallel:
             self.dp.all_reduce_gradients(module._srgan_arena)
 
     def discriminator_losses_shared_forwards(self, labeled_examples, labels, unlabeled_examples, fake_examples):
@@ -776,7 +783,7 @@ class Experiment(ABC):
             # The reference's branch AS WRITTEN (srgan.py:444-447): the base mean is divided by its norm, but line 447
             # divides the un-meaned ``other_features`` (B, F) by the norm of their mean, so the difference broadcasts to
             # (B, F) and the distance function averages over examples as well.  Off by default (settings.py:39).
-            if self.dp is not None and self.dp.world_size > 1:
+            if self.parallel:
                 raise NotImplementedError('normalize_feature_norm=True averages over the (B, F) broadcast of the '
                                           'reference (srgan.py:447); it is single-device only')
             epsilon = 1e-5

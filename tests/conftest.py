@@ -22,3 +22,17 @@ def pytest_sessionstart(session):
             _build.build()
     except Exception as error:           # the tests that need the library then report the real problem
         print(f'[conftest] could not build libsrgan_hip.so: {error}', file=sys.stderr)
+
+
+# Facts a reader of the `-q` tail needs (which batch the bench-size parity test really ran at, which collective backends
+# ran): tests append lines here and the terminal summary prints them after the pass / fail counts.
+PARITY_NOTES = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    for line in PARITY_NOTES:
+        terminalreporter.write_line('[parity] ' + line)
+    skipped = terminalreporter.stats.get('skipped', [])
+    for report in skipped:                                   # a skip is never silent, even under -q
+        reason = report.longrepr[2] if isinstance(report.longrepr, tuple) else str(report.longrepr)
+        terminalreporter.write_line(f'[skipped] {report.nodeid}: {reason}')

@@ -197,3 +197,46 @@ def test_noise_draws_under_data_parallelism_are_shards_of_the_global_draw():
     halves = [draw(rank, 2) for rank in range(2)]
     assert halves[0].shape == (4, 4) and not torch.equal(halves[0], halves[1])
     assert torch.equal(torch.cat(halves), whole)
+
+
+def _forced_worker(port, queue):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    torch.set_num_threads(1)
+    import srgan_amd  # noqa: F401
+    from srgan_amd.parallel import DataParallel
+    from srgan_amd.srgan import Experiment
+    from srgan_amd.settings import Settings
+
+    class Bare(Experiment):
+        def dataset_setup(self): pass
+        def model_setup(self): pass
+        def validation_summaries(self, step): pass
+    plain, forced = DataParallel.from_environment('gloo'), DataParallel(force=True)
+    experiment = Bare(Settings())
+    experiment.dp = plain
+    on_plain = experiment.parallel
+    experiment.dp = forced
+    flat = torch.arange(100, dtype=torch.float32)
+
+    class Arena:
+        grad = flat
+    exchange = forced.gradient_exchange(Arena)
+    exchange.finish().wait()
+    queue.put((plain.active, on_plain, forced.active, experiment.parallel, exchange.launched, flat.tolist() == list(range(100)),
+               forced.broadcast_object({'step': 3}), forced.all_reduce_sum_float(2.5)))
+    forced.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_a_world_of_one_runs_the_exchanges_only_when_forced():
+    """``DataParallel(force=True)`` / SRGAN_FORCE_DP=1 / ``bench.py --force-dp``: on ONE rank the collective path stays on
+    (this is how a one-GPU box exercises the nccl backend); without it a world of one takes the single-device path."""
+    context = mp.get_context('spawn')
+    queue = context.Queue()
+    worker = context.Process(target=_forced_worker, args=(_free_port(), queue))
+    worker.start()
+    plain_active, plain_parallel, forced_active, forced_parallel, launched, unchanged, message, total = queue.get(timeout=120)
+    worker.join(timeout=60)
+    assert worker.exitcode == 0
+    assert (plain_active, plain_parallel, forced_active, forced_parallel) == (False, False, True, True)
+    assert launched == [(0, 100)] and unchanged and message == {'step': 3} and total == 2.5

@@ -1,7 +1,13 @@
-"""World size 2 on ONE GPU (gloo moves the device tensors) for the HIP engine's data-parallel path: two ranks,
-each with half of the global batch, must reproduce the single-process training step on the whole batch -- logged
-losses and the post-Adam weights of all three networks.  (The driver's multi-GPU runs use the same code over RCCL;
-this test needs only the one GPU of the test box.)"""
+"""The HIP engine's data-parallel path on the test box's GPU(s).
+
+* World size 2: two ranks, each with half of the global batch, must reproduce the single-process training step on the
+  whole batch -- logged losses and the post-Adam weights of all three networks.  Over ``gloo`` both ranks share cuda:0
+  (gloo moves the device tensors through the host); over ``nccl`` (= RCCL) each rank needs its own device, so that case
+  is skipped -- visibly -- on a one-GPU box.
+* World size 1 over ``nccl`` with the exchanges forced on (``DataParallel(force=True)``): the feature-sum all-reduce, the
+  asynchronous bucketed gradient exchange with its stream-side ``work.wait()``, ``broadcast_parameters`` and
+  ``broadcast_object`` all go through RCCL on ONE rank and must leave the step unchanged.  This is the first contact with
+  the backend the 8-GPU runs use (reference srgan.py:264,295,304 are where the gradients complete)."""
 import os
 import socket
 
@@ -22,7 +28,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _step(dp, queue=None):
+def _step(dp, queue=None, broadcast=False):
     import srgan_amd  # noqa: F401
     from test_steps_gpu import make_experiment, finish_setup, run_step, crowd_inputs
     from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
@@ -40,6 +46,20 @@ def _step(dp, queue=None):
                 if isinstance(m, torch.nn.Conv2d):
                     m.weight.mul_(scale)
     finish_setup(experiment)
+    if broadcast:
+        for module in (experiment.D, experiment.DNN, experiment.G):
+            dp.broadcast_parameters(module._srgan_arena)
+    launched = {}
+    if dp is not None:                 # record which buckets every network's exchange launched
+        exchange_of = experiment.gradient_exchange
+
+        def recording(module):
+            exchange = exchange_of(module)
+            name = next(n for n in ('D', 'DNN', 'G') if getattr(experiment, n) is module)
+            if exchange is not None:
+                launched.setdefault(name, []).append(exchange.launched)
+            return exchange
+        experiment.gradient_exchange = recording
     shard = dp.shard if dp is not None else (lambda t: t)
     generator = torch.Generator().manual_seed(int(g['input_seed']))
     x, y, u = crowd_inputs(generator, batch, SIZE)
@@ -54,36 +74,67 @@ def _step(dp, queue=None):
     for name, module in (('D', experiment.D), ('DNN', experiment.DNN), ('G', experiment.G)):
         tensors.update({f'{name}/{k}': v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()})
     if queue is not None:
-        queue.put((dp.rank, result, tensors))
+        queue.put((dp.rank, result, tensors, {name: [list(b) for b in buckets] for name, buckets in launched.items()}))
     return result, tensors
 
 
-def _worker(rank, world_size, port, queue):
+def _worker(rank, world_size, port, queue, backend='gloo', force=False):
+    device = rank if backend == 'nccl' else 0          # RCCL: one device per rank; gloo: both ranks on cuda:0
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
-                      LOCAL_RANK='0')
+                      LOCAL_RANK=str(device), HSA_ENABLE_IPC_MODE_LEGACY='0')
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(device)
     import srgan_amd  # noqa: F401
     from srgan_amd.parallel import DataParallel
-    dp = DataParallel.from_environment('gloo')
-    _step(dp, queue)
+    dp = DataParallel.from_environment(backend, force=force)
+    assert torch.distributed.get_backend() == backend
+    if force:                                            # what Experiment.train() does before the first step
+        assert dp.broadcast_object({'trial': 'x', 'skip': False}) == {'trial': 'x', 'skip': False}
+    _step(dp, queue, broadcast=force)
     dp.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank_on_the_global_batch():
-    reference_result, reference_tensors = _step(None)
+def _run_ranks(world_size, backend, force=False):
     context = mp.get_context('spawn')
     queue = context.Queue()
     port = _free_port()
-    workers = [context.Process(target=_worker, args=(rank, 2, port, queue)) for rank in range(2)]
+    workers = [context.Process(target=_worker, args=(rank, world_size, port, queue, backend, force))
+               for rank in range(world_size)]
     for worker in workers:
         worker.start()
     outputs = [queue.get(timeout=600) for _ in workers]
     for worker in workers:
         worker.join(timeout=120)
         assert worker.exitcode == 0
+    return outputs
+
+
+def test_one_rank_over_rccl_with_the_exchanges_forced_equals_the_plain_step():
+    reference_result, reference_tensors = _step(None)
+    (rank, result, tensors, launched), = _run_ranks(1, 'nccl', force=True)
+    assert launched['DNN'] and launched['D'] and launched['G'], launched     # every arena went through all_reduce
+    for key, value in reference_result.items():
+        # one rank: every all-reduce is the identity, so only the order of the fp32 atomics differs between the runs
+        assert abs(result[key] - value) <= 1e-5 * max(abs(value), 1e-6), (key, result[key], value)
+    for key, value in reference_tensors.items():
+        limit = 2.2e-4 + 1e-3 * float(np.abs(value).max())
+        assert float(np.abs(tensors[key] - value).max()) <= limit, key
+        assert float(np.abs(tensors[key] - value).mean()) <= 0.05 * limit, (key, 'mean difference')
+    import conftest
+    conftest.PARITY_NOTES.append('data-parallel step over nccl (RCCL), world size 1 with the exchanges forced on: '
+                                 f'{sum(len(b) for runs in launched.values() for b in runs)} gradient buckets all-reduced, '
+                                 'losses equal the plain step')
+
+
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_ranks_equal_one_rank_on_the_global_batch(backend):
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('two ranks over nccl (RCCL) need two GPUs; this box has %d (the world-size-1 nccl test above ran)'
+                    % torch.cuda.device_count())
+    reference_result, reference_tensors = _step(None)
+    outputs = [output[:3] for output in _run_ranks(2, backend)]
     for rank, result, tensors in outputs:
         for key, value in reference_result.items():
             assert abs(result[key] - value) <= 1e-3 * max(abs(value), 1e-6), (rank, key, result[key], value)

@@ -1,0 +1,124 @@
+"""Round-3 GPU checks of host-side mechanisms around the kernels: cached launch tables against changed batch-norm
+statistics, the side-stream schedules against the goldens, the forced data-parallel bench line."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN, SIZE = 'g7c_crowd64_gp_active', 64
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import srgan_amd
+    assert torch.cuda.is_available()
+    return srgan_amd
+
+
+def _crowd_experiment(g, **overrides):
+    from test_steps_gpu import make_experiment
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
+    settings = dict(batch_size=int(g['batch_size']), matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
+                    gradient_penalty_multiplier=1e2, map_multiplier=1e-3)
+    settings.update(overrides)
+    experiment = make_experiment(
+        lambda: (DCGenerator(image_size=SIZE), KnnDenseNetCat(image_size=SIZE), KnnDenseNetCat(image_size=SIZE)),
+        settings, crowd=True)
+    scale = float(g['d_scale'])
+    if scale != 1.0:
+        with torch.no_grad():
+            for m in experiment.D.modules():
+                if isinstance(m, torch.nn.Conv2d):
+                    m.weight.mul_(scale)
+    return experiment
+
+
+def _crowd_batches(g):
+    from test_steps_gpu import crowd_inputs
+    generator = torch.Generator().manual_seed(int(g['input_seed']))
+    x, y, u = crowd_inputs(generator, int(g['batch_size']), SIZE)
+    return x.cuda(), tuple(t.cuda() for t in y), u.cuda()
+
+
+def _other_statistics(module, seed):
+    """A state dict of ``module`` whose batch-norm running statistics differ from the current ones."""
+    generator = torch.Generator().manual_seed(seed)
+    state = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    for key, value in state.items():
+        if key.endswith('running_mean'):
+            value += 0.2 * torch.randn(value.shape, generator=generator)
+        elif key.endswith('running_var'):
+            value *= 0.5 + torch.rand(value.shape, generator=generator)
+    return state
+
+
+def test_new_running_statistics_reach_the_cached_launch_tables(pkg):
+    """the grouped weight-gradient / batched-reduction / tangent tables of fused.py keep raw pointers to every
+    layer's inverse standard deviation and mean.  After ``load_state_dict`` with other running statistics the next step
+    must use the NEW statistics everywhere: compared with an experiment that has no cached table (grouped launches off,
+    statistics loaded before its first step).  Learning rate 0, so both see the same weights."""
+    from srgan_amd import fused
+    from test_steps_gpu import finish_setup, run_step
+    g = load_golden(GOLDEN)
+    x, y, u = _crowd_batches(g)
+
+    def gradients(experiment):
+        torch.cuda.synchronize()
+        return {name: getattr(experiment, name)._srgan_arena.grad.detach().cpu().numpy().copy() for name in ('D', 'DNN')}
+
+    cached = _crowd_experiment(g, learning_rate=0.0)
+    finish_setup(cached)
+    states = {name: _other_statistics(getattr(cached, name), seed) for seed, name in enumerate(('D', 'DNN'))}
+    run_step(cached, x, y, u, 0, g)                       # builds every table from the first statistics
+    before = gradients(cached)
+    for name, state in states.items():
+        getattr(cached, name).load_state_dict(state)
+    result_cached = run_step(cached, x, y, u, 0, g)
+    after = gradients(cached)
+
+    saved = fused.GROUPED_WGRAD, fused.BATCHED_REDUCE
+    fused.GROUPED_WGRAD = fused.BATCHED_REDUCE = False
+    try:
+        fresh = _crowd_experiment(g, learning_rate=0.0)
+        for name, state in states.items():
+            getattr(fresh, name).load_state_dict(state)
+        finish_setup(fresh)
+        result_fresh = run_step(fresh, x, y, u, 0, g)
+        expected = gradients(fresh)
+    finally:
+        fused.GROUPED_WGRAD, fused.BATCHED_REDUCE = saved
+    for key, value in result_fresh.items():
+        assert abs(result_cached[key] - value) <= 1e-4 * max(abs(value), 1e-6), (key, result_cached[key], value)
+    for name in ('D', 'DNN'):
+        scale = float(np.abs(expected[name]).max())
+        assert float(np.abs(before[name] - expected[name]).max()) > 1e-2 * scale, 'the statistics did not change anything'
+        error = float(np.abs(after[name] - expected[name]).max())
+        assert error <= 1e-4 * scale, (name, error, scale)
+
+
+def _bench_line(*arguments, environment=None):
+    """bench.py as the driver starts it (a fresh process), small settings; returns rank 0's JSON line."""
+    command = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--image-size', '64',
+               '--batch-per-gpu', '2', '--no-cpu-baseline', '--no-roofline'] + list(arguments)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(environment or {}))
+    done = subprocess.run(command, capture_output=True, text=True, timeout=900, env=env)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
+    return json.loads([line for line in done.stdout.splitlines() if line.startswith('{')][-1])
+
+
+def test_bench_with_the_exchanges_forced_through_rccl_on_one_rank(pkg):
+    """``bench.py --gpus 1 --force-dp --backend nccl``: an nccl (= RCCL) process group of one rank, every collective of the
+    data-parallel path on it; the last step's gradient penalty must equal the plain run's."""
+    plain = _bench_line()
+    forced = _bench_line('--force-dp', '--backend', 'nccl')
+    assert 'forced' in forced['config']['parallelism'] and 'nccl' in forced['config']['gradient_exchange']
+    a, b = plain['config']['gradient_penalty_last'], forced['config']['gradient_penalty_last']
+    assert a > 0 and abs(a - b) <= 1e-4 * abs(a), (a, b)
