@@ -289,21 +289,36 @@ struct Wgrad3Job {
 };
 static_assert(sizeof(Wgrad3Job) == 128, "one 128-byte table slot per job");
 
+// XCD-aware order (as in pointwise_wgrad.hip): the channel chunks of one walker read the same gy tiles, and neighbouring
+// walkers visit neighbouring tiles at the same time (they share the 128-byte lines of a tile row and the halo columns).
+// With blockIdx.x = walker running fastest those workgroups were spread over the eight XCDs and over time: 52.9 GB of fabric
+// traffic per step for 12.6 GB of operands (4.2x, profiles/r02z_pmc_per_kernel.md).  Now the grid is one-dimensional: a UNIT
+// is WG3_UNIT neighbouring walkers x all channel chunks of one problem, XCD b % 8 works through the units 8 * j + (b % 8).
+constexpr int WG3_UNIT = 8;
+
 template <bool RAGGED>
 __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_grouped_kernel(const Wgrad3Job* __restrict__ jobs,
                                                                                const float* x_base, const float* gy_base,
-                                                                               float* gw_base) {
+                                                                               float* gw_base, const int grid_x, const int grid_y,
+                                                                               const int count) {
   __shared__ float smem[Wgrad3Lds<4, 0, RAGGED>::SMEM];
-  const Wgrad3Job job = jobs[blockIdx.z];
-  if ((int)blockIdx.x >= job.walkers || (int)blockIdx.y >= job.ci_chunks * job.co_chunks) return;   // (workgroup-uniform)
+  const int xcd = (int)blockIdx.x & 7, within_xcd = (int)blockIdx.x >> 3;
+  const int per_unit = WG3_UNIT * grid_y, units_per_job = (grid_x + WG3_UNIT - 1) / WG3_UNIT;
+  const int round = within_xcd / per_unit, within = within_xcd % per_unit;
+  const int unit = round * 8 + ((xcd - round) & 7);
+  const int z = unit / units_per_job;
+  if (z >= count) return;                                                                             // (the last round's padding)
+  const int walker = (unit - z * units_per_job) * WG3_UNIT + within / grid_y, chunk = within % grid_y;
+  const Wgrad3Job job = jobs[z];
+  if (walker >= job.walkers || chunk >= job.ci_chunks * job.co_chunks) return;                        // (workgroup-uniform)
   Wgrad3Params p;
   p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off; p.x_bs = job.x_bs; p.gy_bs = job.gy_bs;
   p.gw = gw_base ? gw_base + (int64_t)(intptr_t)job.gw : job.gw;      // (an element offset into the per-step buffer)
   p.N = job.N; p.CI = job.CI; p.CO = job.CO; p.H = job.H; p.W = job.W;
   p.tiles_x = job.tiles_x; p.tiles_y = job.tiles_y; p.tiles = job.tiles; p.debug = 0;
   p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
-  const int co_chunk = (int)blockIdx.y / job.ci_chunks;
-  conv3x3_wgrad_body<4, 0, RAGGED>(p, (int)blockIdx.x, job.walkers, (int)blockIdx.y - co_chunk * job.ci_chunks, co_chunk, smem);
+  const int co_chunk = chunk / job.ci_chunks;
+  conv3x3_wgrad_body<4, 0, RAGGED>(p, walker, job.walkers, chunk - co_chunk * job.ci_chunks, co_chunk, smem);
 }
 
 int profile_bracket_begin(hipStream_t stream);
@@ -327,6 +342,7 @@ static int conv3x3_wgrad_walkers(int tiles, int ci_chunks, int co_chunks, int gr
   const int wanted = group > 1 ? (resident * oversubscription + group - 1) / group : resident;
   int walkers = wanted / (ci_chunks * co_chunks);
   if (walkers > (tiles + depth - 1) / depth) walkers = (tiles + depth - 1) / depth;
+  if (group > 1 && walkers > 8) walkers -= walkers % 8;     // whole units of the grouped kernel's XCD-aware order
   return walkers < 1 ? 1 : walkers;
 }
 
@@ -395,12 +411,15 @@ int conv3x3_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int
                             int64_t elements, hipStream_t stream) {
   SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped conv3x3 wgrad grid");
   const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
-  dim3 grid((unsigned)grid_x, (unsigned)grid_y, (unsigned)count);
+  // one-dimensional: 8 XCDs x (units per XCD, rounded up) x (WG3_UNIT walkers x channel chunks) -- see the kernel
+  const int64_t units = (int64_t)((grid_x + WG3_UNIT - 1) / WG3_UNIT) * count, rounds = (units + 7) / 8;
+  SRGAN_REQUIRE(rounds * 8 * WG3_UNIT * grid_y < ((int64_t)1 << 31), SRGAN_ERANGE, "grouped conv3x3 wgrad grid");
+  dim3 grid((unsigned)(rounds * 8 * WG3_UNIT * grid_y), 1, 1);
   const int profile_slot = profile_bracket_begin(stream);
   if (rag) hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<true>), grid, dim3(WG3_THREADS), 0, stream,
-                              reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base);
+                              reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base, grid_x, grid_y, count);
   else hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<false>), grid, dim3(WG3_THREADS), 0, stream,
-                          reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base);
+                          reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base, grid_x, grid_y, count);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 4, 4, WG3_TW, grid_x, 0, 0, elements > pixels ? elements - pixels : 0);
   return status;

@@ -201,13 +201,28 @@ struct PwWgradJob {
 static_assert(sizeof(PwWgradJob) == 128, "one 128-byte table slot per job");
 
 // (gw_base != NULL: the job's gw field holds an element OFFSET into that per-step buffer instead of a pointer.)
+//
+// XCD-aware order.  The tiles of one SLICE (one problem, one K range) read the same gy rows (every tile) and the same x
+// rows (the tiles_m tiles of a column): dispatched round-robin over the eight XCDs -- workgroup b runs on XCD b % 8,
+// MI355X_MICROARCH.md -- each XCD's L2 fetched those rows separately: 129.5 GB of fabric traffic per step for 42.1 GB of
+// operands (3.1x, profiles/r02z_pmc_per_kernel.md), 5.3 TB/s, i.e. the kernel sat on the HBM roofline of its own
+// re-reads.  Now the grid is one-dimensional and a hardware workgroup id b means: XCD b % 8 works through the slices
+// s = 8 * j + (b % 8), j = 0, 1, ..., and within a slice through its tiles, so that all the tiles of a slice are resident
+// on ONE XCD at the same time and the rows come from HBM once (slices go to the XCDs round-robin: a problem's slices --
+// and the problems' different widths -- spread evenly).
 template <bool PRO, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const PwWgradJob* __restrict__ jobs,
                                                                          const float* x_base, const float* gy_base,
-                                                                         float* gw_base) {
+                                                                         float* gw_base, const int grid_x, const int grid_y,
+                                                                         const int count) {
   __shared__ float red[2 * PWG_MI * 32 * (PWG_NI * 32 + 1)];
-  const PwWgradJob job = jobs[blockIdx.z];
-  if ((int)blockIdx.x >= job.tiles || (int)blockIdx.y >= job.split) return;       // (workgroup-uniform)
+  const int xcd = (int)blockIdx.x & 7, within_xcd = (int)blockIdx.x >> 3;
+  const int round = within_xcd / grid_x, tile = within_xcd % grid_x;
+  const int slice = round * 8 + ((xcd - round) & 7);        // (rotated per round: a problem's first slices visit every XCD)
+  const int z = slice / grid_y, y = slice - z * grid_y;
+  if (z >= count) return;                                                          // (the padding of the last round)
+  const PwWgradJob job = jobs[z];
+  if (tile >= job.tiles || y >= job.split) return;                                 // (workgroup-uniform)
   PwWgradParams p;
   p.x = x_base + job.x_off; p.gy = gy_base + job.gy_off;
   p.gw = gw_base ? gw_base + (int64_t)(intptr_t)job.gw : job.gw;
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const P
   p.tiles_n = job.tiles_n; p.chunks = job.chunks; p.chunks_per_worker = job.chunks_per_worker;
   p.chunks_per_image = job.chunks_per_image; p.mode = job.mode;
   p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
-  pointwise_wgrad_body<PRO, RAGGED>(p, (int)blockIdx.x, (int)blockIdx.y, red);
+  pointwise_wgrad_body<PRO, RAGGED>(p, tile, y, red);
 }
 
 int profile_bracket_begin(hipStream_t stream);
@@ -316,13 +331,19 @@ int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, i
                               int64_t elements, hipStream_t stream) {
   SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped pointwise wgrad grid");
   const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
-  dim3 grid((unsigned)grid_x, (unsigned)grid_y, (unsigned)count);
+  // one-dimensional: 8 XCDs x (slices per XCD, rounded up) x tiles (see the kernel)
+  const int64_t slices = (int64_t)grid_y * count, rounds = (slices + 7) / 8;
+  SRGAN_REQUIRE(rounds * 8 * grid_x < ((int64_t)1 << 31), SRGAN_ERANGE, "grouped pointwise wgrad grid");
+  dim3 grid((unsigned)(rounds * 8 * grid_x), 1, 1);
   const PwWgradJob* table = reinterpret_cast<const PwWgradJob*>(jobs);
   const int profile_slot = profile_bracket_begin(stream);
-  if (fused_bn && rag) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<true, true>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
-  else if (fused_bn) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<true, false>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
-  else if (rag) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<false, true>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
-  else hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<false, false>), grid, dim3(256), 0, stream, table, x_base, gy_base, gw_base);
+#define SRGAN_PWG_LAUNCH(PRO, RAG) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<PRO, RAG>), grid, dim3(256), 0, stream, \
+                                                      table, x_base, gy_base, gw_base, grid_x, grid_y, count)
+  if (fused_bn && rag) SRGAN_PWG_LAUNCH(true, true);
+  else if (fused_bn) SRGAN_PWG_LAUNCH(true, false);
+  else if (rag) SRGAN_PWG_LAUNCH(false, true);
+  else SRGAN_PWG_LAUNCH(false, false);
+#undef SRGAN_PWG_LAUNCH
   const int status = launch_status();
   // logical shape of the group: M x (sum of the input widths) x pixels, i.e. flops_mn = sum CO * CI
   profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 6, PWG_MI * 32, PWG_NI * 32, grid_y, 0, 0,
