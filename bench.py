@@ -76,8 +76,11 @@ def parse():
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-roofline', action='store_true')
     parser.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
-    parser.add_argument('--overlap-dnn', action='store_true',
-                        help='enqueue the DNN step on a second stream (faster step, per-kernel timings not attributable)')
+    parser.add_argument('--overlap-dnn', action='store_true', help=argparse.SUPPRESS)      # (the default now; kept for old command lines)
+    parser.add_argument('--single-stream', action='store_true',
+                        help='timed region on ONE stream.  Default: the DNN step, the grouped weight gradients of every dense '
+                             'block and the un-differentiated D(unlabeled) forward of the generator step run on side streams '
+                             'next to the main chain (the event-bracketed roofline step is always single-stream)')
     parser.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL)')
     parser.add_argument('--force-dp', action='store_true',
                         help='keep the data-parallel path on at world size 1: the feature-sum all-reduce, the asynchronous '
@@ -118,7 +121,8 @@ def build_experiment(args, dp):
     settings.gradient_penalty_multiplier, settings.map_multiplier = 1e2, 1e-3
     settings.learning_rate = 1e-4
     settings.reference_schedule = args.reference_schedule
-    settings.overlap_dnn_step = args.overlap_dnn
+    streams = side_streams(args)
+    settings.overlap_dnn_step = settings.wgrad_stream = settings.overlap_generator_forwards = streams
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
     settings.step_graph = bool(args.step_graph)
     if workload is None:
@@ -153,6 +157,10 @@ def build_experiment(args, dp):
         for module in (experiment.D, experiment.DNN, experiment.G):
             dp.broadcast_parameters(module._srgan_arena)
     return experiment
+
+
+def side_streams(args):
+    return not args.single_stream and not args.step_graph
 
 
 def gp_scale(args):
@@ -418,6 +426,8 @@ def main():
                    'discriminator_weight_scale': gp_scale(args)},
     }
     captured = getattr(experiment, '_captured_iteration', None)
+    result['config']['streams'] = ('timed region: main chain + DNN step / grouped weight gradients / D(unlabeled) of the generator '
+                                   'step on side streams; roofline step: single stream' if side_streams(args) else 'single stream')
     result['config']['launch'] = (f'HIP graph replay ({captured.replays} replayed, {captured.eager_iterations} eager iterations)'
                                   if captured is not None else 'eager (Python tape enqueues every kernel)')
     if dp is not None:
@@ -432,6 +442,11 @@ def main():
         import ctypes
         from srgan_amd import _lib
         lib = _lib.library()
+        # per-kernel attribution needs one kernel at a time: this extra step runs on ONE stream
+        experiment.join_dnn_stream()
+        torch.cuda.synchronize()
+        for name in ('overlap_dnn_step', 'wgrad_stream', 'overlap_generator_forwards'):
+            setattr(experiment.settings, name, False)
         lib.srgan_profile_begin()
         one_step(experiment, labeled, unlabeled, args.warmup + args.steps, eager=True)
         experiment.join_dnn_stream()

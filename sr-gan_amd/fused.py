@@ -33,24 +33,42 @@ import torch
 
 from . import _lib
 from . import functional as F
-from .tape import Var, Node, grad_enabled, incoming_gradient_is_exclusive
+from .tape import Var, Node, grad_enabled, incoming_gradient_is_exclusive, at_sweep_end
 from .nn import parameter_var
 
 
 ENABLED = True      # tests flip this to compare the fused block with the primitive path
 PROLOGUE = True     # batch-norm + ReLU evaluated inside the convolution kernels (tests flip this too)
 EPILOGUE = True     # batch-norm + ReLU backward evaluated in the epilogue of the data-gradient kernels
-# Experiment (off by default): the weight-gradient kernels of a block's backward only feed the optimizer, so they can
-# run on a second stream next to the data-gradient chain.  Throughput rises, but kernels then overlap and the
-# per-kernel timings behind bench.py's roofline no longer describe one kernel at a time.
+# The weight-gradient kernels of a block's backward only feed the optimizer, so they can run on a second stream next to
+# the data-gradient chain: the grouped launches of block k then overlap the chain of block k - 1, whose kernels on the small
+# planes cannot fill 256 CUs.  The join is deferred to the end of the backward sweep (``tape.at_sweep_end``).  Kernels then
+# overlap, so per-kernel timings no longer describe one kernel at a time: bench.py switches this on for the timed region
+# (``settings.wgrad_stream`` -> ``fused.WGRAD_STREAM``) and off for the event-bracketed step behind its roofline line.
 WGRAD_STREAM = os.environ.get('SRGAN_WGRAD_STREAM', '0') == '1'
 _side_streams = {}
 
 
-def _side_stream(device):
-    if device not in _side_streams:
-        _side_streams[device] = torch.cuda.Stream(device=device)
-    return _side_streams[device]
+def _side_stream(device, main=None):
+    """The weight-gradient stream that belongs to ``main`` (the DNN side stream gets its own)."""
+    key = (str(device), main.cuda_stream if main is not None else 0)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def _launch_on_side_stream(device, tensors, launch):
+    """``launch(stream handle)`` on the weight-gradient stream of the current stream, after everything enqueued so far;
+    ``tensors`` (read or written by those launches) stay allocated until they have run; the current stream waits for them
+    at the end of the backward sweep in progress."""
+    main = torch.cuda.current_stream(device)
+    side = _side_stream(device, main)
+    side.wait_stream(main)
+    launch(_lib.stream_handle(side))
+    for tensor in tensors:
+        if tensor is not None:
+            tensor.record_stream(side)
+    at_sweep_end(lambda: main.wait_stream(side))
 
 
 def _ptr(tensor, offset_elements=0):
@@ -66,6 +84,13 @@ def _empty(shape, device):
     if F.POISON:
         return torch.full(tuple(shape), float('nan'), dtype=torch.float32, device=device)
     return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _zeros(shape, device):
+    """Zero-filled by the library's own kernel (no torch arithmetic on the path; replays correctly inside HIP graphs)."""
+    tensor = torch.empty(shape, dtype=torch.float32, device=device)
+    F._call('srgan_fill', tensor.data_ptr(), tensor.numel(), 0.0, F._stream())
+    return tensor
 
 
 BATCHED_REDUCE = True   # one batch-norm parameter-sum reduction per block backward instead of one per convolution
@@ -271,7 +296,7 @@ def dense_block(x, layers):
         if zero_new:
             F._call('srgan_fill', buffer.data_ptr(), buffer.numel(), 0.0, stream)
         if zero_b1:
-            b1_all = torch.zeros((len(layers), n, width, h, w), dtype=torch.float32, device=device)
+            b1_all = _zeros((len(layers), n, width, h, w), device)
         elif requires:
             b1_all = _empty((len(layers), n, width, h, w), device)     # one tensor: the grouped weight gradient indexes it
     F._call('srgan_copy_channels', x.data.data_ptr(), c0, 0, buffer.data_ptr(), total, 0, c0, n, hw, 0, stream)
@@ -334,15 +359,17 @@ def dense_block(x, layers):
                 scratch = _empty((plan['total'],), device)
         # (not while a HIP graph is being captured: a captured fork / join per layer replayed slower and, together with the
         # DNN side stream, crashed the runtime)
-        overlap = WGRAD_STREAM and want_params and prologue and not recorded and not torch.cuda.is_current_stream_capturing()
+        side_ok = WGRAD_STREAM and want_params and prologue and not recorded and not torch.cuda.is_current_stream_capturing()
         grouped = None
-        if GROUPED_WGRAD and want_params and prologue and not recorded and not overlap:
+        if GROUPED_WGRAD and want_params and prologue and not recorded:
             grouped = _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device)
+        overlap = side_ok and grouped is None     # no grouped form for this geometry: the per-layer launches go to the side stream
         # (recorded: the double backward's grouped weight gradients index the kept gradients through one tensor, too)
         one_tensor = grouped is not None or (recorded and GROUPED_WGRAD and prologue)
         g_b1_all = _empty((len(layers), n, layers[0].conv1.out_channels, h, w), device) if one_tensor else None
         if overlap:
-            main, side = torch.cuda.current_stream(device), _side_stream(device)
+            main = torch.cuda.current_stream(device)
+            side = _side_stream(device, main)
             wstream = _lib.stream_handle(side)
             alive = []                            # tensors the side stream still reads
         else:
@@ -424,8 +451,13 @@ def dense_block(x, layers):
                 saved[index] = None
         if grouped is not None:
             # (the gradient slices of gbuf the 3x3 group reads are final: later layers only wrote channels below them)
-            _run_wgrad_group(grouped[3], 3, True, b1_all, gbuf, None, stream)
-            _run_wgrad_group(grouped[1], 1, True, buffer, g_b1_all, None, stream)
+            def run_groups(on):
+                _run_wgrad_group(grouped[3], 3, True, b1_all, gbuf, None, on)
+                _run_wgrad_group(grouped[1], 1, True, buffer, g_b1_all, None, on)
+            if side_ok:
+                _launch_on_side_stream(device, (b1_all, gbuf, buffer, g_b1_all), run_groups)
+            else:
+                run_groups(stream)
         if plan is not None:
             F._call('srgan_bn_partial_reduce_batched', plan['jobs'].data_ptr(), plan['count'], plan['max_channels'],
                     plan['max_tiles'], scratch.data_ptr(), stream)
@@ -459,7 +491,7 @@ def dense_block(x, layers):
         # weight gradients q themselves accumulate into ONE pre-zeroed buffer (no zero-fill launch of their own).
         tangent = _tangent_plan(layers, c0, growth, device)
         scaled_all = _empty((tangent['total'],), device)
-        q_all = torch.zeros(tangent['total'], dtype=torch.float32, device=device) if want_params else None
+        q_all = _zeros((tangent['total'],), device) if want_params else None
         F._call('srgan_bn_conv_tangent_weights_grouped', tangent['table'].data_ptr(), tangent['count'], tangent['max_inner'],
                 tangent['max_co'], scaled_all.data_ptr(), None, stream)
         # the plain weight gradients q of every layer: two grouped launches at the end, reading the masked tangents of all
@@ -500,12 +532,18 @@ def dense_block(x, layers):
                 F._call('srgan_conv2d_bwd_weight', desc2, u2.data_ptr(), _ptr(gbuf, cin * hw), _ptr(q_all, at2), 1, 0, stream)
             F._call('srgan_conv2d_fwd', desc2, u2.data_ptr(), _ptr(scaled_all, at2), None, _ptr(vbuf, cin * hw), 0, stream)
             kept[index] = None
-        if grouped is not None:
-            _run_wgrad_group(grouped[1], 1, False, u1_all, g_b1_all, q_all, stream)
-            _run_wgrad_group(grouped[3], 3, False, u2_all, gbuf, q_all, stream)
-        if want_params:                                 # dL/dW += q * a;  dL/dgamma += inv_std * sum_co W * q   (a = inv_std * gamma)
+        def run_parameter_part(on):
+            if grouped is not None:
+                _run_wgrad_group(grouped[1], 1, False, u1_all, g_b1_all, q_all, on)
+                _run_wgrad_group(grouped[3], 3, False, u2_all, gbuf, q_all, on)
+            # dL/dW += q * a;  dL/dgamma += inv_std * sum_co W * q   (a = inv_std * gamma)
             F._call('srgan_bn_conv_tangent_weights_grouped', tangent['table'].data_ptr(), tangent['count'],
-                    tangent['max_inner'], tangent['max_co'], None, q_all.data_ptr(), stream)
+                    tangent['max_inner'], tangent['max_co'], None, q_all.data_ptr(), on)
+        if want_params and grouped is not None and WGRAD_STREAM and not torch.cuda.is_current_stream_capturing():
+            # nothing in the rest of the sweep reads q or the arena: the whole parameter part runs next to the chain
+            _launch_on_side_stream(device, (u1_all, u2_all, g_b1_all, gbuf, q_all, scaled_all), run_parameter_part)
+        elif want_params:
+            run_parameter_part(stream)
         return (Var(vbuf) if needs2[0] else None,) + (None,) * len(parameter_vars)
 
     out.node = Node((x,) + tuple(parameter_vars), backward, 'dense_block')
@@ -578,7 +616,7 @@ def bn_relu_conv(x, norm, conv):
                 norm.weight.data_ptr(), norm.bias.data_ptr(), 1, u.data_ptr(), None, None, n, cin, hw, 0, 0, 0, 0, 1, stream)
         q = None
         if want_params:
-            q = torch.zeros(conv.weight.shape, dtype=torch.float32, device=device)
+            q = _zeros(tuple(conv.weight.shape), device)
             F._call('srgan_conv2d_bwd_weight', desc, u.data_ptr(), g.data.data_ptr(), q.data_ptr(), 1, 0, stream)
         scaled = _empty(conv.weight.shape, device)
         F._call('srgan_bn_conv_tangent_weights', conv.weight.data_ptr(), q.data_ptr() if want_params else None,

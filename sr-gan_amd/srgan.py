@@ -406,6 +406,7 @@ class Experiment(ABC):
         touches the DNN first calls ``join_dnn_stream()``.  Off by default: with two streams in flight a kernel's
         duration no longer measures the kernel (bench.py's per-kernel roofline would read 34 % instead of 40 %)."""
         examples, labels = as_var(examples), as_var(labels)
+        self._apply_stream_settings()
         side = self._dnn_side_stream()
         if side is None:
             return self._dnn_training_step(examples, labels, step)
@@ -419,6 +420,22 @@ class Experiment(ABC):
         if getattr(self, '_dnn_stream', None) is None:
             self._dnn_stream = torch.cuda.Stream()
         return self._dnn_stream
+
+    def _auxiliary_stream(self):
+        """A second stream for forward passes that nothing differentiates (``settings.overlap_generator_forwards``)."""
+        if not getattr(self.settings, 'overlap_generator_forwards', False) or not examples_on_gpu() or \
+                torch.cuda.is_current_stream_capturing():
+            return None
+        if getattr(self, '_aux_stream', None) is None:
+            self._aux_stream = torch.cuda.Stream()
+        return self._aux_stream
+
+    def _apply_stream_settings(self):
+        """``settings.wgrad_stream`` (None: leave the module default / SRGAN_WGRAD_STREAM) -> ``fused.WGRAD_STREAM``."""
+        wanted = getattr(self.settings, 'wgrad_stream', None)
+        if wanted is not None:
+            from . import fused
+            fused.WGRAD_STREAM = bool(wanted)
 
     def _join_side_stream(self):
         stream = getattr(self, '_dnn_stream', None)
@@ -512,6 +529,7 @@ class Experiment(ABC):
         settings = self.settings
         labeled_examples, labels = as_var(labeled_examples), as_var(labels)
         unlabeled_examples = as_var(unlabeled_examples)
+        self._apply_stream_settings()
         self.D.apply(disable_batch_norm_updates)
         self.gan_summary_writer.step = step
         self.finish_update('G', 'D')         # the previous iteration's generator update (its exchange ran under the DNN step)
@@ -687,11 +705,25 @@ class Experiment(ABC):
     def generator_loss_calculation(self, fake_examples, unlabeled_examples):
         """reference srgan.py:383-391 (no srgan_loss_multiplier, Appendix A.4)."""
         with nn.frozen_parameters(self.D):
-            _ = self.D(fake_examples)
-            self.fake_features = self.D.features
-            with no_grad():
-                _ = self.D(unlabeled_examples)
-                detached_unlabeled_features = self.D.features.detach()
+            side = self._auxiliary_stream()
+            if side is None:
+                _ = self.D(fake_examples)
+                self.fake_features = self.D.features
+                with no_grad():
+                    _ = self.D(unlabeled_examples)
+                    detached_unlabeled_features = self.D.features.detach()
+            else:
+                # D(u) needs no gradient and shares nothing with D(fake) but the (frozen) weights: its batch-sized kernels
+                # run on a second stream next to D(fake)'s, which on their own cannot fill the GPU on the small planes
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)                   # the discriminator update and the batch are enqueued on main
+                with torch.cuda.stream(side), no_grad():
+                    _ = self.D(unlabeled_examples)
+                    detached_unlabeled_features = self.D.features.detach()
+                detached_unlabeled_features.data.record_stream(main)
+                _ = self.D(fake_examples)
+                self.fake_features = self.D.features
+                main.wait_stream(side)
         generator_loss = self.feature_distance_loss(detached_unlabeled_features, self.fake_features)
         return F.scale(generator_loss, self.settings.matching_loss_multiplier)
 

@@ -149,6 +149,24 @@ def _frontiers(order, flat):
     return frontier
 
 
+_sweep_end_hooks = []     # callables run (once) when the outermost running sweep ends, or earlier by ``run_sweep_end_hooks``
+_sweep_depth = 0
+
+
+def at_sweep_end(hook):
+    """Run ``hook()`` when the backward sweep in progress has enqueued its last node -- e.g. the join of a side stream that
+    carries weight-gradient launches nothing inside the sweep depends on.  Outside a sweep the hook runs at once."""
+    if _sweep_depth == 0:
+        hook()
+    else:
+        _sweep_end_hooks.append(hook)
+
+
+def run_sweep_end_hooks():
+    while _sweep_end_hooks:
+        _sweep_end_hooks.pop(0)()
+
+
 _accumulating = False     # inside a plain backward sweep (no ``inputs``, not recorded)
 _exclusive = False        # the gradient handed to the node being swept is referenced by nobody else
 
@@ -196,14 +214,16 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
     results = {}
     wanted = {id(v): v for v in inputs} if inputs is not None else {}
     frontier = _frontiers(order, grad_ready.flat) if grad_ready is not None else None
-    global _accumulating, _exclusive
+    global _accumulating, _exclusive, _sweep_depth
     previous, _accumulating = _accumulating, (inputs is None and not create_graph)
+    _sweep_depth += 1
     try:
         with context:
             if id(root) in wanted:
                 results[id(root)] = grad
             for position, var in enumerate(order):
                 if frontier is not None:
+                    run_sweep_end_hooks()     # side-stream launches write the arena too: joined before a tail is declared final
                     grad_ready.ready_from(frontier[position])
                 g = grads.pop(id(var), None)
                 if g is None:
@@ -244,6 +264,9 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
                     node.inputs = ()
     finally:
         _accumulating = previous
+        _sweep_depth -= 1
+        if _sweep_depth == 0:
+            run_sweep_end_hooks()
     if frontier is not None:
         grad_ready.ready_from(0)
     if inputs is not None:

@@ -107,6 +107,36 @@ def test_new_running_statistics_reach_the_cached_launch_tables(pkg):
         assert stale > 10 * error and stale > 1e-2 * scale, (name, 'the statistics did not change anything', stale, error)
 
 
+STREAM_CASES = [('g7b_crowd64', 2, False), ('g7b_crowd64', 1, True), ('g7c_crowd64_gp_active', 1, False),
+                ('g7c_crowd64_gp_active', 1, True)]
+
+
+@pytest.fixture
+def single_stream_afterwards():
+    from srgan_amd import fused
+    saved = fused.WGRAD_STREAM
+    yield
+    fused.WGRAD_STREAM = saved
+
+
+@pytest.mark.parametrize('name,steps,reference_schedule', STREAM_CASES)
+def test_crowd_steps_with_the_side_streams(pkg, single_stream_afterwards, name, steps, reference_schedule):
+    """bench.py's default schedule for the timed region: the DNN step, the grouped weight gradients of every dense block
+    (first and double backward) and the generator step's D(unlabeled) on side streams -- same results as the goldens."""
+    import test_steps_gpu as reference_tests
+    reference_tests.test_crowd_steps(pkg, name, SIZE, steps, reference_schedule, streams=True)
+
+
+@pytest.mark.parametrize('name,steps,reference_schedule', STREAM_CASES[2:])
+def test_side_streams_on_poisoned_allocations(pkg, single_stream_afterwards, monkeypatch, name, steps, reference_schedule):
+    """Every allocation starts as NaN: a side stream that read a tensor before its producer wrote it, or after the
+    allocator recycled it, would show."""
+    import test_steps_gpu as reference_tests
+    from srgan_amd import functional as F
+    monkeypatch.setattr(F, 'POISON', True)
+    reference_tests.test_crowd_steps(pkg, name, SIZE, steps, reference_schedule, streams=True)
+
+
 def _bench_line(*arguments, environment=None):
     """bench.py as the driver starts it (a fresh process), small settings; returns rank 0's JSON line."""
     command = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--image-size', '64',
