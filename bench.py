@@ -48,6 +48,7 @@ ALGORITHMIC_GFLOP_PER_IMAGE = {512: 1188.7 + 135.6, 224: 227.5 + 26.0}
 GP_SCALE = {512: 1.27, 224: 1.27}
 
 
+RESTORE_PERIOD = 16                      # timed steps between weight restores (see main)
 LOW_PRECISION_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 (MI355X_MICROARCH.md); never the 2:1-sparsity figure
 # The other BASELINE.json configurations that name a precision mode (secondary bench lines; the headline stays crowd).
 WORKLOADS = {
@@ -306,8 +307,9 @@ def cpu_baseline_child(image_size, warmup=1, timed=3):
     elapsed = sum(seconds[warmup:])
     return {'value': batch * timed / elapsed, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'cpu': cpu_model(),
-            'sample': f'{warmup} warm-up + {timed} timed iterations (dnn_training_step + gan_training_step) of the '
-                      f'PyTorch-CPU fp32 oracle, crowd {image_size}x{image_size}, batch {batch}: '
+            'sample': f'BATCH {batch}, i.e. a per-image rate at batch {batch} (the GPU leg runs batch 16 per GPU): '
+                      f'{warmup} warm-up + {timed} timed iterations (dnn_training_step + gan_training_step) of the '
+                      f'PyTorch-CPU fp32 oracle, crowd {image_size}x{image_size}: '
                       + ' / '.join(f'{t:.2f}' for t in seconds[warmup:]) + f' s (warm-up {seconds[0]:.2f} s)'}
 
 
@@ -393,11 +395,23 @@ def main():
                 break
             one_step(experiment, labeled, unlabeled, step=0)
     fence()
+    # The batches are noise and nothing is learned: left alone, the penalty-active discriminator drifts (gradient penalty 1e2
+    # after 13 iterations, 4e4 after 25) and a long --steps would end in non-finite losses.  Every RESTORE_PERIOD steps the
+    # three networks' weights go back to their post-warm-up values (device-to-device copies INSIDE the timed region: 0.76 GB
+    # per 16 steps at 512 x 512, < 0.02 ms per step); every step still runs its full forward / backward / Adam arithmetic.
+    snapshot = [(module._srgan_arena.data, module._srgan_arena.data.clone())
+                for module in (experiment.D, experiment.DNN, experiment.G)]
+    torch.cuda.synchronize()
     start = time.perf_counter()
     for step in range(args.steps):
         one_step(experiment, labeled, unlabeled, args.warmup + step)
+        if step % RESTORE_PERIOD == RESTORE_PERIOD - 1 and step + 1 < args.steps:
+            experiment.join_dnn_stream()
+            for live, saved in snapshot:
+                live.copy_(saved)
     fence()
     elapsed = time.perf_counter() - start
+    del snapshot
     if dp is not None:
         elapsed = dp.all_reduce_max_float(elapsed)
     global_batch = experiment.settings.batch_size
@@ -423,7 +437,9 @@ def main():
                    'schedule': 'reference' if args.reference_schedule else 'shared-forwards',
                    'parallelism': f'dp{world}' + (' (data-parallel exchanges forced on)' if args.force_dp else ''), 'random_init_weights': True,
                    'gradient_penalty': 'active' if penalty > 0.0 else 'inactive', 'gradient_penalty_last': penalty,
-                   'discriminator_weight_scale': gp_scale(args)},
+                   'discriminator_weight_scale': gp_scale(args),
+                   'weights_restored_every': f'{RESTORE_PERIOD} timed steps (to the post-warm-up weights; the batches are noise, '
+                                             'so an unbounded run diverges; every step runs its full arithmetic)'},
     }
     captured = getattr(experiment, '_captured_iteration', None)
     result['config']['streams'] = ('timed region: main chain + DNN step / grouped weight gradients / D(unlabeled) of the generator '
