@@ -124,6 +124,7 @@ def build_experiment(args, dp):
     settings.reference_schedule = args.reference_schedule
     streams = side_streams(args)
     settings.overlap_dnn_step = settings.wgrad_stream = settings.overlap_generator_forwards = streams
+    settings.overlap_gradient_penalty = streams and not os.environ.get('SRGAN_NO_PENALTY_STREAM')
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
     settings.step_graph = bool(args.step_graph)
     if workload is None:
@@ -442,8 +443,8 @@ def main():
                                              'so an unbounded run diverges; every step runs its full arithmetic)'},
     }
     captured = getattr(experiment, '_captured_iteration', None)
-    result['config']['streams'] = ('timed region: main chain + DNN step / grouped weight gradients / D(unlabeled) of the generator '
-                                   'step on side streams; roofline step: single stream' if side_streams(args) else 'single stream')
+    result['config']['streams'] = ('timed region: main chain + DNN step / gradient-penalty chain / grouped weight gradients / D(unlabeled) of '
+                                   'the generator step on side streams; roofline step: single stream' if side_streams(args) else 'single stream')
     result['config']['launch'] = (f'HIP graph replay ({captured.replays} replayed, {captured.eager_iterations} eager iterations)'
                                   if captured is not None else 'eager (Python tape enqueues every kernel)')
     if dp is not None:
@@ -461,7 +462,7 @@ def main():
         # per-kernel attribution needs one kernel at a time: this extra step runs on ONE stream
         experiment.join_dnn_stream()
         torch.cuda.synchronize()
-        for name in ('overlap_dnn_step', 'wgrad_stream', 'overlap_generator_forwards'):
+        for name in ('overlap_dnn_step', 'wgrad_stream', 'overlap_generator_forwards', 'overlap_gradient_penalty'):
             setattr(experiment.settings, name, False)
         lib.srgan_profile_begin()
         one_step(experiment, labeled, unlabeled, args.warmup + args.steps, eager=True)

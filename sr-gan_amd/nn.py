@@ -134,6 +134,35 @@ class ParameterArena:
     def zero_grad(self):
         F.fill_(self.grad, 0.0)
 
+    def gradients_into_alternate(self):
+        """Context manager: while it is active, every gradient of this network accumulates into a SECOND buffer of the
+        arena's size (returned; allocated on first use, zeroed by the caller) instead of ``self.grad`` -- for a backward
+        chain that runs on another stream concurrently with one that accumulates into ``self.grad`` (the accumulations are
+        read-modify-write kernels, not atomics).  The caller adds the buffer to ``self.grad`` after joining the streams."""
+        import contextlib
+        if getattr(self, '_alternate', None) is None:
+            self._alternate = torch.empty_like(self.grad)
+            self._alternate_views = [self._alternate[offset:offset + size].view(p.shape)
+                                     for p, offset, size in zip(self.parameters, self.offsets, self.sizes)]
+            self._main_views = [self.grad[offset:offset + size].view(p.shape)
+                                for p, offset, size in zip(self.parameters, self.offsets, self.sizes)]
+
+        def point_at(views):
+            for p, view in zip(self.parameters, views):
+                p.grad = view
+                var = getattr(p, '_srgan_var', None)
+                if var is not None:
+                    var.grad_buffer = view
+
+        @contextlib.contextmanager
+        def redirected():
+            point_at(self._alternate_views)
+            try:
+                yield self._alternate
+            finally:
+                point_at(self._main_views)
+        return redirected()
+
     def rebind(self):
         """Re-point ``p.grad`` at the arena (torch utilities such as zero_grad(set_to_none) may drop it)."""
         for p, offset, size in zip(self.parameters, self.offsets, self.sizes):

@@ -430,6 +430,34 @@ class Experiment(ABC):
             self._aux_stream = torch.cuda.Stream()
         return self._aux_stream
 
+    def _penalty_stream(self):
+        """A stream of its own for the gradient-penalty chain (``settings.overlap_gradient_penalty``; single device, shared-
+        forwards schedule, not while a HIP graph is captured): D(interpolates), the recorded gradient w.r.t. them, the double
+        backward and the backward through the forward graph (reference srgan.py:294-295) are a chain of batch-sized kernels
+        that depends on nothing of the stacked pass over [x, u, fake] (srgan.py:279-292) but the generated images -- the two
+        chains run next to each other, each into its own gradient buffer of D's arena."""
+        if not getattr(self.settings, 'overlap_gradient_penalty', False) or not examples_on_gpu() or self.parallel or \
+                torch.cuda.is_current_stream_capturing() or getattr(self.D, '_srgan_arena', None) is None:
+            return None
+        if getattr(self, '_gp_stream', None) is None:
+            self._gp_stream = torch.cuda.Stream()
+        return self._gp_stream
+
+    def _gradient_penalty_on_its_own_stream(self, stream, fake_examples, unlabeled_examples):
+        main = torch.cuda.current_stream()
+        stream.wait_stream(main)                          # the generated images, the batch, last step's weight update
+        arena = self.D._srgan_arena
+        with torch.cuda.stream(stream):
+            with arena.gradients_into_alternate() as alternate:
+                F.fill_(alternate, 0.0)
+                with self.precision('penalty'):
+                    gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
+                    self.scaled_backward(gradient_penalty)
+        for var in (gradient_penalty, self.gradient_norm, self.interpolates_features):
+            if var is not None:
+                var.data.record_stream(main)              # read on the main stream after the join (summaries)
+        return gradient_penalty
+
     def _apply_stream_settings(self):
         """``settings.wgrad_stream`` (None: leave the module default / SRGAN_WGRAD_STREAM) -> ``fused.WGRAD_STREAM``."""
         wanted = getattr(self.settings, 'wgrad_stream', None)
@@ -535,6 +563,7 @@ class Experiment(ABC):
         self.finish_update('G', 'D')         # the previous iteration's generator update (its exchange ran under the DNN step)
         self.d_optimizer.zero_grad()
         batch_size = unlabeled_examples.shape[0]
+        penalty_stream = None
         with self.precision():
             if getattr(settings, 'reference_schedule', False):
                 labeled_loss = self.labeled_loss_calculation(labeled_examples, labels)
@@ -550,13 +579,23 @@ class Experiment(ABC):
                 z = self.sample_discriminator_noise(batch_size)
                 with no_grad():
                     fake_examples = self.G(z)
+                penalty_stream = self._penalty_stream()
+                if penalty_stream is not None:
+                    gradient_penalty = self._gradient_penalty_on_its_own_stream(penalty_stream, fake_examples,
+                                                                                unlabeled_examples)
                 labeled_loss, unlabeled_loss, fake_loss = self.discriminator_losses_shared_forwards(
                     labeled_examples, labels, unlabeled_examples, fake_examples)
                 self.scaled_backward(F.add(F.add(labeled_loss, unlabeled_loss), fake_loss))
         exchange = self.gradient_exchange(self.D)
-        with self.precision('penalty'):
-            gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
-            self.scaled_backward(gradient_penalty, grad_ready=exchange)   # the last backward pass into D's arena (srgan.py:295)
+        if penalty_stream is not None:
+            # the penalty chain accumulated into the arena's second gradient buffer on its own stream: join and add
+            torch.cuda.current_stream().wait_stream(penalty_stream)
+            arena = self.D._srgan_arena
+            F._binary_raw(F.B_ADD, arena.grad, arena._alternate, out=arena.grad)
+        else:
+            with self.precision('penalty'):
+                gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
+                self.scaled_backward(gradient_penalty, grad_ready=exchange)   # the last backward pass into D's arena (srgan.py:295)
         self.start_update('D', self.d_optimizer, exchange)
         generator_loss = None
         if step % settings.generator_training_step_period == 0:

@@ -238,7 +238,8 @@ def test_crowd_steps(pkg, name, size, steps, reference_schedule, overlap=False, 
         lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
         dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
              gradient_penalty_multiplier=1e2, map_multiplier=1e-3, reference_schedule=reference_schedule,
-             overlap_dnn_step=overlap or streams, wgrad_stream=streams, overlap_generator_forwards=streams), crowd=True)
+             overlap_dnn_step=overlap or streams, wgrad_stream=streams, overlap_generator_forwards=streams,
+             overlap_gradient_penalty=streams), crowd=True)
     scale = float(g['d_scale'])
     if scale != 1.0:
         with torch.no_grad():
