@@ -431,12 +431,13 @@ class Experiment(ABC):
         return self._aux_stream
 
     def _penalty_stream(self):
-        """A stream of its own for the gradient-penalty chain (``settings.overlap_gradient_penalty``; single device, shared-
-        forwards schedule, not while a HIP graph is captured): D(interpolates), the recorded gradient w.r.t. them, the double
+        """A stream of its own for the gradient-penalty chain (``settings.overlap_gradient_penalty``; shared-forwards
+        schedule, not while a HIP graph is captured; under data parallelism D's gradient exchange then starts after the
+        two chains have joined and runs under the generator forward instead of under the penalty's backward): D(interpolates), the recorded gradient w.r.t. them, the double
         backward and the backward through the forward graph (reference srgan.py:294-295) are a chain of batch-sized kernels
         that depends on nothing of the stacked pass over [x, u, fake] (srgan.py:279-292) but the generated images -- the two
         chains run next to each other, each into its own gradient buffer of D's arena."""
-        if not getattr(self.settings, 'overlap_gradient_penalty', False) or not examples_on_gpu() or self.parallel or \
+        if not getattr(self.settings, 'overlap_gradient_penalty', False) or not examples_on_gpu() or \
                 torch.cuda.is_current_stream_capturing() or getattr(self.D, '_srgan_arena', None) is None:
             return None
         if getattr(self, '_gp_stream', None) is None:

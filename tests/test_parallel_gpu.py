@@ -28,7 +28,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _step(dp, queue=None, broadcast=False):
+def _step(dp, queue=None, broadcast=False, streams=False):
     import srgan_amd  # noqa: F401
     from test_steps_gpu import make_experiment, finish_setup, run_step, crowd_inputs
     from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
@@ -37,7 +37,8 @@ def _step(dp, queue=None, broadcast=False):
     experiment = make_experiment(
         lambda: (DCGenerator(image_size=SIZE), KnnDenseNetCat(image_size=SIZE), KnnDenseNetCat(image_size=SIZE)),
         dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
-             gradient_penalty_multiplier=1e2, map_multiplier=1e-3), crowd=True)
+             gradient_penalty_multiplier=1e2, map_multiplier=1e-3, overlap_dnn_step=streams, wgrad_stream=streams,
+             overlap_generator_forwards=streams, overlap_gradient_penalty=streams), crowd=True)
     experiment.dp = dp
     scale = float(g['d_scale'])
     if scale != 1.0:
@@ -78,7 +79,7 @@ def _step(dp, queue=None, broadcast=False):
     return result, tensors
 
 
-def _worker(rank, world_size, port, queue, backend='gloo', force=False):
+def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=False):
     device = rank if backend == 'nccl' else 0          # RCCL: one device per rank; gloo: both ranks on cuda:0
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
                       LOCAL_RANK=str(device), HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -91,16 +92,16 @@ def _worker(rank, world_size, port, queue, backend='gloo', force=False):
     assert torch.distributed.get_backend() == backend
     if force:                                            # what Experiment.train() does before the first step
         assert dp.broadcast_object({'trial': 'x', 'skip': False}) == {'trial': 'x', 'skip': False}
-    _step(dp, queue, broadcast=force)
+    _step(dp, queue, broadcast=force, streams=streams)
     dp.barrier()
     torch.distributed.destroy_process_group()
 
 
-def _run_ranks(world_size, backend, force=False):
+def _run_ranks(world_size, backend, force=False, streams=False):
     context = mp.get_context('spawn')
     queue = context.Queue()
     port = _free_port()
-    workers = [context.Process(target=_worker, args=(rank, world_size, port, queue, backend, force))
+    workers = [context.Process(target=_worker, args=(rank, world_size, port, queue, backend, force, streams))
                for rank in range(world_size)]
     for worker in workers:
         worker.start()
@@ -111,9 +112,12 @@ def _run_ranks(world_size, backend, force=False):
     return outputs
 
 
-def test_one_rank_over_rccl_with_the_exchanges_forced_equals_the_plain_step():
+@pytest.mark.parametrize('streams', [False, True])
+def test_one_rank_over_rccl_with_the_exchanges_forced_equals_the_plain_step(streams):
+    """``streams``: bench.py's side-stream schedule on top (DNN step, penalty chain, weight gradients, D(unlabeled)): the
+    collectives are then issued from several streams, D's exchange after the two chains have joined."""
     reference_result, reference_tensors = _step(None)
-    (rank, result, tensors, launched), = _run_ranks(1, 'nccl', force=True)
+    (rank, result, tensors, launched), = _run_ranks(1, 'nccl', force=True, streams=streams)
     assert launched['DNN'] and launched['D'] and launched['G'], launched     # every arena went through all_reduce
     for key, value in reference_result.items():
         # one rank: every all-reduce is the identity, so only the order of the fp32 atomics differs between the runs
@@ -125,16 +129,16 @@ def test_one_rank_over_rccl_with_the_exchanges_forced_equals_the_plain_step():
     import conftest
     conftest.PARITY_NOTES.append('data-parallel step over nccl (RCCL), world size 1 with the exchanges forced on: '
                                  f'{sum(len(b) for runs in launched.values() for b in runs)} gradient buckets all-reduced, '
-                                 'losses equal the plain step')
+                                 f'losses equal the plain step (side streams {"on" if streams else "off"})')
 
 
-@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
-def test_two_ranks_equal_one_rank_on_the_global_batch(backend):
+@pytest.mark.parametrize('backend,streams', [('gloo', False), ('gloo', True), ('nccl', False), ('nccl', True)])
+def test_two_ranks_equal_one_rank_on_the_global_batch(backend, streams):
     if backend == 'nccl' and torch.cuda.device_count() < 2:
         pytest.skip('two ranks over nccl (RCCL) need two GPUs; this box has %d (the world-size-1 nccl test above ran)'
                     % torch.cuda.device_count())
     reference_result, reference_tensors = _step(None)
-    outputs = [output[:3] for output in _run_ranks(2, backend)]
+    outputs = [output[:3] for output in _run_ranks(2, backend, streams=streams)]
     for rank, result, tensors in outputs:
         for key, value in reference_result.items():
             assert abs(result[key] - value) <= 1e-3 * max(abs(value), 1e-6), (rank, key, result[key], value)
