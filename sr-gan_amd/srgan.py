@@ -410,7 +410,10 @@ class Experiment(ABC):
         side = self._dnn_side_stream()
         if side is None:
             return self._dnn_training_step(examples, labels, step)
-        side.wait_stream(torch.cuda.current_stream())          # the batch was produced on the main stream
+        if not self._batches_are_resident():
+            side.wait_stream(torch.cuda.current_stream())      # the batch was produced on the main stream
+        # (resident batches: the DNN step of iteration i + 1 may start while iteration i's generator step still runs --
+        # the DNN shares nothing with the GAN networks, so its stream only ever waits for its own previous step)
         with torch.cuda.stream(side):
             self._dnn_training_step(examples, labels, step)
 
@@ -465,6 +468,9 @@ class Experiment(ABC):
         if wanted is not None:
             from . import fused
             fused.WGRAD_STREAM = bool(wanted)
+
+    def _batches_are_resident(self):
+        return bool(getattr(self.train_dataset_loader, 'resident', False))
 
     def _join_side_stream(self):
         stream = getattr(self, '_dnn_stream', None)
@@ -612,7 +618,11 @@ class Experiment(ABC):
         self.finish_update('D', 'DNN')
         self.last_losses.update(labeled_loss=labeled_loss, unlabeled_loss=unlabeled_loss, fake_loss=fake_loss,
                                 gradient_penalty=gradient_penalty, generator_loss=generator_loss)
-        self._join_side_stream()
+        if not self._batches_are_resident() or self.gan_summary_writer.is_summary_step() or \
+                self.dnn_summary_writer.is_summary_step():
+            # (a batch that is freed after the iteration must outlive its DNN step; resident batches let the DNN stream
+            # run on into the next iteration -- everything that reads the DNN joins it first, join_dnn_stream())
+            self._join_side_stream()
         if self.gan_summary_writer.is_summary_step():
             writer = self.gan_summary_writer
             if generator_loss is not None:

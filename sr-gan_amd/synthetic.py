@@ -11,6 +11,9 @@ from .utility import current_device
 
 class SyntheticLoader:
     """An endless iterable of pre-generated device batches (``pool`` distinct batches, cycled)."""
+    # The batches exist -- complete, in HBM -- before the first step and are never freed: a consumer on another stream
+    # needs no ordering against the stream that "produced" them (see Experiment.dnn_training_step).
+    resident = True
 
     def __init__(self, make_batch, pool=4):
         self.batches = [make_batch(i) for i in range(pool)]
