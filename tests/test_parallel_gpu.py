@@ -120,8 +120,10 @@ def test_one_rank_over_rccl_with_the_exchanges_forced_equals_the_plain_step(stre
     (rank, result, tensors, launched), = _run_ranks(1, 'nccl', force=True, streams=streams)
     assert launched['DNN'] and launched['D'] and launched['G'], launched     # every arena went through all_reduce
     for key, value in reference_result.items():
-        # one rank: every all-reduce is the identity, so only the order of the fp32 atomics differs between the runs
-        assert abs(result[key] - value) <= 1e-5 * max(abs(value), 1e-6), (key, result[key], value)
+        # one rank: every all-reduce is the identity, so only the order of the fp32 atomics differs between the runs (the
+        # generator loss is evaluated after D's Adam step, where a rounding-level gradient may flip an update's sign:
+        # observed 2e-5 between two plain runs; the parity bar is 1e-3)
+        assert abs(result[key] - value) <= 1e-4 * max(abs(value), 1e-6), (key, result[key], value)
     for key, value in reference_tensors.items():
         limit = 2.2e-4 + 1e-3 * float(np.abs(value).max())
         assert float(np.abs(tensors[key] - value).max()) <= limit, key
