@@ -289,6 +289,7 @@ def dense_block(x, layers):
     # Small planes make the convolutions split K over the grid (fp32 atomics into a zeroed output): one zero-fill for
     # ALL the layers' outputs instead of one fill launch per convolution.
     zero_b1 = zero_new = False
+    b1_all = None
     if prologue:
         last_cin = c0 + (len(layers) - 1) * growth
         zero_b1 = lib.srgan_conv2d_fwd_bnrelu_splits(_desc(n, last_cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0)) > 1
@@ -297,14 +298,16 @@ def dense_block(x, layers):
             F._call('srgan_fill', buffer.data_ptr(), buffer.numel(), 0.0, stream)
         if zero_b1:
             b1_all = _zeros((len(layers), n, width, h, w), device)
-        elif requires:
-            b1_all = _empty((len(layers), n, width, h, w), device)     # one tensor: the grouped weight gradient indexes it
+        elif requires and GROUPED_WGRAD:
+            # one tensor: the grouped weight gradients index it (peak memory: the slices cannot be freed layer by layer in
+            # the backward, L x n x width x h x w x 4 B more than per-layer tensors -- paid only while the grouped form is on)
+            b1_all = _empty((len(layers), n, width, h, w), device)
     F._call('srgan_copy_channels', x.data.data_ptr(), c0, 0, buffer.data_ptr(), total, 0, c0, n, hw, 0, stream)
     forward1 = 'srgan_conv2d_fwd_bnrelu_into_zeros' if zero_b1 else 'srgan_conv2d_fwd_bnrelu'
     forward2 = 'srgan_conv2d_fwd_bnrelu_into_zeros' if zero_new else 'srgan_conv2d_fwd_bnrelu'
     for index, layer in enumerate(layers):
         cin = c0 + index * growth
-        b1 = b1_all[index] if prologue and (zero_b1 or requires) else _empty((n, width, h, w), device)
+        b1 = b1_all[index] if b1_all is not None else _empty((n, width, h, w), device)
         if prologue:
             F._call(forward1, _desc(n, cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0), buffer.data_ptr(),
                     bn_struct(layer.norm1), layer.conv1.weight.data_ptr(), None, b1.data_ptr(), stream)
@@ -361,7 +364,7 @@ def dense_block(x, layers):
         # DNN side stream, crashed the runtime)
         side_ok = WGRAD_STREAM and want_params and prologue and not recorded and not torch.cuda.is_current_stream_capturing()
         grouped = None
-        if GROUPED_WGRAD and want_params and prologue and not recorded:
+        if GROUPED_WGRAD and want_params and prologue and not recorded and b1_all is not None:
             grouped = _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device)
         overlap = side_ok and grouped is None     # no grouped form for this geometry: the per-layer launches go to the side stream
         # (recorded: the double backward's grouped weight gradients index the kept gradients through one tensor, too)

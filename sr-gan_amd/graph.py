@@ -24,6 +24,7 @@ from .tape import Var
 
 # attributes a training step leaves on the experiment for summaries / tests; after a replay they must again refer to
 # the captured tensors (an eager summary step in between rebinds them)
+MAX_RECORDS = 4          # captured graphs kept per experiment (they share one memory pool)
 STEP_OUTPUTS = ('last_losses', 'gradient_norm', 'labeled_features', 'unlabeled_features', 'fake_features',
                 'interpolates_features')
 
@@ -107,15 +108,22 @@ class CapturedIteration:
         static_inputs = _rebuild(inputs, iter(static))
         injected, e.injected_draws = e.injected_draws, dict(draws)
         graph = torch.cuda.CUDAGraph()
+        # ONE memory pool for every captured graph of this experiment: replays are strictly sequential and the step outputs
+        # are read before the next replay, so the graphs (generator / no-generator phase, other learning rates, a ragged last
+        # batch) can share their activation memory instead of holding a private copy each.
+        pool = next(iter(self.records.values()))['graph'].pool() if self.records else None
+        if len(self.records) >= MAX_RECORDS:                  # bounded: the oldest capture (and its tensors) goes
+            self.records.pop(next(iter(self.records)))
+        advanced = None
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, pool=pool):
                 e.dnn_training_step(static_inputs[0], static_inputs[1], step)
                 e.gan_training_step(static_inputs[0], static_inputs[1], static_inputs[2], step)
+            advanced = [optimizer.step_count - count for optimizer, count in zip(optimizers, before)]
         finally:
             e.injected_draws = injected
-        advanced = [optimizer.step_count - count for optimizer, count in zip(optimizers, before)]
-        for optimizer, count in zip(optimizers, before):       # capturing recorded the launches, it did not run them
-            optimizer.step_count = count
+            for optimizer, count in zip(optimizers, before):   # capturing recorded the launches, it did not run them
+                optimizer.step_count = count                   # (also when the capture raised)
         outputs = {}
         for name in STEP_OUTPUTS:
             value = getattr(e, name, None)
