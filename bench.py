@@ -123,7 +123,9 @@ def build_experiment(args, dp):
     settings.learning_rate = 1e-4
     settings.reference_schedule = args.reference_schedule
     streams = side_streams(args)
-    settings.overlap_dnn_step = settings.wgrad_stream = settings.overlap_generator_forwards = streams
+    settings.overlap_dnn_step = streams and not os.environ.get('SRGAN_NO_DNN_STREAM')
+    settings.wgrad_stream = streams and not os.environ.get('SRGAN_NO_WGRAD_STREAM')
+    settings.overlap_generator_forwards = streams and not os.environ.get('SRGAN_NO_AUX_STREAM')
     settings.overlap_gradient_penalty = streams and not os.environ.get('SRGAN_NO_PENALTY_STREAM')
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
     settings.step_graph = bool(args.step_graph)
