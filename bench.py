@@ -79,9 +79,9 @@ def parse():
     parser.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     parser.add_argument('--overlap-dnn', action='store_true', help=argparse.SUPPRESS)      # (the default now; kept for old command lines)
     parser.add_argument('--single-stream', action='store_true',
-                        help='timed region on ONE stream.  Default: the DNN step, the grouped weight gradients of every dense '
-                             'block and the un-differentiated D(unlabeled) forward of the generator step run on side streams '
-                             'next to the main chain (the event-bracketed roofline step is always single-stream)')
+                        help='timed region on ONE stream.  Default: the DNN step, the gradient-penalty chain and the '
+                             'un-differentiated D(unlabeled) forward of the generator step run on streams of their own next to '
+                             'the main chain (the event-bracketed roofline step is always single-stream)')
     parser.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL)')
     parser.add_argument('--force-dp', action='store_true',
                         help='keep the data-parallel path on at world size 1: the feature-sum all-reduce, the asynchronous '
@@ -124,7 +124,10 @@ def build_experiment(args, dp):
     settings.reference_schedule = args.reference_schedule
     streams = side_streams(args)
     settings.overlap_dnn_step = streams and not os.environ.get('SRGAN_NO_DNN_STREAM')
-    settings.wgrad_stream = streams and not os.environ.get('SRGAN_NO_WGRAD_STREAM')
+    # (the grouped weight gradients on a stream of their own gained +4 % next to ONE chain, but with three chains in flight
+    # a fifth / sixth / seventh stream aliases onto the four hardware queues of the HIP runtime and creates false
+    # dependencies between the chains: 70.3 or 74.9 images/s from run to run, against a steady 75.1 without it)
+    settings.wgrad_stream = streams and bool(os.environ.get('SRGAN_BENCH_WGRAD_STREAM'))
     settings.overlap_generator_forwards = streams and not os.environ.get('SRGAN_NO_AUX_STREAM')
     settings.overlap_gradient_penalty = streams and not os.environ.get('SRGAN_NO_PENALTY_STREAM')
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
@@ -445,8 +448,9 @@ def main():
                                              'so an unbounded run diverges; every step runs its full arithmetic)'},
     }
     captured = getattr(experiment, '_captured_iteration', None)
-    result['config']['streams'] = ('timed region: main chain + DNN step / gradient-penalty chain / grouped weight gradients / D(unlabeled) of '
-                                   'the generator step on side streams; roofline step: single stream' if side_streams(args) else 'single stream')
+    result['config']['streams'] = ('timed region: four streams = the four hardware queues of the HIP runtime -- main chain (stacked discriminator '
+                                   'pass, generator step), gradient-penalty chain, DNN step, D(unlabeled) of the generator step; roofline '
+                                   'step: single stream' if side_streams(args) else 'single stream')
     result['config']['launch'] = (f'HIP graph replay ({captured.replays} replayed, {captured.eager_iterations} eager iterations)'
                                   if captured is not None else 'eager (Python tape enqueues every kernel)')
     if dp is not None:
