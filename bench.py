@@ -234,10 +234,34 @@ def hbm_kernel_rates(experiment):
     bn_s = timed(lambda: lib.srgan_bn_act_bwd(g.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(),
                                              beta.data_ptr(), 1, gx.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
                                              n, c, hw, 0, 0, 0, 0, 0, stream), 20)
-    return {'peak_GBps': 8000.0,
-            'adam': {'achieved_GBps': 28.0 * params / adam_s / 1e9, 'bytes_per_parameter': 28, 'parameters': params},
-            'batch_norm_backward': {'achieved_GBps': 12.0 * n * c * hw / bn_s / 1e9, 'bytes_per_element': 12,
-                                    'shape': [n, c, 32, 32]}}
+    # the fused data gradient of a dense layer's bottleneck convolution (K = 128) with its batch-norm backward epilogue,
+    # accumulating into the block's gradient buffer: HBM-bound by construction -- per pixel 4 * (128 + 3 * C_in) bytes (the
+    # gradient tile in; x for the mask, the gradient buffer in and out) for 2 * 128 * C_in FLOP (dense block 3, layer 24)
+    k, cin, total = 128, 1024, 1056
+    buffer = torch.randn(n, total, hw, device='cuda')
+    gbuf = torch.zeros(n, total, hw, device='cuda')
+    gy = torch.randn(n, k, hw, device='cuda')
+    weight = torch.randn(k, cin, device='cuda') / cin ** 0.5
+    bn = _lib.BnRelu(mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(), beta.data_ptr())
+    desc = _lib.ConvDesc(n, cin, 32, 32, k, 1, 1, 1, 1, 0, 0, 32, 32, total * hw, 0)
+    dg_s = timed(lambda: _lib.check(lib.srgan_conv2d_bwd_data_bnrelu(desc, gy.data_ptr(), weight.data_ptr(), bn, buffer.data_ptr(),
+                                                                     gbuf.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                                                                     1, stream), 'srgan_conv2d_bwd_data_bnrelu'), 20)
+    dg_bytes = 4.0 * (k + 3 * cin) * n * hw
+    achievable = 6300.0                              # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s of the data sheet
+    rates = {'peak_GBps': 8000.0, 'achievable_GBps': achievable,
+             'adam': {'achieved_GBps': 28.0 * params / adam_s / 1e9, 'bytes_per_parameter': 28, 'parameters': params},
+             'batch_norm_backward': {'achieved_GBps': 12.0 * n * c * hw / bn_s / 1e9, 'bytes_per_element': 12,
+                                     'shape': [n, c, 32, 32]},
+             'bottleneck_data_gradient_with_epilogue': {
+                 'achieved_GBps': dg_bytes / dg_s / 1e9, 'bytes_per_pixel': 4 * (k + 3 * cin), 'shape': [n, cin, 32, 32],
+                 'achieved_TFLOPs': 2.0 * k * cin * n * hw / dg_s / 1e12,
+                 'note': 'both rooflines are close at this shape (21 FLOP/B): the kernel alternates matrix and epilogue '
+                         'phases, see DESIGN.md'}}
+    for entry in rates.values():
+        if isinstance(entry, dict):
+            entry['fraction_of_achievable'] = entry['achieved_GBps'] / achievable
+    return rates
 
 
 def usable_cores():

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <type_traits>
+#include <type_traits>
 #include <utility>
 
 namespace srgan {
@@ -52,9 +53,13 @@ struct TileBK { static constexpr int value = (BM * BN >= 128 * 128 || BN >= 256)
 // m/n that share one address decode): the 1x1 convolutions and linear layers, i.e. plain GEMMs on NCHW data.
 // The host (vec_eligible) guarantees that every group is 16-byte aligned and entirely valid or entirely invalid.
 // PREC: 0 = v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak); 1 / 2 = v_mfma_f32_32x32x16_bf16 / _f16 (2.5 PF/s peak):
-// the tiles in LDS stay fp32 and every lane rounds its 8 consecutive-k operand values when it forms the fragment (lane l
-// holds row / column l & 31 and k = 8 * (l >> 5) .. + 7 of a 16-deep step), accumulation is fp32 and the C/D fragment
-// layout is the same, so staging and epilogue are shared.  The mixed-precision modes of BASELINE.json configs 2 and 5.
+// lane l of a fragment holds row / column l & 31 and k = 8 * (l >> 5) .. + 7 of a 16-deep step.  The tiles in LDS are
+// OPERAND-TYPED (round 3): stage() rounds the fp32 values it fetched and writes them as [row][k] with k contiguous and a
+// row stride of BK + 8 elements (80 / 48 bytes: the sixteen lanes of a ds_read_b128 group hit sixteen different bank
+// quads), so a fragment is ONE ds_read_b128 -- it used to be eight ds_read_b32 of fp32 values plus eight conversions per
+// fragment, which kept the kernel at 66-79 TF/s in the bf16 mode, below its own fp32 rate.  Accumulation is fp32 and the
+// C/D fragment layout is the same, so fetch and epilogue are shared.  The mixed-precision modes of BASELINE.json configs
+// 2 and 5.
 template <int BM, int BN, int WGM, bool AKF, bool BKF, bool VEC, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
   constexpr int BK = TileBK<BM, BN, VEC>::value;
@@ -142,7 +147,47 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
       load_group(p.B, sk.off + sn.off, ok, rb[e]);
     }
   };
+  using half_t = typename std::conditional<PREC == 2, _Float16, __bf16>::type;
+  typedef half_t half4_t __attribute__((ext_vector_type(4)));
+  constexpr int LDK = BK + 8;                                     // PREC: elements per operand-typed LDS row
+  half_t* As16 = reinterpret_cast<half_t*>(lds);
+  half_t* Bs16 = As16 + BM * LDK;
+  static_assert(PREC == 0 || (BM + BN) * (BK + 8) * 2 <= (BK * LDA + BK * LDB) * 4, "the typed tiles fit the fp32 allocation");
+  auto stage_typed = [&](half_t* tile, const float (&v)[G], int row, int kk, bool kfast) {
+    if (kfast && VEC) {
+      half4_t packed;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) packed[i] = (half_t)v[G > i ? i : 0];
+      *reinterpret_cast<half4_t*>(&tile[row * LDK + kk]) = packed;      // four consecutive k of one row: 8 aligned bytes
+    } else if (kfast) {
+      tile[row * LDK + kk] = (half_t)v[0];
+    } else {
+#pragma unroll
+      for (int i = 0; i < G; ++i) tile[(row + i) * LDK + kk] = (half_t)v[i];   // G consecutive rows at one k
+    }
+  };
   auto stage = [&]() {
+    if constexpr (PREC != 0) {
+#pragma unroll
+      for (int e = 0; e < EA; ++e) {
+        if (!a_on[e]) continue;
+        const bool ok = (a_ok >> e) & 1u;
+        float v[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[i] = ok ? ra[e][i] : 0.f;
+        stage_typed(As16, v, a_ml[e], a_kk[e], AKF);
+      }
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        if (!b_on[e]) continue;
+        const bool ok = (b_ok >> e) & 1u;
+        float v[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[i] = ok ? rb[e][i] : 0.f;
+        stage_typed(Bs16, v, b_nl[e], b_kk[e], BKF);
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
       if (!a_on[e]) continue;
@@ -198,21 +243,13 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
         using frag = typename std::conditional<PREC == 1, bf16x8, f16x8>::type;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-          frag a[MI], b[NI];
+          frag a[MI], b[NI];                   // one ds_read_b128 each: 8 consecutive k of this lane's row / column
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float v = As[(kk + 8 * lhi + j) * LDA + wm0 + mi * 32 + l31];
-              if constexpr (PREC == 1) a[mi][j] = (__bf16)v; else a[mi][j] = (_Float16)v;
-            }
+            a[mi] = *reinterpret_cast<const frag*>(&As16[(wm0 + mi * 32 + l31) * LDK + kk + 8 * lhi]);
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float v = Bs[(kk + 8 * lhi + j) * LDB + wn0 + ni * 32 + l31];
-              if constexpr (PREC == 1) b[ni][j] = (__bf16)v; else b[ni][j] = (_Float16)v;
-            }
+            b[ni] = *reinterpret_cast<const frag*>(&Bs16[(wn0 + ni * 32 + l31) * LDK + kk + 8 * lhi]);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
