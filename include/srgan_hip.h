@@ -317,12 +317,19 @@ int srgan_crowd_extract_patches(const void* const* images_u8, const float* const
  * clipped at upper_bound when upper_bound > 0, + epsilon).  heads_yx: M (y, x) pairs, float; k <= 8 and k = min(k, M) as in the reference. */
 int srgan_crowd_iknn_map(const float* heads_yx, int32_t M, int32_t H, int32_t W, int32_t k, float epsilon, float upper_bound,
                          float* out, void* stream);
-/* Gaussian density label before its final rescaling (reference generate_density_label with perspective = None,
- * crowd/database_preprocessor.py:110-236: sigma_h = beta * mean distance of head h to its <= 11 nearest heads including
- * itself, window half-size int(2 sigma_h), each window normalised by its unclipped sum): out[y, x] = sum over heads.
- * workspace: 20 * M bytes of device memory.  The caller multiplies by head_count / sum(out) as the reference does. */
-int srgan_crowd_density_label(const float* heads_yx, int32_t M, int32_t H, int32_t W, float beta, void* workspace, float* out,
-                              void* stream);
+/* Gaussian density label before its final rescaling (reference generate_density_label + make_gaussian,
+ * crowd/database_preprocessor.py:110-249), every variant: out[y, x] = sum over the heads' (and bodies') windowed Gaussians,
+ * each normalised by body_parts x its unclipped window sum.
+ *   perspective == NULL: sigma_h = beta * mean distance of head h to its <= 11 nearest heads including itself (the
+ *     "density{beta}" labels of :82-91);
+ *   perspective = device map [H][W]: sigma_h = 0.2 m * perspective[y_h, x_h]; flag 2 (ignore_tiny) drops heads with a
+ *     perspective < 3.1 (they do not count); flag 1 (include_body) adds a second Gaussian 0.875 m below the head with sigma
+ *     (0.2 m, 0.5 m) * perspective and halves both normalisers;
+ *   flag 4: perspective_resizing = False (sigma = 8 pixels); flag 8: positions are (x, y) pairs (yx_order = False).
+ * Window half-sizes int(2 sigma).  workspace: 64 * M bytes of device memory; after the call float 7 of record 2 * h is 1
+ * when head h counts.  The caller multiplies by counted heads / sum(out) (force_full_image_count_normalize). */
+int srgan_crowd_density_label(const float* heads, int32_t M, int32_t H, int32_t W, float beta, const float* perspective,
+                              int32_t flags, void* workspace, float* out, void* stream);
 
 /* Adam on a flat arena, torch.optim.Adam defaults and operation order (reference srgan.py:131-138,266,297,305);
  * `step` is the 1-based update count. */

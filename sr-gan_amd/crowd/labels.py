@@ -38,22 +38,45 @@ def generate_iknn_map(head_positions, label_size, number_of_neighbors=1, epsilon
     return out
 
 
-def generate_density_label(head_positions, label_size, neighbor_deviation_beta=0.15, device=None):
-    """The Gaussian density label of the reference's preprocessor for databases without a perspective map
-    (``generate_density_label(positions, size, perspective_resizing=True, yx_order=True, neighbor_deviation_beta=beta)``,
-    crowd/database_preprocessor.py:82-91,110-236): every head a Gaussian of sigma = beta x its mean distance to its 11
-    nearest heads (itself included), windowed at int(2 sigma), normalised, and the whole label rescaled to the head
-    count.  float32 device tensor [H, W]."""
+def generate_density_label(head_positions, label_size, perspective=None, include_body=False, ignore_tiny=False,
+                           force_full_image_count_normalize=True, perspective_resizing=True, yx_order=True,
+                           neighbor_deviation_beta=0.15, device=None):
+    """The Gaussian density label of the reference's preprocessor (``generate_density_label``,
+    crowd/database_preprocessor.py:110-223; same keyword arguments), as a float32 device tensor [H, W]:
+
+    * ``perspective=None``: every head a Gaussian of sigma = beta x its mean distance to its 11 nearest heads (itself
+      included) -- the "density{beta}" labels of databases without a perspective map (:82-91);
+    * ``perspective`` = an [H, W] map (pixels per metre): sigma = 0.2 m x the perspective at the head; ``ignore_tiny`` drops
+      heads whose perspective is below 3.1; ``include_body`` adds a body Gaussian (0.2 m x 0.5 m, 0.875 m below the head) and
+      gives head and body half a person each;
+    * ``perspective_resizing=False``: sigma = 8 pixels for every head.
+
+    Windows reach int(2 sigma), are normalised before clipping, and the label is rescaled to the number of counted heads
+    unless ``force_full_image_count_normalize=False``.  ``yx_order``: positions are (y, x) pairs (what the dataset
+    preprocessors pass; the reference's default is (x, y))."""
     device = device or current_device()
     heads = torch.as_tensor(np.ascontiguousarray(head_positions, dtype=np.float32)).to(device)
-    if heads.ndim != 2 or heads.shape[1] != 2 or heads.shape[0] < 2:
-        raise ValueError('head_positions must be an (M >= 2, 2) array of (y, x) pairs')
+    if heads.ndim != 2 or heads.shape[1] != 2 or heads.shape[0] == 0:
+        raise ValueError('head_positions must be a non-empty (M, 2) array')
     height, width = int(label_size[0]), int(label_size[1])
+    spacing_based = perspective is None and perspective_resizing
+    if spacing_based and heads.shape[0] < 2:
+        raise ValueError('the neighbour-spacing label needs at least two heads')
+    perspective_map = None
+    if perspective is not None and perspective_resizing:
+        perspective_map = torch.as_tensor(np.ascontiguousarray(perspective, dtype=np.float32)).to(device)
+        if tuple(perspective_map.shape) != (height, width):
+            raise ValueError(f'perspective map {tuple(perspective_map.shape)} does not match the label size {(height, width)}')
+    flags = (1 if include_body else 0) | (2 if ignore_tiny else 0) | (0 if perspective_resizing else 4) | (0 if yx_order else 8)
     out = torch.empty((height, width), dtype=torch.float32, device=device)
-    workspace = torch.empty((heads.shape[0], 5), dtype=torch.float32, device=device)
+    workspace = torch.empty((heads.shape[0], 2, 8), dtype=torch.float32, device=device)
     _lib.check(_lib.library().srgan_crowd_density_label(heads.data_ptr(), heads.shape[0], height, width,
-                                                        float(neighbor_deviation_beta), workspace.data_ptr(), out.data_ptr(),
+                                                        float(neighbor_deviation_beta),
+                                                        perspective_map.data_ptr() if perspective_map is not None else None,
+                                                        flags, workspace.data_ptr(), out.data_ptr(),
                                                         torch.cuda.current_stream(device).cuda_stream),
                'srgan_crowd_density_label')
-    counted = (workspace[:, 4] > 0).sum()             # heads whose window reaches the image
+    if not force_full_image_count_normalize:
+        return out
+    counted = workspace[:, 0, 7].sum()                # heads the label counts (all but those `ignore_tiny` dropped)
     return out * (counted / out.sum())

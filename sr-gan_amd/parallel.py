@@ -145,14 +145,23 @@ class DataParallel:
         dist.all_reduce(holder, op=dist.ReduceOp.MAX, group=self.group)
         return float(holder.item())
 
-    def all_reduce_sum_var(self, var):
-        """Tape version: forward all-reduce of a (small) var, identity backward."""
+    def all_reduce_sum_var(self, var, reduce_backward=False):
+        """Tape version: forward all-reduce of a (small) var.  Backward: the identity when every rank goes on to compute
+        the SAME function of the sum (each then holds the full gradient w.r.t. it already); with ``reduce_backward`` the
+        gradient is all-reduced as well -- for a sum that feeds rank-specific terms of a loss that is itself a sum over
+        ranks (the ``normalize_feature_norm`` branch, whose distance runs over every rank's own rows)."""
         from .tape import Var, Node, grad_enabled
         data = var.data.clone()
         dist.all_reduce(data, op=dist.ReduceOp.SUM, group=self.group)
         out = Var(data, requires_grad=grad_enabled() and var.requires_grad)
         if out.requires_grad:
-            out.node = Node((var,), lambda g, needs: (g,), 'all_reduce_sum')
+            def backward(g, needs):
+                if not reduce_backward:
+                    return (g,)
+                total = g.data.clone()
+                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+                return (Var(total),)
+            out.node = Node((var,), backward, 'all_reduce_sum')
         return out
 
     def all_reduce_gradients(self, arena):

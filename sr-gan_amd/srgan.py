@@ -382,11 +382,12 @@ class Experiment(ABC):
     def _global_batch(self, local):
         return local if self.dp is None else self.dp.global_batch(local)
 
-    def batch_mean_of_features(self, features):
-        """Mean over the (global) batch -> shape features.shape[1:] (the ``mean(0)`` of srgan.py:442-443)."""
+    def batch_mean_of_features(self, features, rank_specific_use=False):
+        """Mean over the (global) batch -> shape features.shape[1:] (the ``mean(0)`` of srgan.py:442-443).
+        ``rank_specific_use``: what is computed from the mean differs between the ranks (see ``all_reduce_sum_var``)."""
         sums = F.col_sum(features)
         if self.parallel:
-            sums = self.dp.all_reduce_sum_var(sums)
+            sums = self.dp.all_reduce_sum_var(sums, reduce_backward=rank_specific_use)
         return F.scale(sums, 1.0 / self._global_batch(features.shape[0]))
 
     def batch_mean_of_examples(self, per_example):
@@ -639,6 +640,17 @@ class Experiment(ABC):
                         mean = self.batch_mean_of_features(features.detach())
                         writer.add_scalar('Feature Norm/' + tag, F.sqrt(F.sum_all(F.square(mean))).item())
 
+    def _distance_over_the_ranks_rows(self, distance_function, difference):
+        from . import utility
+        mean_type = (utility.abs_mean, utility.abs_mean_neg, utility.abs_plus_one_log_mean_neg,
+                     utility.abs_plus_one_sqrt_mean_neg, utility.square_mean)
+        if distance_function in mean_type:
+            return F.scale(self.dp.all_reduce_sum_var(distance_function(difference)), 1.0 / self.dp.world_size)
+        if distance_function is utility.norm_mean:
+            return F.sqrt(self.dp.all_reduce_sum_var(F.sum_all(F.square(difference))))
+        raise NotImplementedError(f'normalize_feature_norm under data parallelism: no rule to assemble '
+                                  f'{getattr(distance_function, "__name__", distance_function)} from the ranks\' rows')
+
     def loss_value(self, loss, partial=False):
         """Host value of a device scalar; ``partial`` scalars are per-rank partial sums under data parallelism."""
         value = float(loss.item())
@@ -859,15 +871,16 @@ class Experiment(ABC):
         """distance(mean_b(base) - mean_b(other)) (reference srgan.py:438-449)."""
         if distance_function is None:
             distance_function = self.settings.matching_distance_function
-        base_mean_features = self.batch_mean_of_features(base_features)
-        other_mean_features = self.batch_mean_of_features(other_features)
-        if self.settings.normalize_feature_norm:
+        normalize = self.settings.normalize_feature_norm
+        base_mean_features = self.batch_mean_of_features(base_features, rank_specific_use=normalize)
+        other_mean_features = self.batch_mean_of_features(other_features, rank_specific_use=normalize)
+        if normalize:
             # The reference's branch AS WRITTEN (srgan.py:444-447): the base mean is divided by its norm, but line 447
             # divides the un-meaned ``other_features`` (B, F) by the norm of their mean, so the difference broadcasts to
             # (B, F) and the distance function averages over examples as well.  Off by default (settings.py:39).
-            if self.parallel:
-                raise NotImplementedError('normalize_feature_norm=True averages over the (B, F) broadcast of the '
-                                          'reference (srgan.py:447); it is single-device only')
+            # Under data parallelism a rank holds its own rows of that (B, F) difference: the distance is assembled from the
+            # ranks' parts (a mean over all elements = the mean of the equally sized shards' means; a norm = the root of the
+            # summed squares), and the two batch means pass their gradients through an all-reduce of their own.
             epsilon = 1e-5
 
             def inverse_norm(vector):
@@ -877,6 +890,8 @@ class Experiment(ABC):
             other_rows = F.flatten2d(other_features)
             other_normalized = F.scalar_mul(other_rows, inverse_norm(other_mean_features))
             difference = F.sub(F.col_broadcast(base_normalized, other_rows.shape[0]), other_normalized)
+            if self.parallel:
+                return self._distance_over_the_ranks_rows(distance_function, difference)
             return distance_function(difference)
         return distance_function(F.sub(base_mean_features, other_mean_features))
 

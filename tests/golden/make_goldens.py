@@ -796,6 +796,47 @@ def g12_crowd_labels():
     save('g12_crowd_labels', **out)
 
 
+def g12b_crowd_label_variants():
+    """The other branches of the reference's ``generate_density_label`` (crowd/database_preprocessor.py:113-223): a
+    perspective map (head sigma = 0.2 m x perspective), ``include_body`` (second, anisotropic Gaussian below the head),
+    ``ignore_tiny`` (heads with a perspective < 3.1 dropped and not counted), ``perspective_resizing=False`` (sigma 8),
+    ``force_full_image_count_normalize=False`` and the (x, y) position order.  Heads keep a window's distance from the top /
+    left border (under NumPy 2 the reference's clipping there wraps around, see g12); bottom / right clipping is exercised."""
+    from crowd.database_preprocessor import generate_density_label
+    random_state = np.random.RandomState(121)
+    out = {}
+    for index, (shape, heads) in enumerate((((96, 120), 60), ((80, 100), 300))):
+        margin = 18
+        positions = margin + random_state.rand(heads, 2) * (np.array(shape) - 1 - margin)          # (y, x)
+        ys, xs = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing='ij')
+        perspective = (1.2 + 7.5 * ys / shape[0] + 0.5 * np.sin(xs / 7.0)).astype(np.float32)
+        out[f'scene{index}/shape'] = np.array(shape)
+        out[f'scene{index}/heads_yx'] = positions
+        out[f'scene{index}/perspective'] = perspective
+        tiny = int(sum(perspective[int(np.rint(y)), int(np.rint(x))] < 3.1 for y, x in positions))
+        assert 0 < tiny < heads
+        out[f'scene{index}/tiny_heads'] = np.array(tiny)
+        variants = {
+            'perspective': dict(perspective=perspective),
+            'perspective_body': dict(perspective=perspective, include_body=True),
+            'perspective_tiny': dict(perspective=perspective, ignore_tiny=True),
+            'perspective_body_tiny': dict(perspective=perspective, include_body=True, ignore_tiny=True),
+            'perspective_body_unnormalized': dict(perspective=perspective, include_body=True,
+                                                  force_full_image_count_normalize=False),
+            'body_without_perspective': dict(include_body=True, neighbor_deviation_beta=0.3),
+            'fixed_sigma': dict(perspective_resizing=False),
+            'fixed_sigma_unnormalized': dict(perspective_resizing=False, force_full_image_count_normalize=False),
+        }
+        for name, arguments in variants.items():
+            with contextlib.redirect_stdout(None):
+                out[f'scene{index}/{name}'] = generate_density_label(positions, shape, yx_order=True, **arguments)
+        with contextlib.redirect_stdout(None):
+            out[f'scene{index}/perspective_body_xy'] = generate_density_label(positions[:, ::-1], shape, perspective=perspective,
+                                                                                include_body=True, yx_order=False)
+        assert np.array_equal(out[f'scene{index}/perspective_body_xy'], out[f'scene{index}/perspective_body'])
+    save('g12b_crowd_label_variants', **out)
+
+
 def g13_crowd_patches():
     """the training-batch assembly of the reference's crowd pipeline, by its own transforms
     (crowd/shanghai_tech_data.py:76-104 composes them): ``ExtractPatchForPosition(allow_padded=True)`` around a centre
@@ -905,7 +946,7 @@ def g14_crowd_sgan(size=64, batch=4, steps=2, d_scale=3.0):
 
 ALL = {'g0': g0_toydata, 'g1': g1_distance, 'g2': g2_sgan_math, 'g3': g3_coefficient_srgan,
        'g4': g4_coefficient_sgan, 'g4b': g4b_coefficient_dggan, 'g5': g5_tiny_dcgan, 'g6': g6_layers, 'g7': g7_crowd, 'g7c': g7c_crowd_gp_active, 'g8': g8_age,
-       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan, 'g11': g11_crowd_evaluation, 'g12': g12_crowd_labels,
+       'g8b': g8b_vgg, 'g9': g9_crowd_sliding_window, 'g10': g10_crowd_dggan, 'g11': g11_crowd_evaluation, 'g12': g12_crowd_labels, 'g12b': g12b_crowd_label_variants,
        'g13': g13_crowd_patches, 'g14': g14_crowd_sgan}
 
 if __name__ == '__main__':

@@ -780,6 +780,39 @@ def test_crowd_offline_labels(F):
 
 
 @gpu
+def test_crowd_density_label_variants(F):
+    """Every branch of the reference's generate_density_label (crowd/database_preprocessor.py:113-223) against its own output
+    (golden g12b): a perspective map, include_body, ignore_tiny (dropped heads do not count), perspective_resizing=False,
+    force_full_image_count_normalize=False, body parts without a perspective map, and the (x, y) position order."""
+    from helpers import load_golden
+    from srgan_amd.crowd.labels import generate_density_label
+    g = load_golden('g12b_crowd_label_variants')
+    for index in range(2):
+        heads, shape = g[f'scene{index}/heads_yx'], tuple(int(v) for v in g[f'scene{index}/shape'])
+        perspective = g[f'scene{index}/perspective']
+        variants = {
+            'perspective': dict(perspective=perspective),
+            'perspective_body': dict(perspective=perspective, include_body=True),
+            'perspective_tiny': dict(perspective=perspective, ignore_tiny=True),
+            'perspective_body_tiny': dict(perspective=perspective, include_body=True, ignore_tiny=True),
+            'perspective_body_unnormalized': dict(perspective=perspective, include_body=True,
+                                                  force_full_image_count_normalize=False),
+            'body_without_perspective': dict(include_body=True, neighbor_deviation_beta=0.3),
+            'fixed_sigma': dict(perspective_resizing=False),
+            'fixed_sigma_unnormalized': dict(perspective_resizing=False, force_full_image_count_normalize=False),
+        }
+        for name, arguments in variants.items():
+            expected = torch.from_numpy(g[f'scene{index}/{name}'])
+            label = generate_density_label(heads, shape, **arguments)
+            close(label, expected, 1e-4, f'scene {index} {name}')
+            assert abs(float(label.sum()) - float(expected.sum())) <= 1e-3 * float(expected.sum()), name
+        label = generate_density_label(heads[:, ::-1], shape, perspective=perspective, include_body=True, yx_order=False)
+        close(label, torch.from_numpy(g[f'scene{index}/perspective_body_xy']), 1e-4, f'scene {index} (x, y) order')
+        counted = float(generate_density_label(heads, shape, perspective=perspective, ignore_tiny=True).sum())
+        assert abs(counted - (len(heads) - int(g[f'scene{index}/tiny_heads']))) < 1e-2          # ignored heads are not counted
+
+
+@gpu
 @pytest.mark.parametrize('shape', [(2, 8, 16, 16), (3, 5, 10, 12), (2, 64, 56, 56)])
 def test_fused_stem_norm_relu_pool(F, shape):
     """functional.bn_relu_max_pool2d (norm0 -> relu0 -> pool0 in one pass each way) against the two-op form: output,

@@ -28,7 +28,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _step(dp, queue=None, broadcast=False, streams=False):
+def _step(dp, queue=None, broadcast=False, streams=False, normalize=False):
     import srgan_amd  # noqa: F401
     from test_steps_gpu import make_experiment, finish_setup, run_step, crowd_inputs
     from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
@@ -38,7 +38,8 @@ def _step(dp, queue=None, broadcast=False, streams=False):
         lambda: (DCGenerator(image_size=SIZE), KnnDenseNetCat(image_size=SIZE), KnnDenseNetCat(image_size=SIZE)),
         dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
              gradient_penalty_multiplier=1e2, map_multiplier=1e-3, overlap_dnn_step=streams, wgrad_stream=streams,
-             overlap_generator_forwards=streams, overlap_gradient_penalty=streams), crowd=True)
+             overlap_generator_forwards=streams, overlap_gradient_penalty=streams, normalize_feature_norm=normalize),
+        crowd=True)
     experiment.dp = dp
     scale = float(g['d_scale'])
     if scale != 1.0:
@@ -79,7 +80,7 @@ def _step(dp, queue=None, broadcast=False, streams=False):
     return result, tensors
 
 
-def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=False):
+def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=False, normalize=False):
     device = rank if backend == 'nccl' else 0          # RCCL: one device per rank; gloo: both ranks on cuda:0
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
                       LOCAL_RANK=str(device), HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -92,16 +93,16 @@ def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=
     assert torch.distributed.get_backend() == backend
     if force:                                            # what Experiment.train() does before the first step
         assert dp.broadcast_object({'trial': 'x', 'skip': False}) == {'trial': 'x', 'skip': False}
-    _step(dp, queue, broadcast=force, streams=streams)
+    _step(dp, queue, broadcast=force, streams=streams, normalize=normalize)
     dp.barrier()
     torch.distributed.destroy_process_group()
 
 
-def _run_ranks(world_size, backend, force=False, streams=False):
+def _run_ranks(world_size, backend, force=False, streams=False, normalize=False):
     context = mp.get_context('spawn')
     queue = context.Queue()
     port = _free_port()
-    workers = [context.Process(target=_worker, args=(rank, world_size, port, queue, backend, force, streams))
+    workers = [context.Process(target=_worker, args=(rank, world_size, port, queue, backend, force, streams, normalize))
                for rank in range(world_size)]
     for worker in workers:
         worker.start()
@@ -134,13 +135,17 @@ def test_one_rank_over_rccl_with_the_exchanges_forced_equals_the_plain_step(stre
                                  f'losses equal the plain step (side streams {"on" if streams else "off"})')
 
 
-@pytest.mark.parametrize('backend,streams', [('gloo', False), ('gloo', True), ('nccl', False), ('nccl', True)])
-def test_two_ranks_equal_one_rank_on_the_global_batch(backend, streams):
+@pytest.mark.parametrize('backend,streams,normalize', [('gloo', False, False), ('gloo', True, False), ('gloo', False, True),
+                                                       ('nccl', False, False), ('nccl', True, False)])
+def test_two_ranks_equal_one_rank_on_the_global_batch(backend, streams, normalize):
+    """``normalize``: ``settings.normalize_feature_norm`` -- the reference's branch whose distance runs over the (B, F)
+    broadcast (srgan.py:444-447): every rank holds its own rows of it, the batch means pass their gradients through an
+    all-reduce of their own."""
     if backend == 'nccl' and torch.cuda.device_count() < 2:
         pytest.skip('two ranks over nccl (RCCL) need two GPUs; this box has %d (the world-size-1 nccl test above ran)'
                     % torch.cuda.device_count())
-    reference_result, reference_tensors = _step(None)
-    outputs = [output[:3] for output in _run_ranks(2, backend, streams=streams)]
+    reference_result, reference_tensors = _step(None, normalize=normalize)
+    outputs = [output[:3] for output in _run_ranks(2, backend, streams=streams, normalize=normalize)]
     for rank, result, tensors in outputs:
         for key, value in reference_result.items():
             assert abs(result[key] - value) <= 1e-3 * max(abs(value), 1e-6), (rank, key, result[key], value)
