@@ -812,7 +812,7 @@ def g12b_crowd_label_variants():
         perspective = (1.2 + 7.5 * ys / shape[0] + 0.5 * np.sin(xs / 7.0)).astype(np.float32)
         out[f'scene{index}/shape'] = np.array(shape)
         out[f'scene{index}/heads_yx'] = positions
-        out[f'scene{index}/perspective'] = perspective
+        out[f'scene{index}/perspective_map'] = perspective
         tiny = int(sum(perspective[int(np.rint(y)), int(np.rint(x))] < 3.1 for y, x in positions))
         assert 0 < tiny < heads
         out[f'scene{index}/tiny_heads'] = np.array(tiny)

@@ -789,7 +789,7 @@ def test_crowd_density_label_variants(F):
     g = load_golden('g12b_crowd_label_variants')
     for index in range(2):
         heads, shape = g[f'scene{index}/heads_yx'], tuple(int(v) for v in g[f'scene{index}/shape'])
-        perspective = g[f'scene{index}/perspective']
+        perspective = g[f'scene{index}/perspective_map']
         variants = {
             'perspective': dict(perspective=perspective),
             'perspective_body': dict(perspective=perspective, include_body=True),
