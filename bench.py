@@ -199,11 +199,13 @@ def pmc_traffic(args):
         entries = json.load(open(path))['entries']
     except (OSError, KeyError, ValueError):
         return None, 'profiles/pmc_traffic.json absent'
+    size = args.image_size if isinstance(args.image_size, int) else args.image_size[0]
     for entry in entries:
-        if (entry.get('image_size') == args.image_size and entry.get('batch_per_gpu') == args.batch_per_gpu and
-                entry.get('kernel_source_id') == _build.source_id()):
+        if (entry.get('workload', 'crowd') == args.workload and entry.get('image_size') == size and
+                entry.get('batch_per_gpu') == args.batch_per_gpu and entry.get('kernel_source_id') == _build.source_id()):
             return entry['hbm_bytes_per_launch'], entry.get('source', path)
-    return None, f'no PMC entry for image size {args.image_size}, batch {args.batch_per_gpu}, kernel sources {_build.source_id()}'
+    return None, (f'no PMC entry for workload {args.workload}, image size {size}, batch {args.batch_per_gpu}, kernel sources '
+                  f'{_build.source_id()}')
 
 
 def hbm_kernel_rates(experiment):

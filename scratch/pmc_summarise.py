@@ -1,6 +1,6 @@
 """Summarises the rocprofv3 PMC passes of one bench step into profiles/ (VERDICT r1 item 2c/2d).
 
-    python scratch/pmc_summarise.py <tag> <image_size> <batch> <dir with one sub-directory per pass> 
+    python scratch/pmc_summarise.py <tag> <image_size> <batch> <dir with one sub-directory per pass> [workload, default crowd]
 
 Passes (each `rocprofv3 --kernel-trace --pmc <counters> --output-format csv -d <dir>/<pass> -- python3 bench.py --steps 1
 --warmup 0 --no-cpu-baseline --no-roofline [--image-size S]`; counters never combined with other trace domains):
@@ -53,9 +53,10 @@ def read(directory):
 
 def main():
     tag, image_size, batch, base = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    workload = sys.argv[5] if len(sys.argv) > 5 else 'crowd'
     fetch, write, sq = (read(os.path.join(base, name)) for name in ('fetch', 'write', 'sq'))
     kernels = sorted(set(fetch) | set(write) | set(sq))
-    lines = [f'PMC summary of ONE training step ({image_size}x{image_size}, batch {batch}; setup kernels of the process included in the '
+    lines = [f'PMC summary of ONE training step (workload {workload}, {image_size}x{image_size}, batch {batch}; setup kernels of the process included in the '
              'non-contraction rows), kernel sources ' + _build.source_id() + '.', '',
              'HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE reports half of a wide coalesced read). MFMA busy = '
              'SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe cycles summed over the 1024 SIMDs; = 64 x the v_mfma_f32_32x32x2_f32 count) / '
@@ -95,11 +96,12 @@ def main():
         document = {'note': 'HBM traffic of the contraction kernels of one training step from separate rocprofv3 --pmc FETCH_SIZE / '
                             '--pmc WRITE_SIZE passes (scratch/pmc_summarise.py); hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB. '
                             'bench.py uses an entry only for the same image size, batch and kernel sources.', 'entries': []}
-    entry = {'image_size': image_size, 'batch_per_gpu': batch, 'kernel_source_id': _build.source_id(), 'source': f'profiles/{tag}_pmc_per_kernel.md',
+    entry = {'workload': workload, 'image_size': image_size, 'batch_per_gpu': batch, 'kernel_source_id': _build.source_id(), 'source': f'profiles/{tag}_pmc_per_kernel.md',
              'fetch_size_kb_raw': totals['fetch'], 'write_size_kb_raw': totals['write'], 'launches': totals['launches'],
              'hbm_bytes_per_step': per_step, 'hbm_bytes_per_launch': per_step / max(totals['launches'], 1)}
-    document['entries'] = [e for e in document['entries'] if (e['image_size'], e['batch_per_gpu'], e['kernel_source_id']) !=
-                           (image_size, batch, entry['kernel_source_id'])] + [entry]
+    document['entries'] = [e for e in document['entries']
+                           if (e.get('workload', 'crowd'), e['image_size'], e['batch_per_gpu'], e['kernel_source_id']) !=
+                           (workload, image_size, batch, entry['kernel_source_id'])] + [entry]
     json.dump(document, open(path, 'w'), indent=1)
     print('\n'.join(lines[-3:]))
 

@@ -236,9 +236,19 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
                     input_grads = node.backward(g, needs)
                 finally:
                     _exclusive = False
-                handed_out = [id(pg) for pg in input_grads if pg is not None]
-                for pg in input_grads:      # one var handed to several inputs (or passed through): not exclusive
-                    if pg is not None and (handed_out.count(id(pg)) > 1 or pg is g or id(g) in shared and pg.data.data_ptr() == g.data.data_ptr()):
+                # Which of the returned gradients may a consumer overwrite in place?  Not one that is handed to several
+                # inputs, passed through, or that SHARES MEMORY with another returned gradient or with the incoming one
+                # (distinct Var wrappers over one storage, row slices at an offset: judged by storage + byte range).
+                returned = [pg for pg in input_grads if pg is not None]
+                handed_out = [id(pg) for pg in returned]
+                spans = [_span(pg.data) for pg in returned]
+                incoming = _span(g.data)
+                for index, pg in enumerate(returned):
+                    aliased = handed_out.count(id(pg)) > 1 or pg is g or \
+                        (id(g) in shared and _overlap(spans[index], incoming)) or \
+                        any(other != index and returned[other] is not pg and _overlap(spans[index], spans[other])
+                            for other in range(len(returned)))
+                    if aliased:
                         shared.add(id(pg))
                 for parent, need, pg in zip(node.inputs, needs, input_grads):
                     if not need or pg is None:
@@ -272,6 +282,16 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
     if inputs is not None:
         return [results.get(id(v)) for v in inputs]
     return None
+
+
+def _span(tensor):
+    """(storage address, first byte, one past the last byte) of a contiguous tensor's memory."""
+    first = tensor.data_ptr()
+    return tensor.untyped_storage().data_ptr(), first, first + tensor.numel() * tensor.element_size()
+
+
+def _overlap(a, b):
+    return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
 
 
 def _released(*_):

@@ -240,3 +240,15 @@ def test_a_world_of_one_runs_the_exchanges_only_when_forced():
     assert worker.exitcode == 0
     assert (plain_active, plain_parallel, forced_active, forced_parallel) == (False, False, True, True)
     assert launched == [(0, 100)] and unchanged and message == {'step': 3} and total == 2.5
+
+
+def test_gradients_that_share_memory_are_not_exclusive():
+    """a backward that returns distinct vars over ONE storage (row slices at an offset, two views) must not
+    let a consumer overwrite "its" gradient in place -- aliasing is judged by storage and byte range."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd.tape import _span, _overlap
+    whole = torch.zeros(8, 4)
+    first, second, tail = whole[:4], whole[4:], whole[2:6]
+    assert not _overlap(_span(first), _span(second))
+    assert _overlap(_span(first), _span(tail)) and _overlap(_span(tail), _span(second))
+    assert _overlap(_span(whole), _span(second)) and not _overlap(_span(whole), _span(torch.zeros(8, 4)))
