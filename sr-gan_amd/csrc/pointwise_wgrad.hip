@@ -8,15 +8,10 @@
 // v_mfma_f32_32x32x2_f32 (A[i][k]: lane = i + 32*k, B[k][j]: lane = j + 32*k) lane (i, half) simply owns 16 consecutive
 // pixels of row i -- half 0 the first 16 of a 32-pixel chunk, half 1 the last 16 -- as four 16-byte loads, and the
 // 16 MFMA steps of the chunk walk those registers (the order of a sum does not matter as long as A and B agree on
-// it).  Every 128-byte line is fetched by exactly one load instruction and used completely.  A workgroup owns a 128 x 128
-// block of gw over ONE range of pixel chunks; its four waves are the block's 2 x 2 quadrants of 64 x 64 (round 3: they used
-// to be four K-range workers of one 64 x 64 tile, summed through LDS).  The waves of a workgroup therefore read the same
-// pixels at the same time -- a gy row is wanted by the two waves of a block row, an x row by the two of a block column, and
-// the second request hits the CU's vector L1 -- so a workgroup pulls (128 + 128) rows per chunk from L2 for 2 x 128 x 128 x
-// 32 FLOP (32 FLOP/B instead of 16), and with 128 output channels (every bottleneck convolution) the gradient rows are no
-// longer read C_in / 64 times but C_in / 128 times.  The next chunk is in flight while the current one is in the matrix pipe
-// (explicit ping-pong register sets); a wave adds its quadrant to gw with fp32 atomics straight from the accumulator
-// fragment (lanes along the input channels: 128-byte runs).
+// it).  Every 128-byte line is fetched by exactly one load instruction and used completely.  Each WAVE is an
+// independent worker over its own range of pixel chunks for the workgroup's 64 x 64 output tile; the next chunk is
+// in flight while the current one is in the matrix pipe (explicit ping-pong register sets).  The four waves' tiles
+// are summed through LDS and leave as one coalesced fp32-atomic pass per workgroup.
 // The generic gather-GEMM staged both operands through LDS with a transpose and reached 55 TF/s on these shapes.
 #include "common.h"
 #include <stdlib.h>
@@ -30,29 +25,28 @@ struct PwWgradParams {
   const float* x; const float* gy; float* gw;
   int64_t x_bs, gy_bs;
   int32_t N, CI, CO, HW;
-  int32_t tiles_n;               // ci blocks (of 128 input channels)
+  int32_t tiles_n;               // ci tiles
   int32_t chunks, chunks_per_worker, chunks_per_image;
   int32_t mode;                  // 1 accumulate (single K-slice per tile), 2 atomic
   // x is relu(batch_norm_eval(x)) computed on the fly (per input channel) when bn_mean != NULL
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
 
-constexpr int PWG_MI = 2, PWG_NI = 2;      // 64 x 64 quadrant per wave
-constexpr int PWG_BLOCK = 128;             // 128 x 128 block of gw per workgroup (2 x 2 waves)
+constexpr int PWG_MI = 2, PWG_NI = 2;      // 64 x 64 output tile per workgroup
 
 // RAGGED: planes whose size is not a multiple of 32 pixels (28 x 28, 14 x 14, 7 x 7 at the reference's 224 x 224) or
 // whose rows are only 4-byte aligned.  An image is ceil(HW / 32) chunks; a float4 that would cross the end of the row
 // is loaded from the row's last four pixels instead (the SAME pixels for both operands), and the elements that repeat
 // an earlier float4 of the lane are switched off in the gy operand when it is used -- a zero times a finite value.
 template <bool PRO, bool RAGGED>
-__device__ __forceinline__ void pointwise_wgrad_body(const PwWgradParams& p, const int block_x, const int block_y) {
-  constexpr int MI = PWG_MI, NI = PWG_NI;
+__device__ __forceinline__ void pointwise_wgrad_body(const PwWgradParams& p, const int block_x, const int block_y, float* red) {
+  constexpr int MI = PWG_MI, NI = PWG_NI, ROWS = MI * 32, COLS = NI * 32, LDR = COLS + 1;
 
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int tm = block_x / p.tiles_n, tn = block_x - tm * p.tiles_n;
-  const int co0 = tm * PWG_BLOCK + (wave >> 1) * (MI * 32), ci0 = tn * PWG_BLOCK + (wave & 1) * (NI * 32);
-  if (co0 >= p.CO || ci0 >= p.CI) return;                 // a quadrant outside the matrix (wave-uniform; no barrier below)
-  const int cbeg = block_y * p.chunks_per_worker;
+  const int co0 = tm * ROWS, ci0 = tn * COLS;
+  const int worker = block_y * 4 + wave;
+  const int cbeg = worker * p.chunks_per_worker;
   const int cend = min(p.chunks, cbeg + p.chunks_per_worker);
 
   uint32_t a_row[MI], b_row[NI];            // element offset of this lane's 16-pixel run inside an image
@@ -144,29 +138,55 @@ __device__ __forceinline__ void pointwise_wgrad_body(const PwWgradParams& p, con
     }
   }
 
-  // ---- the quadrant leaves straight from the accumulator fragment.  C/D fragment: column = lane & 31 (input channel:
-  // consecutive lanes = consecutive floats of one gw row), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-  if (cbeg >= cend) return;
+  // ---- sum the four waves' tiles through LDS, then one coalesced pass out.  C/D fragment: column = lane & 31, row =
+  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Two LDS tiles: waves 2, 3 deposit, waves 0, 1 add them to their
+  // registers and deposit the pair sums, all 256 threads add the two tiles.
+  float* mine = red + (wave & 1) * (ROWS * LDR);
+  auto at = [&](int mi, int ni, int r) { return (mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDR + ni * 32 + l31; };
+  if (wave >= 2) {
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (co >= p.CO) continue;
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int ci = ci0 + ni * 32 + l31;
-        if (ci >= p.CI) continue;
-        float* dst = p.gw + (int64_t)co * p.CI + ci;
-        if (p.mode == 2) unsafeAtomicAdd(dst, acc[mi][ni][r]);
-        else *dst += acc[mi][ni][r];
-      }
+        for (int r = 0; r < 16; ++r) mine[at(mi, ni, r)] = acc[mi][ni][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += mine[at(mi, ni, r)];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[at(mi, ni, r)] = acc[mi][ni][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < ROWS * COLS / 256; ++e) {
+    const int idx = tid + 256 * e;
+    const int row = idx / COLS, col = idx - row * COLS;
+    const float v = red[row * LDR + col] + red[ROWS * LDR + row * LDR + col];
+    if (co0 + row < p.CO && ci0 + col < p.CI) {
+      float* dst = p.gw + (int64_t)(co0 + row) * p.CI + ci0 + col;
+      if (p.mode == 2) unsafeAtomicAdd(dst, v);
+      else *dst += v;
     }
+  }
 }
 
 template <bool PRO, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const PwWgradParams p) {
-  pointwise_wgrad_body<PRO, RAGGED>(p, (int)blockIdx.x, (int)blockIdx.y);
+  __shared__ float red[2 * PWG_MI * 32 * (PWG_NI * 32 + 1)];
+  pointwise_wgrad_body<PRO, RAGGED>(p, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
 // GROUPED: blockIdx.z selects one of many independent problems (all the bottleneck convolutions of a dense block's
@@ -195,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const P
                                                                          const float* x_base, const float* gy_base,
                                                                          float* gw_base, const int grid_x, const int grid_y,
                                                                          const int count) {
+  __shared__ float red[2 * PWG_MI * 32 * (PWG_NI * 32 + 1)];
   const int xcd = (int)blockIdx.x & 7, within_xcd = (int)blockIdx.x >> 3;
   const int round = within_xcd / grid_x, tile = within_xcd % grid_x;
   const int slice = round * 8 + ((xcd - round) & 7);        // (rotated per round: a problem's first slices visit every XCD)
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const P
   p.tiles_n = job.tiles_n; p.chunks = job.chunks; p.chunks_per_worker = job.chunks_per_worker;
   p.chunks_per_image = job.chunks_per_image; p.mode = job.mode;
   p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
-  pointwise_wgrad_body<PRO, RAGGED>(p, tile, y);
+  pointwise_wgrad_body<PRO, RAGGED>(p, tile, y, red);
 }
 
 int profile_bracket_begin(hipStream_t stream);
@@ -224,30 +245,29 @@ bool pointwise_wgrad_enabled() {
   return enabled;
 }
 
-// Grid plan of one problem: 128 x 128 blocks, the pixel chunks split into K ranges (one workgroup per block and range).
+// Grid plan of one problem: tiles, K split over wave workers, chunks per worker.
 // `group`: the number of problems launched together (their workgroups share the GPU, so each needs fewer of its own).
 static int pointwise_wgrad_plan(int32_t N, int32_t CI, int32_t CO, int32_t HW, PwWgradParams& p, int& tiles, int& split,
                                 int group = 1) {
-  const int tiles_m = (CO + PWG_BLOCK - 1) / PWG_BLOCK;
-  p.tiles_n = (CI + PWG_BLOCK - 1) / PWG_BLOCK;
+  const int tiles_m = (CO + PWG_MI * 32 - 1) / (PWG_MI * 32);
+  p.tiles_n = (CI + PWG_NI * 32 - 1) / (PWG_NI * 32);
   tiles = tiles_m * p.tiles_n;
   SRGAN_REQUIRE(HW >= 4, SRGAN_EUNSUPPORTED, "pointwise wgrad plane of fewer than 4 pixels");
   p.chunks_per_image = (HW + 31) / 32;
   const int64_t chunks = (int64_t)N * p.chunks_per_image;
   SRGAN_REQUIRE(chunks < ((int64_t)1 << 30) && tiles < (1 << 30), SRGAN_ERANGE, "pointwise wgrad grid");
   p.chunks = (int)chunks;
-  // Three resident workgroups per CU (166 registers per lane): 768 workgroups over the whole grid, but at least `min_chunks`
-  // chunks per K range so that a wave's atomic pass over its 64 x 64 quadrant is amortised.
+  // Three resident workgroups per CU (166 registers per lane): 768 workgroups = 3072 wave workers over the whole grid, but at least `min_chunks` chunks per worker so the LDS reduction + atomic pass is amortised.
   static const int resident = getenv("SRGAN_PWG_WGS") ? atoi(getenv("SRGAN_PWG_WGS")) : 768;
-  static const int min_chunks = getenv("SRGAN_PWG_DEPTH") ? atoi(getenv("SRGAN_PWG_DEPTH")) : 4;
+  static const int min_chunks = getenv("SRGAN_PWG_DEPTH") ? atoi(getenv("SRGAN_PWG_DEPTH")) : 2;   // (8 measured equal at 512 x 512, 2.5 % slower at 224 x 224)
   static const int oversubscription = getenv("SRGAN_GROUP_OVERSUB") ? atoi(getenv("SRGAN_GROUP_OVERSUB")) : 4;
   const int wanted = group > 1 ? (resident * oversubscription + group - 1) / group : resident;
   split = (wanted + tiles - 1) / tiles;
-  const int max_split = (int)((chunks + min_chunks - 1) / min_chunks);
+  const int max_split = (int)((chunks + 4 * min_chunks - 1) / (4 * min_chunks));
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
-  p.chunks_per_worker = (int)((chunks + split - 1) / split);
-  split = (int)((chunks + (int64_t)p.chunks_per_worker - 1) / (int64_t)p.chunks_per_worker);
+  p.chunks_per_worker = (int)((chunks + 4 * split - 1) / (4 * split));
+  split = (int)((chunks + 4 * (int64_t)p.chunks_per_worker - 1) / (4 * (int64_t)p.chunks_per_worker));
   SRGAN_REQUIRE(split <= 65535, SRGAN_ERANGE, "pointwise wgrad split");
   p.mode = split > 1 ? 2 : 1;
   return SRGAN_OK;
@@ -277,7 +297,7 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
   else if (bn) hipLaunchKernelGGL((pointwise_wgrad_kernel<true, false>), grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((pointwise_wgrad_kernel<false, false>), grid, dim3(256), 0, stream, p);
   const int status = launch_status();
-  profile_bracket_end(profile_slot, stream, CO, CI, (int64_t)N * HW, 6, PWG_BLOCK, PWG_BLOCK, split);
+  profile_bracket_end(profile_slot, stream, CO, CI, (int64_t)N * HW, 6, PWG_MI * 32, PWG_NI * 32, split);
   return status;
 }
 
@@ -326,7 +346,7 @@ int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, i
 #undef SRGAN_PWG_LAUNCH
   const int status = launch_status();
   // logical shape of the group: M x (sum of the input widths) x pixels, i.e. flops_mn = sum CO * CI
-  profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 6, PWG_BLOCK, PWG_BLOCK, grid_y, 0, 0,
+  profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 6, PWG_MI * 32, PWG_NI * 32, grid_y, 0, 0,
                       elements > pixels ? elements - pixels : 0);
   return status;
 }
