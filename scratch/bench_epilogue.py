@@ -11,7 +11,7 @@ shapes = [(16, 160, 128, 128), (16, 320, 64, 64), (16, 512, 64, 64), (16, 512, 3
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
 lib = _lib.library()
-stream = torch.cuda.current_stream().cuda_stream
+stream = _lib.stream_handle()          # (registers the split-K / partial-sum workspace for the stream)
 k = 128
 for (n, c, h, w) in shapes:
     total = c + 32
