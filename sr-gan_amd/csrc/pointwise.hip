@@ -221,28 +221,6 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     // complete inside one half-wave -- no second combine.  Loads first, stores last (the compiler cannot prove that
     // the stores do not alias x or the accumulated gradient, so a load issued after a store would wait for it).
     static_assert(!EPI || MI <= 2, "the staged output tile of the epilogue fits the LDS up to 64 rows");
-    // This lane's float4 column of the output tile (a half-wave owns one output row): the rows of x and of the accumulated
-    // gradient do not depend on the accumulators, so their loads go out FIRST and fly while the accumulator tile is
-    // transposed through LDS (two barriers); the registers of the operand ping-pong sets are free by now.
-    constexpr int RPT = BM / 8;                    // rows per thread: row = (tid >> 5) + 8 * e
-    const int half = tid >> 5, q4 = (tid & 31) * 4;
-    const int64_t my_group = (int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5);               // this lane's 32-pixel group
-    const int my_n = my_group < total ? (int)(my_group / p.gpi) : 0;
-    const int my_start = my_group < total ? (int)(my_group - (int64_t)my_n * p.gpi) * 32 + (q4 & 31) : 0;
-    const bool my_live = my_group < total && my_start < p.HW;        // (HW % 4 == 0: a float4 is inside or outside)
-    const int my_pix = my_live ? my_start : 0;
-    const int my_count = RAGROW ? (my_live ? min(4, p.HW - my_start) : 0) : 4;     // RAGROW: pixels of the float4 that exist
-    const float* x_lane = p.epi_x + (int64_t)my_n * p.epi_x_bs + my_pix;
-    float* out_lane = p.out + (int64_t)my_n * p.out_bs + my_pix;
-    float4 early_x[RAGROW ? 1 : RPT], early_old[RAGROW ? 1 : RPT];
-    if constexpr (!RAGROW) {
-#pragma unroll
-      for (int e = 0; e < RPT; ++e) {
-        const int o = min(m0 + half + 8 * e, p.CO - 1);
-        early_x[e] = *reinterpret_cast<const float4*>(x_lane + (int64_t)o * p.HW);
-        if (p.mode != 0) early_old[e] = *reinterpret_cast<const float4*>(out_lane + (int64_t)o * p.HW);
-      }
-    }
     __syncthreads();                               // every wave is done with the weight tiles: the LDS is reused
     float* tile = lds;                             // [BM][LDT]
     float* table = lds + BM * LDT;                 // [BM][4]: a, b, mean of output row m0 + i
@@ -259,6 +237,14 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
       table[tid * 4 + 0] = a; table[tid * 4 + 1] = b; table[tid * 4 + 2] = mu;
     }
     __syncthreads();
+    constexpr int RPT = BM / 8;                    // rows per thread: row = (tid >> 5) + 8 * e
+    const int half = tid >> 5, q4 = (tid & 31) * 4;
+    const int64_t my_group = (int64_t)(bid / p.tiles_m) * 4 + (q4 >> 5);               // this lane's 32-pixel group
+    const int my_n = my_group < total ? (int)(my_group / p.gpi) : 0;
+    const int my_start = my_group < total ? (int)(my_group - (int64_t)my_n * p.gpi) * 32 + (q4 & 31) : 0;
+    const bool my_live = my_group < total && my_start < p.HW;        // (HW % 4 == 0: a float4 is inside or outside)
+    const int my_pix = my_live ? my_start : 0;
+    const int my_count = RAGROW ? (my_live ? min(4, p.HW - my_start) : 0) : 4;     // RAGROW: pixels of the float4 that exist
     auto load4 = [&](const float* src) {
       if constexpr (!RAGROW) return *reinterpret_cast<const float4*>(src);
       float4 v;
@@ -266,19 +252,16 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
       v.z = my_count > 2 ? src[2] : 0.f; v.w = my_count > 3 ? src[3] : 0.f;
       return v;
     };
+    const float* x_lane = p.epi_x + (int64_t)my_n * p.epi_x_bs + my_pix;
+    float* out_lane = p.out + (int64_t)my_n * p.out_bs + my_pix;
     const bool sums_wanted = p.epi_partial != nullptr;
     auto emit = [&](auto accumulate) {
       float4 xs[RPT], olds[RPT];
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
         const int o = min(m0 + half + 8 * e, p.CO - 1);
-        if constexpr (!RAGROW) {
-          xs[e] = early_x[e];
-          if constexpr (decltype(accumulate)::value) olds[e] = early_old[e];
-        } else {
-          xs[e] = load4(x_lane + (int64_t)o * p.HW);
-          if constexpr (decltype(accumulate)::value) olds[e] = load4(out_lane + (int64_t)o * p.HW);
-        }
+        xs[e] = load4(x_lane + (int64_t)o * p.HW);
+        if constexpr (decltype(accumulate)::value) olds[e] = load4(out_lane + (int64_t)o * p.HW);
       }
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
