@@ -101,6 +101,12 @@ class _Transition(nn.Sequential):
         self.add_module('pool', nn.AvgPool2d(kernel_size=2, stride=2))
 
     def forward(self, x):
+        if fused.POOL_FIRST:
+            # avg_pool2d and a 1x1 convolution commute -- both are linear and the convolution acts per pixel -- so the
+            # reference's conv -> pool (crowd/models.py:369-371) is evaluated as pool -> conv: the convolution, its data
+            # and weight gradients and their double-backward forms run on a QUARTER of the pixels (the transitions are
+            # 12 % of the network's convolution FLOPs).  Same function, fp32 summation order aside (~1e-7 relative).
+            return self.conv(self.pool(self.norm(x, relu=True)))
         y = fused.bn_relu_conv(x, self.norm, self.conv) if fused.ENABLED else None
         if y is None:
             y = self.conv(self.norm(x, relu=True))

@@ -38,6 +38,7 @@ from .nn import parameter_var
 
 
 ENABLED = True      # tests flip this to compare the fused block with the primitive path
+POOL_FIRST = os.environ.get('SRGAN_POOL_FIRST', '0') == '1'   # DenseNet transitions as norm -> relu -> pool -> conv (crowd/models.py)
 PROLOGUE = True     # batch-norm + ReLU evaluated inside the convolution kernels (tests flip this too)
 EPILOGUE = True     # batch-norm + ReLU backward evaluated in the epilogue of the data-gradient kernels
 # The weight-gradient kernels of a block's backward only feed the optimizer, so they can run on a second stream next to
