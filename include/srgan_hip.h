@@ -278,6 +278,17 @@ int srgan_bn_relu_maxpool_bwd(const float* gy, const int32_t* argmax, const floa
                               const float* gamma, const float* beta, float* gx, float* g_gamma, float* g_beta, int32_t N,
                               int32_t C, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p, int32_t OH, int32_t OW,
                               void* stream);
+/* avg_pool2d(relu(batch_norm_eval(x)), 2, 2) as ONE pass each way, for the DenseNet transitions evaluated as norm -> relu ->
+ * pool -> conv (reference crowd/models.py:364-371 has conv -> pool; the 1x1 convolution and the average pooling commute, so
+ * the convolution and its gradients run on a quarter of the pixels).  Forward: y[N, C, H/2, W/2]; backward: gx = 0.25 *
+ * gy[h/2, w/2] * [bn(x) > 0] * inv_std * gamma, g_gamma / g_beta (both or neither) ADDED to.  Even H, W % 4 == 0
+ * (`_supported`). */
+int srgan_bn_relu_avgpool2_supported(int32_t N, int32_t C, int32_t H, int32_t W);
+int srgan_bn_relu_avgpool2_fwd(const float* x, const float* mean, const float* inv_std, const float* gamma, const float* beta,
+                               float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int srgan_bn_relu_avgpool2_bwd(const float* gy, const float* x, const float* mean, const float* inv_std, const float* gamma,
+                               const float* beta, float* gx, float* g_gamma, float* g_beta, int32_t N, int32_t C, int32_t H,
+                               int32_t W, void* stream);
 int srgan_maxpool2d_fwd(const float* x, float* y, int32_t* argmax, int32_t planes, int32_t H, int32_t W, int32_t k,
                         int32_t s, int32_t p, int32_t OH, int32_t OW, void* stream);
 int srgan_maxpool2d_bwd(const float* g, const int32_t* argmax, float* gx, int32_t planes, int32_t H, int32_t W, int32_t k,

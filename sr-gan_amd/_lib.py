@@ -75,6 +75,9 @@ SIGNATURES = {
     'srgan_bn_relu_maxpool_bwd_supported': ([i32, i32, i32, i32, i32, i32, i32], ctypes.c_int),
     'srgan_bn_relu_maxpool_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
                                   ctypes.c_int),
+    'srgan_bn_relu_avgpool2_supported': ([i32, i32, i32, i32], ctypes.c_int),
+    'srgan_bn_relu_avgpool2_fwd': ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp], ctypes.c_int),
+    'srgan_bn_relu_avgpool2_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp], ctypes.c_int),
     'srgan_maxpool2d_fwd': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], ctypes.c_int),
     'srgan_maxpool2d_bwd': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], ctypes.c_int),
     'srgan_pool_scatter': ([vp, vp, vp, i32, i64, i64, vp], ctypes.c_int),

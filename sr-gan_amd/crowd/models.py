@@ -106,7 +106,13 @@ class _Transition(nn.Sequential):
             # reference's conv -> pool (crowd/models.py:369-371) is evaluated as pool -> conv: the convolution, its data
             # and weight gradients and their double-backward forms run on a QUARTER of the pixels (the transitions are
             # 12 % of the network's convolution FLOPs).  Same function, fp32 summation order aside (~1e-7 relative).
-            return self.conv(self.pool(self.norm(x, relu=True)))
+            pooled = None
+            if fused.ENABLED and self.pool.kernel_size == 2 and self.pool.stride == 2:
+                inv_std, mean = self.norm._inverse_std()
+                pooled = F.bn_relu_avg_pool2d(x, mean, inv_std, nn.P(self.norm.weight), nn.P(self.norm.bias))
+            if pooled is None:
+                pooled = self.pool(self.norm(x, relu=True))
+            return self.conv(pooled)
         y = fused.bn_relu_conv(x, self.norm, self.conv) if fused.ENABLED else None
         if y is None:
             y = self.conv(self.norm(x, relu=True))

@@ -211,6 +211,82 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
   }
 }
 
+// ---- avg_pool2d(relu(batch_norm_eval(x)), 2, 2) as one pass each way: the DenseNet transitions evaluated as
+// norm -> relu -> pool -> conv (reference crowd/models.py:364-371 has conv -> pool; a 1x1 convolution and the average
+// pooling commute).  A thread owns two vertically adjacent float4 of x (rows 2 oh, 2 oh + 1; W % 4 == 0) = two pooled pixels.
+// Forward: the activated tensor -- four times the pooled one -- is never written.  Backward: gx = 0.25 * g[oh, ow] * mask * a
+// and the two parameter sums (beta: sum of the masked 0.25 g; gamma: inv_std * sum of masked 0.25 g * (x - mean)), one
+// workgroup = POOL_BWD_QUADS thread items of ONE plane (blockIdx.y), reduced per workgroup and added atomically.
+__global__ __launch_bounds__(256) void bn_relu_avgpool2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ inv_std,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ y,
+                                                                   int C, int H, int W) {
+  const uint32_t plane = blockIdx.y, w4 = (uint32_t)W >> 2, items = ((uint32_t)H >> 1) * w4;
+  const int c = (int)(plane % (uint32_t)C);
+  float a, b;
+  bn_coefficients(mean[c], inv_std[c], gamma[c], beta[c], a, b);
+  const float* src = x + (int64_t)plane * H * W;
+  float* dst = y + (int64_t)plane * (H >> 1) * (W >> 1);
+  const uint32_t first = blockIdx.x * POOL_BWD_QUADS;
+  for (uint32_t q = first + threadIdx.x; q < min(first + POOL_BWD_QUADS, items); q += 256u) {
+    const uint32_t oh = q / w4, wq = q - oh * w4;
+    const float4 top = *reinterpret_cast<const float4*>(src + (int64_t)(2 * oh) * W + 4 * wq);
+    const float4 low = *reinterpret_cast<const float4*>(src + (int64_t)(2 * oh + 1) * W + 4 * wq);
+    auto act = [&](float v) { return fmaxf(fmaf(v, a, b), 0.f); };
+    // (the order avgpool_fwd_kernel adds a window in: row by row)
+    const float left = (((act(top.x) + act(top.y)) + act(low.x)) + act(low.y)) * 0.25f;
+    const float right = (((act(top.z) + act(top.w)) + act(low.z)) + act(low.w)) * 0.25f;
+    *reinterpret_cast<float2*>(dst + (int64_t)oh * (W >> 1) + 2 * wq) = make_float2(left, right);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_avgpool2_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ inv_std,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ gx,
+                                                                   float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                                   int C, int H, int W) {
+  __shared__ float scratch[2][4];
+  const uint32_t plane = blockIdx.y, w4 = (uint32_t)W >> 2, items = ((uint32_t)H >> 1) * w4;
+  const int c = (int)(plane % (uint32_t)C);
+  float a, b;
+  const float mu = mean[c];
+  bn_coefficients(mu, inv_std[c], gamma[c], beta[c], a, b);
+  const float* src = g + (int64_t)plane * (H >> 1) * (W >> 1);
+  float sum_plain = 0.f, sum_centred = 0.f;
+  const uint32_t first = blockIdx.x * POOL_BWD_QUADS;
+  for (uint32_t q = first + threadIdx.x; q < min(first + POOL_BWD_QUADS, items); q += 256u) {
+    const uint32_t oh = q / w4, wq = q - oh * w4;
+    const float2 pooled = *reinterpret_cast<const float2*>(src + (int64_t)oh * (W >> 1) + 2 * wq);
+    const float gl = pooled.x * 0.25f, gr = pooled.y * 0.25f;
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+      const int64_t at = ((int64_t)plane * H + 2 * oh + row) * W + 4 * wq;
+      const float4 xv = *reinterpret_cast<const float4*>(x + at);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      float v[4] = {gl, gl, gr, gr};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = fmaf(xs[j], a, b) > 0.f ? v[j] : 0.f;
+        sum_plain += v[j];
+        sum_centred = fmaf(v[j], xs[j] - mu, sum_centred);
+      }
+      *reinterpret_cast<float4*>(gx + at) = make_float4(v[0] * a, v[1] * a, v[2] * a, v[3] * a);
+    }
+  }
+  if (g_gamma == nullptr) return;
+  const float plain = wave_sum(sum_plain), centred = wave_sum(sum_centred);
+  const int wave = (int)threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { scratch[0][wave] = plain; scratch[1][wave] = centred; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(g_beta + c, (scratch[0][0] + scratch[0][1]) + (scratch[0][2] + scratch[0][3]));
+    unsafeAtomicAdd(g_gamma + c, ((scratch[1][0] + scratch[1][1]) + (scratch[1][2] + scratch[1][3])) * inv_std[c]);
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                           float* __restrict__ out, int64_t in_plane, int64_t out_plane,
                                                           int64_t n) {
@@ -314,6 +390,38 @@ int srgan_bn_relu_maxpool_bwd(const float* gy, const int32_t* argmax, const floa
   dim3 grid((plane_quads + POOL_BWD_QUADS - 1) / POOL_BWD_QUADS, (unsigned)(N * C), 1);
   hipLaunchKernelGGL((bn_relu_maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, gy, argmax, x, mean, inv_std,
                      gamma, beta, gx, g_gamma, g_beta, C, H, W, OH, OW);
+  return launch_status();
+}
+
+// 1 when srgan_bn_relu_avgpool2_fwd / _bwd have this geometry (2 x 2 windows on even planes of whole float4 rows)
+int srgan_bn_relu_avgpool2_supported(int32_t N, int32_t C, int32_t H, int32_t W) {
+  return (N > 0 && C > 0 && H >= 2 && W >= 4 && H % 2 == 0 && W % 4 == 0 && (int64_t)N * C <= 65535 &&
+          (int64_t)N * C * H * W < ((int64_t)1 << 31)) ? 1 : 0;
+}
+
+int srgan_bn_relu_avgpool2_fwd(const float* x, const float* mean, const float* inv_std, const float* gamma, const float* beta,
+                               float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+  SRGAN_REQUIRE(x && mean && inv_std && gamma && beta && y, SRGAN_EINVAL, "srgan_bn_relu_avgpool2_fwd arguments");
+  SRGAN_REQUIRE(srgan_bn_relu_avgpool2_supported(N, C, H, W) && ((((uintptr_t)x) & 15) | (((uintptr_t)y) & 7)) == 0,
+                SRGAN_EUNSUPPORTED, "srgan_bn_relu_avgpool2_fwd geometry");
+  const uint32_t items = ((uint32_t)H >> 1) * ((uint32_t)W >> 2);
+  dim3 grid((items + POOL_BWD_QUADS - 1) / POOL_BWD_QUADS, (unsigned)(N * C), 1);
+  hipLaunchKernelGGL(bn_relu_avgpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, mean, inv_std, gamma, beta, y, C, H, W);
+  return launch_status();
+}
+
+int srgan_bn_relu_avgpool2_bwd(const float* gy, const float* x, const float* mean, const float* inv_std, const float* gamma,
+                               const float* beta, float* gx, float* g_gamma, float* g_beta, int32_t N, int32_t C, int32_t H,
+                               int32_t W, void* stream) {
+  SRGAN_REQUIRE(gy && x && mean && inv_std && gamma && beta && gx, SRGAN_EINVAL, "srgan_bn_relu_avgpool2_bwd arguments");
+  SRGAN_REQUIRE((g_gamma == nullptr) == (g_beta == nullptr), SRGAN_EINVAL, "srgan_bn_relu_avgpool2_bwd parameter outputs");
+  SRGAN_REQUIRE(srgan_bn_relu_avgpool2_supported(N, C, H, W) &&
+                ((((uintptr_t)x | (uintptr_t)gx) & 15) | (((uintptr_t)gy) & 7)) == 0, SRGAN_EUNSUPPORTED,
+                "srgan_bn_relu_avgpool2_bwd geometry");
+  const uint32_t items = ((uint32_t)H >> 1) * ((uint32_t)W >> 2);
+  dim3 grid((items + POOL_BWD_QUADS - 1) / POOL_BWD_QUADS, (unsigned)(N * C), 1);
+  hipLaunchKernelGGL(bn_relu_avgpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, x, mean, inv_std, gamma, beta, gx,
+                     g_gamma, g_beta, C, H, W);
   return launch_status();
 }
 

@@ -714,6 +714,44 @@ def bn_relu_max_pool2d(x, mean, inv_std, gamma, beta, kernel_size, stride, paddi
     return out
 
 
+def bn_relu_avg_pool2d(x, mean, inv_std, gamma, beta):
+    """``avg_pool2d(relu(batch_norm_eval(x)), 2, 2)`` as ONE pass each way (the DenseNet transitions evaluated as norm -> relu
+    -> pool -> conv, see ``crowd.models._Transition``): the activated tensor -- four times the pooled one -- is never
+    written; first-order backward in one pass too (`srgan_bn_relu_avgpool2_bwd`).  A RECORDED backward (gradient penalty)
+    re-evaluates the two-op form and differentiates that.  Returns None when the kernels do not have the geometry."""
+    n, c, h, w = x.shape
+    if not _lib.library().srgan_bn_relu_avgpool2_supported(n, c, h, w) or (x.data.data_ptr() & 15):
+        return None
+    data = _empty((n, c, h // 2, w // 2), x.data)
+    _call('srgan_bn_relu_avgpool2_fwd', _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma), _ptr(beta), data.data_ptr(),
+          n, c, h, w, _stream())
+    out = _out(data, (x, gamma, beta), None, 'bn_relu_avg_pool2d')
+    if out.node is None:
+        return out
+
+    def backward(g, needs):
+        if grad_enabled():
+            from .tape import backward as sweep
+            pooled = avg_pool2d(batch_norm_eval(x, mean, inv_std, gamma, beta, relu=True), 2, 2)
+            wanted = [v for v, need in zip((x, gamma, beta), needs) if need]
+            grads = iter(sweep(pooled, grad=g, inputs=wanted, create_graph=True))
+            return tuple(next(grads) if need else None for need in needs)
+        want_params = needs[1] or needs[2]
+        direct = needs[1] and needs[2] and accumulates_into(gamma) and accumulates_into(beta)
+        both = _zeros((2, c), x.data) if want_params and not direct else None
+        into_gamma = gamma.grad_buffer.data_ptr() if direct else (both[0].data_ptr() if want_params else None)
+        into_beta = beta.grad_buffer.data_ptr() if direct else (both[1].data_ptr() if want_params else None)
+        gx_data = _empty(x.shape, x.data)
+        upstream = g.data if g.data.is_contiguous() else g.data.contiguous()
+        _call('srgan_bn_relu_avgpool2_bwd', upstream.data_ptr(), _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(gamma), _ptr(beta),
+              gx_data.data_ptr(), into_gamma, into_beta, n, c, h, w, _stream())
+        ggamma = Var(both[0]) if want_params and not direct else None
+        gbeta = Var(both[1]) if want_params and not direct else None
+        return (Var(gx_data) if needs[0] else None), ggamma, gbeta
+    out.node.backward = backward
+    return out
+
+
 def _max_pool2d_backward(g, argmax, in_shape, geometry):
     """Gather form (every input element written once: no zero-fill, no atomics); its own backward is the gather of
     the incoming tensor at the forward's arg-max, as for the scatter form."""

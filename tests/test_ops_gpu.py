@@ -850,3 +850,88 @@ def test_fused_stem_norm_relu_pool(F, shape):
     for i, what in enumerate(('output', 'input gradient', 'gamma gradient', 'beta gradient', 'recorded input gradient',
                               'penalty gamma gradient')):
         close(results[True][i], results[False][i], 1e-5, 'fused stem pool: ' + what)
+
+
+@gpu
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16), (3, 5, 10, 12), (2, 64, 56, 56), (2, 6, 6, 14)])
+def test_fused_transition_norm_relu_avg_pool(F, shape):
+    """functional.bn_relu_avg_pool2d (the transitions' norm -> relu -> pool in one pass each way, pooling BEFORE the 1x1
+    convolution) against the two-op form: output, first-order gradients of x / gamma / beta, and the recorded
+    (gradient-penalty) route through it.  (2, 6, 6, 14): a width the fused kernels do not have -> None."""
+    from srgan_amd.tape import backward
+    gen = torch.Generator().manual_seed(43)
+    n, c, h, w = shape
+    x_host = torch.randn(n, c, h, w, generator=gen)
+    stats = dict(mean=torch.randn(c, generator=gen) * 0.3, inv=(torch.rand(c, generator=gen) + 0.5).rsqrt(),
+                 gamma=torch.rand(c, generator=gen) + 0.5, beta=torch.randn(c, generator=gen) * 0.3)
+    cotangent = torch.randn(n, c, h // 2, w // 2, generator=gen)
+    if w % 4:
+        x = F.leaf(dev(x_host))
+        assert F.bn_relu_avg_pool2d(x, F.constant(dev(stats['mean'])), F.constant(dev(stats['inv'])),
+                                    F.leaf(dev(stats['gamma'])), F.leaf(dev(stats['beta']))) is None
+        return
+    results = {}
+    for fused_form in (False, True):
+        x = F.leaf(dev(x_host), requires_grad=True)
+        gamma, beta = F.leaf(dev(stats['gamma']), requires_grad=True), F.leaf(dev(stats['beta']), requires_grad=True)
+        mean, inv = F.constant(dev(stats['mean'])), F.constant(dev(stats['inv']))
+
+        def forward(x):
+            if fused_form:
+                y = F.bn_relu_avg_pool2d(x, mean, inv, gamma, beta)
+                assert y is not None
+                return y
+            return F.avg_pool2d(F.batch_norm_eval(x, mean, inv, gamma, beta, relu=True), 2, 2)
+        y = forward(x)
+        backward(y, grad=F.leaf(dev(cotangent)))
+        first = (y.cpu(), x.grad.cpu(), gamma.grad.cpu(), beta.grad.cpu())
+        x2 = F.leaf(dev(x_host), requires_grad=True)
+        gamma.grad = beta.grad = None
+        scalar = F.sum_all(F.mul(forward(x2), F.leaf(dev(cotangent))))
+        (gx,) = backward(scalar, inputs=[x2], create_graph=True)
+        penalty = F.mean_all(F.square(F.add_scalar(F.row_norm(F.flatten2d(gx)), -1.0)))
+        backward(penalty)
+        results[fused_form] = first + (gx.cpu(), gamma.grad.cpu())
+    for i, what in enumerate(('output', 'input gradient', 'gamma gradient', 'beta gradient', 'recorded input gradient',
+                              'penalty gamma gradient')):
+        close(results[True][i], results[False][i], 1e-5, 'fused transition pool: ' + what)
+
+
+@gpu
+def test_transition_with_the_pooling_first_equals_the_reference_order(F):
+    """crowd.models._Transition: norm -> relu -> pool -> conv (fused.POOL_FIRST) against the reference's norm -> relu -> conv
+    -> pool (crowd/models.py:364-371) -- output, input gradient, all parameter gradients, and the recorded route."""
+    from srgan_amd import fused, nn
+    from srgan_amd.crowd.models import _Transition
+    from srgan_amd.tape import backward
+    gen = torch.Generator().manual_seed(44)
+    torch.manual_seed(44)
+    module = _Transition(24, 12)
+    with torch.no_grad():
+        module.norm.running_mean.copy_(torch.randn(24, generator=gen) * 0.3)
+        module.norm.running_var.copy_(torch.rand(24, generator=gen) + 0.5)
+        module.norm.weight.copy_(torch.rand(24, generator=gen) + 0.5)
+        module.norm.bias.copy_(torch.randn(24, generator=gen) * 0.3)
+    nn.flatten_parameters(module, torch.device('cuda'))
+    x_host = torch.randn(3, 24, 16, 24, generator=gen)
+    cotangent = torch.randn(3, 12, 8, 12, generator=gen)
+    saved, results = fused.POOL_FIRST, {}
+    try:
+        for pool_first in (False, True):
+            fused.POOL_FIRST = pool_first
+            module._srgan_arena.zero_grad()
+            x = F.leaf(dev(x_host), requires_grad=True)
+            y = module(x)
+            backward(y, grad=F.leaf(dev(cotangent)))
+            first = (y.cpu(), x.grad.cpu(), module._srgan_arena.grad.detach().cpu().clone())
+            module._srgan_arena.zero_grad()
+            x2 = F.leaf(dev(x_host), requires_grad=True)
+            scalar = F.sum_all(F.mul(module(x2), F.leaf(dev(cotangent))))
+            (gx,) = backward(scalar, inputs=[x2], create_graph=True)
+            backward(F.mean_all(F.square(F.add_scalar(F.row_norm(F.flatten2d(gx)), -1.0))))
+            results[pool_first] = first + (gx.cpu(), module._srgan_arena.grad.detach().cpu().clone())
+    finally:
+        fused.POOL_FIRST = saved
+    for i, what in enumerate(('output', 'input gradient', 'parameter gradients', 'recorded input gradient',
+                              'penalty parameter gradients')):
+        close(results[True][i], results[False][i], 2e-5, 'pooling first: ' + what)
