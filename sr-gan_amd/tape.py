@@ -226,7 +226,10 @@ def backward(root, grad=None, inputs=None, create_graph=False, retain_graph=None
                     run_sweep_end_hooks()     # side-stream launches write the arena too: joined before a tail is declared final
                     grad_ready.ready_from(frontier[position])
                 g = grads.pop(id(var), None)
-                if g is None:
+                if g is None or id(var) in wanted:
+                    # (a requested input is the END of the differentiated sub-graph even when it has a producer: running that
+                    # producer's backward -- with no input wanting a gradient -- would be a whole wasted pass, e.g. a dense
+                    # block's data-gradient chain behind a fused op that re-evaluates itself for a recorded backward)
                     continue
                 node = var.node
                 needs = tuple(required and (relevant is None or id(p) in relevant)
