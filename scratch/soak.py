@@ -12,6 +12,8 @@ for i in range(40):
     if i % 10 == 9:
         torch.cuda.synchronize()
         losses = {k: float(v.item()) for k, v in exp.last_losses.items() if v is not None}
-        marks.append((i + 1, torch.cuda.memory_allocated() / 2**30, torch.cuda.max_memory_allocated() / 2**30, losses))
-for step, allocated, peak, losses in marks:
-    print(f'step {step}: allocated {allocated:.2f} GiB, peak {peak:.2f} GiB, ' + ', '.join(f'{k} {v:.4g}' for k, v in losses.items()))
+        marks.append((i + 1, torch.cuda.memory_allocated() / 2**30, torch.cuda.max_memory_allocated() / 2**30,
+                      torch.cuda.memory_reserved() / 2**30, losses))
+for step, allocated, peak, reserved, losses in marks:
+    print(f'step {step}: allocated {allocated:.2f} GiB, peak {peak:.2f} GiB, reserved by the caching allocator {reserved:.2f} GiB, '
+          + ', '.join(f'{k} {v:.4g}' for k, v in losses.items()))
