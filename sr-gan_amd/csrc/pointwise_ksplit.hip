@@ -30,7 +30,7 @@ struct PwKsplitParams {
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;   // PRO
 };
 
-constexpr int PKS_MI = 2;                 // 64 output rows per workgroup
+constexpr int PKS_MI = 1;                 // 32 output rows per workgroup
 constexpr int PKS_MAX_K = 2048;           // PRO: (a, b) of every input channel live in LDS
 
 template <bool PRO>
