@@ -26,10 +26,6 @@ namespace srgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef SRGAN_PW_LOADS_FIRST
-#define SRGAN_PW_LOADS_FIRST 1      // tuning switch (compile time): the next slice's activation loads at the top of a slice
-#endif
-
 struct PointwiseParams {
   const float* in;      // [N, CI, HW], batch stride in_bs
   const float* w;       // element (o, i) at w[o * w_so + i * w_si]
@@ -173,20 +169,6 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     // (A laboratory copy of this loop measured 97 vs 91 TF/s for "all first" vs "one per k-pair", and the
     // sched_group_barrier pinning of the interleave measured slower than the compiler's own schedule.)
     fetch_a(k0 + BK);
-    // ... and so do the next slice's ACTIVATION loads (clamped, so that the slice stays one basic block; the last slice's
-    // are unused): issued here they have this slice's whole matrix work -- 16 * MI * NI MFMAs -- to land.  The scheduling
-    // barrier keeps them here: left alone, the machine scheduler sinks all of them BEHIND the slice's MFMAs (it did: the
-    // next slice then opened with s_waitcnt vmcnt(15) on loads issued a few hundred cycles earlier, i.e. every slice began
-    // with an exposed L2 / HBM round trip that only the other resident workgroups could cover).
-    if (SRGAN_PW_LOADS_FIRST) {
-#pragma unroll
-      for (int q = 0; q < KP; ++q) {
-        const int k = min(k0 + BK + 2 * q, kend - 2);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bnxt[ni][q] = (b_wave + (int64_t)k * p.HW)[lane_off + 32 * ni];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
     float a[2][MI];
     float2 cf[2];
     const float2* cs = &coef[PRO ? buffer : 0][PRO ? lhi : 0];
@@ -209,7 +191,7 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi], bq[ni], acc[mi][ni], 0, 0, 0);
-      if (!SRGAN_PW_LOADS_FIRST) {   // unconditional (clamped) so that the slice stays one basic block; the last slice's loads are unused
+      {   // unconditional (clamped) so that the slice stays one basic block; the last slice's loads are unused
         const int k = min(k0 + BK + 2 * q, kend - 2);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bnxt[ni][q] = (b_wave + (int64_t)k * p.HW)[lane_off + 32 * ni];
