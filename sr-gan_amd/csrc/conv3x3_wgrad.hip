@@ -273,10 +273,22 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const Wgrad3Params& p, const 
   }
 }
 
+// One-dimensional grid in XCD-aware order (hardware workgroup b runs on XCD b % 8): the walkers go round-robin to the XCDs and
+// ALL channel-chunk workgroups of a walker follow each other on its XCD -- they read the same pixel tiles (an x chunk is
+// wanted by every output-channel chunk, a gy chunk by every input-channel chunk: 16 + 16 distinct tiles for 256 workgroups at
+// 512 -> 512 channels), so each tile comes from HBM once and from that XCD's L2 afterwards.  With (walker, ci chunk, co chunk)
+// as a three-dimensional grid the chunks of a walker were spread over all eight L2s and over time: 28.1 GB of fabric traffic
+// for 4.8 GB of operands on the VGG-16 workload (5.9x, profiles/r03z_age_vgg64_bf16_pmc_per_kernel.md).
 template <int TH, int PREC = 0, bool RAGGED = false>
-__global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgrad3Params p) {
+__global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_kernel(const Wgrad3Params p, const int walkers,
+                                                                       const int ci_chunks, const int co_chunks) {
   __shared__ float smem[Wgrad3Lds<TH, PREC, RAGGED>::SMEM];
-  conv3x3_wgrad_body<TH, PREC, RAGGED>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+  const int chunks = ci_chunks * co_chunks;
+  const int xcd = (int)blockIdx.x & 7, within_xcd = (int)blockIdx.x >> 3;
+  const int walker = (within_xcd / chunks) * 8 + xcd, chunk = within_xcd % chunks;
+  if (walker >= walkers) return;                                       // (the last round's padding; workgroup-uniform)
+  const int co_chunk = chunk / ci_chunks;
+  conv3x3_wgrad_body<TH, PREC, RAGGED>(p, walker, walkers, chunk - co_chunk * ci_chunks, co_chunk, smem);
 }
 
 // GROUPED: blockIdx.z selects one of many independent problems (all the growth convolutions of a dense block's backward)
@@ -343,6 +355,10 @@ static int conv3x3_wgrad_walkers(int tiles, int ci_chunks, int co_chunks, int gr
   int walkers = wanted / (ci_chunks * co_chunks);
   if (walkers > (tiles + depth - 1) / depth) walkers = (tiles + depth - 1) / depth;
   if (group > 1 && walkers > 8) walkers -= walkers % 8;     // whole units of the grouped kernel's XCD-aware order
+  if (group == 1) {                                         // single problem: walkers go round-robin to the eight XCDs
+    walkers = (walkers + 7) / 8 * 8;
+    if (walkers > tiles) walkers = tiles;
+  }
   return walkers < 1 ? 1 : walkers;
 }
 
@@ -369,13 +385,18 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   p.tiles = (int)tiles;
   const int walkers = conv3x3_wgrad_walkers(p.tiles, ci_chunks, co_chunks);
   if (!accumulate) if (const int status = zero_floats(gw, (int64_t)CO * CI * 9, stream)) return status;
-  dim3 grid((unsigned)walkers, (unsigned)ci_chunks, (unsigned)co_chunks);
+  const int64_t blocks = (int64_t)((walkers + 7) / 8) * 8 * ci_chunks * co_chunks;
+  SRGAN_REQUIRE(blocks < ((int64_t)1 << 31), SRGAN_ERANGE, "conv3x3 wgrad grid");
+  dim3 grid((unsigned)blocks, 1, 1);
   const int profile_slot = profile_bracket_begin(stream);
-  if (precision == 1) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1>), grid, dim3(WG3_THREADS), 0, stream, p);
-  else if (precision == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2>), grid, dim3(WG3_THREADS), 0, stream, p);
-  else if (ragged) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 0, true>), grid, dim3(WG3_THREADS), 0, stream, p);
-  else if (th == 4) hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WG3_THREADS), 0, stream, p);
-  else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(WG3_THREADS), 0, stream, p);
+#define SRGAN_WG3_LAUNCH(...) hipLaunchKernelGGL((conv3x3_wgrad_kernel<__VA_ARGS__>), grid, dim3(WG3_THREADS), 0, stream, p, walkers, \
+                                                 ci_chunks, co_chunks)
+  if (precision == 1) SRGAN_WG3_LAUNCH(4, 1);
+  else if (precision == 2) SRGAN_WG3_LAUNCH(4, 2);
+  else if (ragged) SRGAN_WG3_LAUNCH(4, 0, true);
+  else if (th == 4) SRGAN_WG3_LAUNCH(4);
+  else SRGAN_WG3_LAUNCH(2);
+#undef SRGAN_WG3_LAUNCH
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers, 0, 0, 0, precision);
   return status;
