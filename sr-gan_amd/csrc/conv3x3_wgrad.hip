@@ -75,8 +75,18 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const Wgrad3Params& p, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const float* a_base = gs + l31 * GS + (PREC ? 8 * lhi : lhi);
-  const float* b_base = xs + l31 * PS + kh * PW + (PREC ? 8 * lhi : lhi);
+  const float* a_base = gs + l31 * GS + lhi;
+  const float* b_base = xs + l31 * PS + kh * PW + lhi;
+  // PREC: the tiles are OPERAND-TYPED in LDS (round 3).  x patch: [channel][patch row][24] (18 used; 48-byte rows, channel
+  // stride 6 x 48 + 16 bytes), gy tile: [channel][TH x 16] (+ 8 elements of padding): a lane's fragment -- 8 consecutive pixels
+  // of its half of a 16-pixel row -- is ONE ds_read_b128, and the three kernel columns come out of one window of ten patch
+  // values (a b128 and a b32) by shifting: it used to be 18 ds_read_b32 of fp32 values and 32 conversions per row step.
+  using half_t = typename std::conditional<PREC == 2, _Float16, __bf16>::type;
+  constexpr int XW = 24, XC = PH * XW + 8, GC = GT + 8;             // typed row width / channel strides (elements)
+  half_t* xs16 = reinterpret_cast<half_t*>(smem);
+  half_t* gs16 = xs16 + WG3_CI * XC;
+  static_assert(PREC == 0 || (WG3_CI * (PH * 24 + 8) + WG3_CO * (GT + 8)) * 2 <= Wgrad3Lds<TH, PREC, RAGGED>::SMEM * 4,
+                "the typed tiles fit the fp32 allocation");
 
   // Staging ownership: thread -> (row, channel).  x: one patch row of one input channel = the 6 aligned float4 that
   // cover columns [w0 - 4, w0 + 20) (18 of the 24 floats are the halo row); gy: one tile row of one output channel =
@@ -177,6 +187,40 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const Wgrad3Params& p, const 
 #pragma unroll
         for (int i = 0; i < WG3_TW; ++i) gs_row[i] = (okbits_g >> i) & 1u ? gr[i] : 0.f;
       }
+    } else if constexpr (PREC != 0) {
+      typedef half_t half2_t __attribute__((ext_vector_type(2)));
+      if (x_owner) {
+        float v[24];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const bool ok = (okbits >> q) & 1u;
+          const float f[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = f[j];
+            if (pro) t = fmaxf(fmaf(t, pro_a, pro_b), 0.f);
+            v[4 * q + j] = ok ? t : 0.f;
+          }
+        }
+        half2_t* row = reinterpret_cast<half2_t*>(xs16 + sch * XC + srow * XW);
+#pragma unroll
+        for (int c = 0; c < PW; c += 2) {    // patch column c = float c + 3 (patch column 0 = image column w0 - 1)
+          half2_t pair;
+          pair[0] = (half_t)v[c + 3]; pair[1] = (half_t)v[c + 4];
+          row[c >> 1] = pair;
+        }
+      }
+      if (g_owner) {
+        half2_t* row = reinterpret_cast<half2_t*>(gs16 + sch * GC + srow * WG3_TW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = (okbits >> (8 + q)) & 1u;
+          half2_t lo, hi;
+          lo[0] = (half_t)(ok ? gv[q].x : 0.f); lo[1] = (half_t)(ok ? gv[q].y : 0.f);
+          hi[0] = (half_t)(ok ? gv[q].z : 0.f); hi[1] = (half_t)(ok ? gv[q].w : 0.f);
+          row[2 * q] = lo; row[2 * q + 1] = hi;
+        }
+      }
     } else {
     if (x_owner) {
 #pragma unroll
@@ -212,25 +256,33 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const Wgrad3Params& p, const 
 
     if constexpr (PREC != 0) {
       using frag = typename std::conditional<PREC == 1, bf16x8, f16x8>::type;
-#pragma unroll 1
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const half_t* a16 = gs16 + l31 * GC + 8 * lhi;
+      const half_t* b16 = xs16 + l31 * XC + kh * XW + 8 * lhi;
+#pragma unroll
       for (int h = 0; h < TH; ++h) {
-        frag a, b[3];
-        float window[10];
+        const frag a = *reinterpret_cast<const frag*>(a16 + h * WG3_TW);
+        // ten patch values from column 8 * lhi on: d[0..3] = columns 0..7 (kw = 0), d[1..4] = columns 2..9 (kw = 2), and
+        // kw = 1 is every pair shifted by one element
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(b16 + h * XW);
+        const uint32_t top = *reinterpret_cast<const uint32_t*>(b16 + h * XW + 8);
+        const uint32_t d[5] = {lo[0], lo[1], lo[2], lo[3], top};
+        u32x4 w0, w1, w2;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) window[j] = b_base[h * PW + j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = a_base[h * WG3_TW + j];
-          if constexpr (PREC == 1) a[j] = (__bf16)v; else a[j] = (_Float16)v;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            if constexpr (PREC == 1) b[kw][j] = (__bf16)window[j + kw]; else b[kw][j] = (_Float16)window[j + kw];
-          }
+        for (int i = 0; i < 4; ++i) {
+          w0[i] = d[i];
+          w1[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], 16);
+          w2[i] = d[i + 1];
         }
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          if constexpr (PREC == 1) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[kw], acc[kw], 0, 0, 0);
-          else acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[kw], acc[kw], 0, 0, 0);
+        const frag b0 = __builtin_bit_cast(frag, w0), b1 = __builtin_bit_cast(frag, w1), b2 = __builtin_bit_cast(frag, w2);
+        if constexpr (PREC == 1) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc[2], 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b2, acc[2], 0, 0, 0);
         }
       }
     } else
