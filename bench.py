@@ -124,7 +124,6 @@ def build_experiment(args, dp):
     settings.reference_schedule = args.reference_schedule
     streams = side_streams(args)
     settings.overlap_dnn_step = streams and not os.environ.get('SRGAN_NO_DNN_STREAM')
-    settings.defer_dnn_step = streams and bool(os.environ.get('SRGAN_DEFER_DNN'))
     # (the grouped weight gradients on a stream of their own gained +4 % next to ONE chain, but with three chains in flight
     # a fifth / sixth / seventh stream aliases onto the four hardware queues of the HIP runtime and creates false
     # dependencies between the chains: 70.3 or 74.9 images/s from run to run, against a steady 75.1 without it)
@@ -495,7 +494,7 @@ def main():
         # per-kernel attribution needs one kernel at a time: this extra step runs on ONE stream
         experiment.join_dnn_stream()
         torch.cuda.synchronize()
-        for name in ('overlap_dnn_step', 'wgrad_stream', 'overlap_generator_forwards', 'overlap_gradient_penalty', 'defer_dnn_step'):
+        for name in ('overlap_dnn_step', 'wgrad_stream', 'overlap_generator_forwards', 'overlap_gradient_penalty'):
             setattr(experiment.settings, name, False)
         lib.srgan_profile_begin()
         one_step(experiment, labeled, unlabeled, args.warmup + args.steps, eager=True)

@@ -411,29 +411,12 @@ class Experiment(ABC):
         side = self._dnn_side_stream()
         if side is None:
             return self._dnn_training_step(examples, labels, step)
-        self._flush_deferred_dnn_step()
-        if getattr(self.settings, 'defer_dnn_step', False) and self._batches_are_resident():
-            # enqueued by gan_training_step once the discriminator step's two chains have joined: the DNN step then runs
-            # next to the generator step (one chain on the main stream) instead of next to two chains
-            self._deferred_dnn_step = (examples, labels, step)
-            return
         if not self._batches_are_resident():
             side.wait_stream(torch.cuda.current_stream())      # the batch was produced on the main stream
         # (resident batches: the DNN step of iteration i + 1 may start while iteration i's generator step still runs --
         # the DNN shares nothing with the GAN networks, so its stream only ever waits for its own previous step)
         with torch.cuda.stream(side):
             self._dnn_training_step(examples, labels, step)
-
-    def _flush_deferred_dnn_step(self, after_main=False):
-        pending = getattr(self, '_deferred_dnn_step', None)
-        if pending is None:
-            return
-        self._deferred_dnn_step = None
-        side = self._dnn_side_stream()
-        if after_main:
-            side.wait_stream(torch.cuda.current_stream())      # start where the main stream is now (the chains have joined)
-        with torch.cuda.stream(side):
-            self._dnn_training_step(*pending)
 
     def _dnn_side_stream(self):
         if not getattr(self.settings, 'overlap_dnn_step', False) or not examples_on_gpu():
@@ -498,7 +481,6 @@ class Experiment(ABC):
     def join_dnn_stream(self):
         """Settle the networks before anything outside the training step reads them: the current stream waits for an
         enqueued DNN step, and optimizer updates still waiting for their gradient exchange are applied."""
-        self._flush_deferred_dnn_step()
         self.finish_update()
         self._join_side_stream()
 
@@ -633,7 +615,6 @@ class Experiment(ABC):
                 gradient_penalty = self.gradient_penalty_calculation(fake_examples, unlabeled_examples)
                 self.scaled_backward(gradient_penalty, grad_ready=exchange)   # the last backward pass into D's arena (srgan.py:295)
         self.start_update('D', self.d_optimizer, exchange)
-        self._flush_deferred_dnn_step(after_main=True)
         generator_loss = None
         if generator_phase:
             with self.precision():
