@@ -267,7 +267,8 @@ def schedule_check(experiment, labeled, unlabeled, step):
         for name, value in flags.items():
             setattr(experiment.settings, name, value)
     worst = difference(timed_losses, single_losses)
-    floor = max(difference(again_losses, single_losses), difference(timed_again, timed_losses))
+    single_floor = difference(again_losses, single_losses)
+    timed_floor = difference(timed_again, timed_losses)
     weight_difference = max(float((a - b).abs().max()) for a, b in zip(timed_weights, single_weights))
     for (m, o), (data, exp_avg, exp_avg_sq, count) in zip(zip(modules, optimizers), saved):     # back to the timed state
         m._srgan_arena.data.copy_(data)
@@ -277,18 +278,15 @@ def schedule_check(experiment, labeled, unlabeled, step):
         if o.device_state is not None:
             o.device_state[0] = count
     torch.cuda.synchronize()
-    # Two runs of ONE schedule already differ: fp32 atomics (split-K partial sums) add in the order the workgroups happen to
-    # run, and a pre-activation that lands within rounding of zero flips its ReLU mask -- a discrete change of the recorded
-    # gradient whose norm the penalty squares.  On one stream the order is nearly fixed (1e-7 .. 1e-6 between repetitions);
-    # with chains in flight it is not: at 64 x 64, batch 2 -- every plane K-split with atomics -- the penalty of two runs of
-    # the SAME multi-stream schedule is up to 6e-4 apart while the other five losses agree to 1e-7
-    # (profiles/r04h_schedule_check_bisect.txt); at the benchmark's own size the difference is 6e-6 .. 4e-5.  The limit is
-    # 1e-4, or four times what a schedule differs from its own repetition by when that is more.
+    # The limit is FIXED against the single-stream run: 1e-4, or four times what the SINGLE-STREAM schedule differs from its
+    # own repetition by.  The multi-stream schedule's own repetition difference is reported (`timed_schedule_twice`) but never
+    # widens the limit: a cross-chain race makes exactly that number large, so a limit scaled by it could not fail on the
+    # defect the check exists to catch.
     return {'max_relative_loss_difference': worst, 'max_weight_difference': weight_difference,
-            'same_schedule_twice': floor, 'limit': max(SCHEDULE_CHECK_LIMIT, 4.0 * floor),
+            'single_stream_twice': single_floor, 'timed_schedule_twice': timed_floor,
+            'limit': max(SCHEDULE_CHECK_LIMIT, 4.0 * single_floor),
             'what': 'one iteration on the timed schedule vs the same iteration on ONE stream (eager), from the same weights, '
-                    'Adam state, batch and draws, after the timed region; same_schedule_twice = the larger of the two schedules\' '
-                    'differences from their own repetition',
+                    'Adam state, batch and draws, after the timed region; *_twice = a schedule against its own repetition',
             'losses_timed_schedule': timed_losses, 'losses_single_stream': single_losses}
 
 
@@ -583,23 +581,14 @@ def main():
         raise SystemExit('non-finite losses in the last timed step')
     check = None
     if side_streams(args) or args.step_graph:
-        # The comparison is repeated (twice more) only when it comes out above its limit: the rounding-level differences it
-        # has to tolerate are not deterministic (see schedule_check), a race is -- it is off by orders of magnitude, or NaN,
-        # every time.  Two of three attempts have to pass; every attempt is in the line.
-        attempts = []
-        while True:
-            check = schedule_check(experiment, labeled, unlabeled, args.warmup + args.steps)
-            excess = check['max_relative_loss_difference'] / check['limit']
-            if dp is not None:              # one decision for all ranks: a rank that left alone would hang the others
-                excess = dp.all_reduce_max_float(excess if excess == excess else float('inf'))
-                check['worst_rank_excess_over_limit'] = excess
-            attempts.append({'max_relative_loss_difference': check['max_relative_loss_difference'], 'limit': check['limit'],
-                             'within_limit': bool(excess <= 1.0)})
-            passed = sum(a['within_limit'] for a in attempts)
-            if (len(attempts) == 1 and passed == 1) or len(attempts) == 3:
-                break
-        check['attempts'] = attempts
-        if passed < (1 if len(attempts) == 1 else 2):
+        # ONE comparison against a fixed limit, no second chances: a difference above it is a failure of the schedule.
+        check = schedule_check(experiment, labeled, unlabeled, args.warmup + args.steps)
+        excess = check['max_relative_loss_difference'] / check['limit']
+        if dp is not None:                  # one decision for all ranks: a rank that left alone would hang the others
+            excess = dp.all_reduce_max_float(excess if excess == excess else float('inf'))
+            check['worst_rank_excess_over_limit'] = excess
+        check['within_limit'] = bool(excess <= 1.0)
+        if not check['within_limit']:
             raise SystemExit(f'the timed schedule and the single-stream schedule disagree: {json.dumps(check)}')
 
     result = {

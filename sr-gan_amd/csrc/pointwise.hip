@@ -536,29 +536,12 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     const int profile_slot = profile_bracket_begin(stream);
     int32_t rows_done = 0;
     if (const int status = pointwise_ring_run(in, in_bs, w, w_so, w_si, out, out_bs, N, CI, CO, HW, accumulate, stream, bn,
-                                              epilogue, epi_partial, (int32_t)col_blocks128, ring_pixels, &rows_done))
+                                              epilogue, epi_partial, (int32_t)col_blocks128, ring_pixels, &rows_done)) {
+      profile_bracket_end(profile_slot, stream, 0, 0, 0, 13, 128, ring_pixels, 1);      // close the bracket this call opened
       return status;
-    if (rows_done < CO) {
-      const int rest = CO - rows_done, rest_mi = rest <= 32 ? 1 : 2;
-      p.m_base = rows_done;
-      p.tiles_m = (rest + rest_mi * 32 - 1) / (rest_mi * 32);
-      p.k_per_split = ((CI + 63) / 64) * 64;
-      p.mode = accumulate == 1 ? 1 : 0;
-      p.xcd_remap = 0;
-      p.gpi = (HW + 31) / 32;
-      p.wide_out = ((((uintptr_t)out & 15) | (out_bs & 3) | (HW & 3)) == 0) ? 1 : 0;
-      if (epilogue) {
-        p.epi_ragged = 0;
-        p.epi_x = epilogue->x; p.epi_x_bs = epilogue->x_bs;
-        p.bn_mean = epilogue->bn[0]; p.bn_inv = epilogue->bn[1]; p.bn_gamma = epilogue->bn[2]; p.bn_beta = epilogue->bn[3];
-        p.epi_cols = (int32_t)col_blocks128;
-        p.epi_partial = epi_partial;
-      }
-      const int64_t col_blocks_short = ((int64_t)N * ((HW + 31) / 32) + 3) / 4;      // (= col_blocks128 when HW % 128 == 0)
-      const dim3 grid((unsigned)(col_blocks_short * p.tiles_m), 1, 1);
-      if (rest_mi == 2) launch_pointwise<2, 32, 1>(p, grid, stream);
-      else launch_pointwise<1, 32, 1>(p, grid, stream);
     }
+    // (the ring kernel covers every row: its last 128-row tile may be partial)
+    SRGAN_REQUIRE(rows_done == CO, SRGAN_EINVAL, "pointwise ring: rows left uncovered");
     if (epi_partial && !epilogue->partial_out)
       bn_partial_reduce_run(epi_partial, (int)col_blocks128, CO, epilogue->bn[1], epilogue->g_gamma, epilogue->g_beta, stream);
     const int status = launch_status();

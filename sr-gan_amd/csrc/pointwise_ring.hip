@@ -25,6 +25,7 @@
 //     epilogue phases, which measured better than three or four stages at one workgroup per CU.
 // Roofline: fp32 MFMA 157.3 TF/s; algorithmic bytes 4 * (CI + CO) per pixel (+ the epilogue streams of a fused data
 // gradient).
+#include <atomic>
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -371,10 +372,16 @@ static int launch_ring(const RingParams& p, unsigned blocks, hipStream_t stream)
   constexpr int STAGES = 2;
   constexpr int bytes = STAGES * (128 * 32 * 4 + 32 * 128 * NI + (FUSE == 1 ? 2048 : 0));
   auto kernel = pointwise_ring_kernel<STAGES, NI, A_KCONTIG, FUSE>;
-  static bool configured = false;
-  if (!configured) {      // more than 64 KB of dynamic LDS needs the attribute (once per kernel)
+  // More than 64 KB of dynamic LDS needs the attribute -- once per kernel AND per device (the attribute belongs to the
+  // device's copy of the function); a bit per device ordinal, set with an atomic OR so that two host threads launching
+  // for the first time together at worst both set the (idempotent) attribute.
+  static std::atomic<uint64_t> configured_devices{0};
+  int device = 0;
+  SRGAN_HIP(hipGetDevice(&device));
+  const uint64_t bit = (uint64_t)1 << (device & 63);
+  if (!(configured_devices.load(std::memory_order_acquire) & bit)) {
     SRGAN_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    configured = true;
+    configured_devices.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), bytes, stream, p);
   return launch_status();

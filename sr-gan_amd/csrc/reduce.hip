@@ -115,9 +115,12 @@ __global__ __launch_bounds__(256) void chan_reduce_rows_ordered_kernel(const flo
   if (threadIdx.x == 0) {
     // Device-scope atomics only (they act at the memory side: coherent across the eight XCDs' L2s by themselves); a
     // device-scope FENCE here would write back / invalidate a whole L2 per workgroup (measured: 76 us for the 30 us
-    // reduction).  The partial is acknowledged (vmcnt(0): the workgroup-scope release) before the ticket is taken.
+    // reduction).  The partial (a write-through `sc1` store) must be ACKNOWLEDGED before the ticket is taken: store and
+    // ticket live in different L2 channels, so without the wait the row's last workgroup -- possibly on another XCD --
+    // could draw the final ticket and still read the previous launch's partial (a workgroup-scope release fence
+    // emits no instruction at all here; the ISA had the atomic straight behind the store).  Stores count in vmcnt on gfx9.
     __hip_atomic_store(row + blockIdx.y, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1);
   }
   __syncthreads();

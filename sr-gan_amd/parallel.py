@@ -124,9 +124,10 @@ class GradientExchange:
     def ready_from(self, offset):
         offset = max(0, min(int(offset), self.sent_from))
         if self.wire != 'f32' or self.form != 'all_reduce':
-            # staged buckets start on a 32-byte boundary of the arena (the pack / copy kernels move 16-byte groups); rounding
-            # the frontier UP only declares fewer elements final
-            offset = min((offset + 7) // 8 * 8, self.sent_from)
+            # staged buckets start on a 16-byte boundary of the arena (4 elements: what the pack / copy kernels check; the
+            # arena's length and the bucket size are multiples of 4, so every later split keeps it); rounding the frontier
+            # UP only declares fewer elements final
+            offset = min((offset + 3) // 4 * 4, self.sent_from)
         if self.sent_from - offset >= self.min_bucket:
             self._send(offset, self.sent_from)
 

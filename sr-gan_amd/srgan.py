@@ -37,36 +37,47 @@ from .tape import Var, backward, no_grad
 from .utility import SummaryWriter, MixtureModel, current_device, make_directory_name_unique, seed_all
 
 
-def as_var(value):
-    """Device tensors from the data pipeline enter the tape as constants."""
+def as_var(value, staged=False):
+    """Device tensors from the data pipeline enter the tape as constants.  ``staged``: a small host tensor goes through a
+    pinned staging buffer (the three random draws of an iteration ask for it; nothing else does)."""
     if isinstance(value, Var) or value is None:
         return value
     if isinstance(value, (tuple, list)):
         return tuple(as_var(v) for v in value)
     if isinstance(value, np.ndarray):
         value = torch.from_numpy(value)
-    if value.device.type == 'cpu' and torch.cuda.is_available() and value.dtype == torch.float32 and \
-            0 < value.numel() <= _STAGING_LIMIT:
+    if staged and value.device.type == 'cpu' and torch.cuda.is_available() and value.dtype == torch.float32 and \
+            0 < value.numel() <= _STAGING_LIMIT and not torch.cuda.is_current_stream_capturing():
         return F.constant(_through_pinned_staging(value))
     return F.constant(value.to(current_device(), non_blocking=True))
 
 
-# Small host tensors (the three random draws of an iteration, srgan.py:286-289,301,364) reach the device through PINNED
-# staging buffers: a copy from pageable memory is staged by the runtime and its blit kernel sat 0.55 ms on the stream per
-# draw (rocprofv3, round 3: three __amd_rocclr_copyBuffer launches of 555 us per iteration, the first in front of the
-# generator's forward pass).  A ring of buffers per size; a buffer is reused only after the copy that read it has finished.
+# The three random draws of an iteration (srgan.py:286-289,301,364) reach the device through PINNED staging buffers: a copy
+# from pageable memory is staged by the runtime and its blit kernel sat 0.55 ms on the stream per draw (rocprofv3, round 3:
+# three __amd_rocclr_copyBuffer launches of 555 us per iteration, the first in front of the generator's forward pass).  A ring
+# of buffers per size; a buffer is reused only after the copy that read it has finished.  Only the draw call sites stage
+# (`as_var(..., staged=True)`), never while a stream is capturing (a captured copy would re-read whatever the reusable slot
+# holds at replay time), and the rings of at most _STAGING_SIZES distinct sizes are kept (least recently used dropped), so
+# pinned memory stays bounded when batch sizes vary.
 _STAGING_LIMIT = 1 << 20
 _STAGING_RING = 8
+_STAGING_SIZES = 6
 _staging = {}
 
 
 def _through_pinned_staging(value):
     device = current_device()
     key = (value.numel(), str(device))
-    ring = _staging.get(key)
+    ring = _staging.pop(key, None)
     if ring is None:
-        ring = _staging[key] = {'next': 0, 'slots': [[torch.empty(value.numel(), dtype=torch.float32).pin_memory(), None]
-                                                    for _ in range(_STAGING_RING)]}
+        while len(_staging) >= _STAGING_SIZES:
+            oldest = _staging.pop(next(iter(_staging)))
+            for _, event in oldest['slots']:
+                if event is not None:
+                    event.synchronize()             # its copies are done before the pinned pages go away
+        ring = {'next': 0, 'slots': [[torch.empty(value.numel(), dtype=torch.float32).pin_memory(), None]
+                                     for _ in range(_STAGING_RING)]}
+    _staging[key] = ring                            # (re-inserted last: the dict's order is the recency order)
     slot = ring['slots'][ring['next']]
     ring['next'] = (ring['next'] + 1) % _STAGING_RING
     if slot[1] is not None:
@@ -74,9 +85,8 @@ def _through_pinned_staging(value):
     slot[0].copy_(value.reshape(-1))
     out = torch.empty(value.shape, dtype=torch.float32, device=device)
     out.view(-1).copy_(slot[0], non_blocking=True)
-    if not torch.cuda.is_current_stream_capturing():
-        slot[1] = torch.cuda.Event()
-        slot[1].record()
+    slot[1] = torch.cuda.Event()
+    slot[1].record()
     return out
 
 
@@ -400,15 +410,15 @@ class Experiment(ABC):
 
     def sample_discriminator_noise(self, batch_size):
         z = self._take_draw('z_d')
-        return as_var(self.draw_discriminator_noise(batch_size) if z is None else z)
+        return as_var(self.draw_discriminator_noise(batch_size) if z is None else z, staged=True)
 
     def sample_generator_noise(self, batch_size):
         z = self._take_draw('z_g')
-        return as_var(self.draw_generator_noise(batch_size) if z is None else z)
+        return as_var(self.draw_generator_noise(batch_size) if z is None else z, staged=True)
 
     def sample_interpolation_alpha(self, batch_size):
         alpha = self._take_draw('alpha')
-        return as_var((self.draw_interpolation_alpha(batch_size) if alpha is None else alpha).reshape(-1))
+        return as_var((self.draw_interpolation_alpha(batch_size) if alpha is None else alpha).reshape(-1), staged=True)
 
     # ------------------------------------------------------------------------------------------ batch reductions
     def _global_batch(self, local):
