@@ -417,6 +417,23 @@ def cpu_baseline(image_size, batch=1, timed=3, limit_seconds=600):
                 'sample': f'not measured: {type(error).__name__} (limit {limit_seconds} s)'}
 
 
+def committed_cpu_baseline(image_size, batch, cpu):
+    """The oracle timed ONCE at the GPU leg's own batch (two minutes per iteration and 90 GiB at 512 x 512 / 16: too long
+    for every default run), as committed under profiles/ -- carried next to the live sample so that the line holds the
+    like-for-like figure too.  None unless a committed measurement of this image size and batch exists; `same_cpu_model`
+    says whether it was taken on the CPU model this run sees."""
+    path = os.path.join(ROOT, 'profiles', f'cpu_baseline_{image_size}x{image_size}_batch{batch}.json')
+    try:
+        entry = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return {'value': entry['value'], 'unit': entry['unit'], 'cores': entry['cores'], 'kind': entry['kind'], 'batch': entry['batch'],
+            'cpu': entry.get('cpu'), 'same_cpu_model': entry.get('cpu') == cpu,
+            'seconds_per_iteration': entry.get('seconds_per_iteration'),
+            'provenance': f'profiles/{os.path.basename(path)} (python bench.py --cpu-baseline-child --cpu-baseline-batch {batch}, '
+                          'measured on a GPU box of this pool in round 4; not re-timed in this run)'}
+
+
 def cpu_baseline_child(image_size, batch=1, warmup=1, timed=3):
     """The oracle's full iteration (reference srgan.py:104-118) on the host cores: ``warmup`` + ``timed`` iterations of
     the same image shape at ``batch`` images.  The per-image rate FALLS with the batch on the GPU box's 16
@@ -696,6 +713,8 @@ def main():
         result['hbm_kernels'] = hbm_kernel_rates(experiment)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'crowd':
         result['cpu_baseline'] = cpu_baseline(args.image_size, batch=args.cpu_baseline_batch, timed=args.cpu_baseline_timed)
+        result['cpu_baseline']['like_for_like'] = committed_cpu_baseline(args.image_size, args.batch_per_gpu,
+                                                                         result['cpu_baseline'].get('cpu'))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dp is not None:

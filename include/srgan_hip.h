@@ -16,8 +16,10 @@
  *   - thread safety: calls may come from several host threads (the registry and the profile state are locked,
  *     srgan_last_error is thread-local); two threads must not launch on the SAME stream with the same workspace
  *     concurrently, as with any stream-ordered resource.
- *   - collectives are deliberately NOT part of this ABI: the data-parallel exchange (feature sums, gradient arenas)
- *     stays in torch.distributed (backend "nccl" = RCCL over xGMI) on the host side, see INTEGRATION.md.
+ *   - collectives: thin RCCL entry points (srgan_comm_*, srgan_all_reduce_sum, srgan_reduce_scatter_sum,
+ *     srgan_all_gather, at the end of this file) carry the data-parallel exchange for a caller without torch.distributed;
+ *     the Python host keeps torch.distributed (backend "nccl" = the same RCCL over xGMI) as its default transport and can
+ *     be switched onto these entry points (`SRGAN_ABI_COLLECTIVES=1`, sr-gan_amd/parallel.py), see INTEGRATION.md.
  *   - `stream` is a hipStream_t (NULL = default stream); every call is asynchronous on it.
  *   - `accumulate` != 0 adds into the existing output (gradient accumulation across the four
  *     discriminator backward passes, reference srgan.py:280-295) instead of overwriting it.
@@ -357,6 +359,27 @@ int srgan_adam_step_counted(float* p, const float* g, float* m, float* v, int64_
  * (round to nearest even) and back; both buffers 16-byte aligned.  The master gradients stay fp32. */
 int srgan_pack_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 int srgan_unpack_bf16(const uint16_t* src, float* dst, int64_t n, void* stream);
+
+/* ---- collectives (RCCL over xGMI) -------------------------------------------------------------------------------
+ * The reference has no collectives (one device: its batch means are `features.mean(0)`, srgan.py:442-443, and its
+ * gradients complete on that device at srgan.py:264,295,304); the data-parallel path needs the SUM of the
+ * ranks' feature sums in the forward pass (F floats: 80 for crowd) and the sum of the flat gradient arenas.  These are thin
+ * wrappers: RCCL is resolved with dlopen("librccl.so.1") at first use -- the copy already mapped by the process if there
+ * is one -- so the library has no link-time dependency on it.  A communicator belongs to the device that was current
+ * when it was created; collectives are asynchronous on `stream`, in issue order; `dtype`: 0 = fp32, 1 = bf16 (the wire
+ * format of srgan_pack_bf16).  A failing RCCL call returns 10000 + ncclResult_t with RCCL's message in srgan_last_error();
+ * -2 when RCCL cannot be loaded. */
+int srgan_comm_available(void);                               /* 1 when librccl could be resolved, else 0 (no error) */
+int srgan_comm_unique_id(void* id128);                        /* ncclGetUniqueId: 128 bytes, made on rank 0 and handed to every rank by the caller */
+int srgan_comm_init(void** comm, int32_t world_size, int32_t rank, const void* id128);   /* ncclCommInitRank on the current device */
+int srgan_comm_world_size(void* comm, int32_t* world_size);
+int srgan_comm_destroy(void* comm);
+/* recv[i] = sum over ranks of send[i], i < count (send == recv: in place): gradient buckets and the tiny feature sums */
+int srgan_all_reduce_sum(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, void* stream);
+/* the same sum as two halves over all links at once (point-to-point xGMI): rank r receives elements [r, r + 1) * recv_count
+ * of the sum of send[0 .. world * recv_count); all_gather puts rank r's send_count elements at [r, r + 1) * send_count */
+int srgan_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t recv_count, int32_t dtype, void* stream);
+int srgan_all_gather(void* comm, const void* send, void* recv, int64_t send_count, int32_t dtype, void* stream);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------
  * Between begin and end every contraction launch (conv / gemm passes) is bracketed by a pair of HIP events on

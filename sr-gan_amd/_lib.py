@@ -108,6 +108,14 @@ SIGNATURES = {
     'srgan_adam_step_counted': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp], ctypes.c_int),
     'srgan_pack_bf16': ([vp, vp, i64, vp], ctypes.c_int),
     'srgan_unpack_bf16': ([vp, vp, i64, vp], ctypes.c_int),
+    'srgan_comm_available': ([], ctypes.c_int),
+    'srgan_comm_unique_id': ([vp], ctypes.c_int),
+    'srgan_comm_init': ([ctypes.POINTER(vp), i32, i32, vp], ctypes.c_int),
+    'srgan_comm_world_size': ([vp, ctypes.POINTER(i32)], ctypes.c_int),
+    'srgan_comm_destroy': ([vp], ctypes.c_int),
+    'srgan_all_reduce_sum': ([vp, vp, vp, i64, i32, vp], ctypes.c_int),
+    'srgan_reduce_scatter_sum': ([vp, vp, vp, i64, i32, vp], ctypes.c_int),
+    'srgan_all_gather': ([vp, vp, vp, i64, i32, vp], ctypes.c_int),
 }
 
 

@@ -101,10 +101,17 @@ class GradientExchange:
             self.pending.append((buffer, first, stop))
         else:
             buffer = target
+        abi = getattr(self.dp, 'abi', None)         # the C ABI's RCCL entry points instead of torch.distributed (opt-in)
         if self.form == 'all_reduce':
-            self.works.append(dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            self.works.append(abi.all_reduce_async(buffer) if abi is not None else
+                              dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=group, async_op=True))
             return
         shard = torch.empty(padded // world, dtype=buffer.dtype, device=buffer.device)
+        if abi is not None:                 # one communication stream: in issue order
+            self.works.append(abi.reduce_scatter_async(shard, buffer))
+            self.works.append(abi.all_gather_async(buffer, shard))
+            self.pending.append((shard, None, None))
+            return
         scatter = dist.reduce_scatter_tensor(shard, buffer, op=dist.ReduceOp.SUM, group=group, async_op=True)
         if not self.in_order:               # (gloo runs asynchronous work on several threads)
             scatter.wait()
@@ -161,8 +168,96 @@ class _AllReduceSum(torch.autograd.Function):
         return grad, None
 
 
+class _StreamWork:
+    """What an asynchronous collective of ``AbiCommunicator`` returns: ``wait()`` makes the CURRENT stream wait for it (the
+    contract of ``torch.distributed``'s NCCL work objects, which ``GradientExchange.wait`` relies on)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class AbiCommunicator:
+    """The data-parallel collectives through the C ABI's RCCL entry points (include/srgan_hip.h, "collectives") instead of
+    ``torch.distributed``: one RCCL communicator per rank, created from a unique id that rank 0 makes and the existing
+    process group hands to the others (the rendezvous a reference-side caller would do over its own channel).  The tiny
+    forward all-reduce of the feature sums runs on the caller's stream; gradient buckets run on ONE communication stream
+    (in issue order) that first waits for the compute stream, and return a work object whose ``wait()`` orders the current
+    stream behind them.  Device tensors only, fp32 or bf16."""
+
+    def __init__(self, dp):
+        import ctypes
+        from . import _lib
+        self.lib = _lib.library()
+        self.check = _lib.check
+        if not self.lib.srgan_comm_available():
+            raise RuntimeError('the C ABI could not resolve librccl.so.1')
+        identifier = ctypes.create_string_buffer(128)
+        if dp.rank == 0:
+            self.check(self.lib.srgan_comm_unique_id(identifier), 'srgan_comm_unique_id')
+        raw = dp.broadcast_object(identifier.raw if dp.rank == 0 else None)
+        self.comm = ctypes.c_void_p()
+        self.check(self.lib.srgan_comm_init(ctypes.byref(self.comm), dp.world_size, dp.rank, raw), 'srgan_comm_init')
+        world = ctypes.c_int32()
+        self.check(self.lib.srgan_comm_world_size(self.comm, ctypes.byref(world)), 'srgan_comm_world_size')
+        assert world.value == dp.world_size
+        self.world_size = dp.world_size
+        self.stream = torch.cuda.Stream()
+        self.calls = 0                       # collectives issued (tests / diagnostics)
+
+    @staticmethod
+    def _wire(tensor):
+        if not tensor.is_cuda or not tensor.is_contiguous() or tensor.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('ABI collectives take contiguous fp32 / bf16 device tensors')
+        return 0 if tensor.dtype == torch.float32 else 1
+
+    def all_reduce_sum_(self, tensor):
+        """In place, on the current stream (the feature sums: F floats)."""
+        self.calls += 1
+        self.check(self.lib.srgan_all_reduce_sum(self.comm, tensor.data_ptr(), tensor.data_ptr(), tensor.numel(),
+                                                 self._wire(tensor), torch.cuda.current_stream().cuda_stream),
+                   'srgan_all_reduce_sum')
+        return tensor
+
+    def _on_communication_stream(self, launch, *tensors):
+        self.calls += 1
+        self.stream.wait_stream(torch.cuda.current_stream())
+        launch(self.stream.cuda_stream)
+        for tensor in tensors:
+            tensor.record_stream(self.stream)
+        event = torch.cuda.Event()
+        event.record(self.stream)
+        return _StreamWork(event)
+
+    def all_reduce_async(self, tensor):
+        wire = self._wire(tensor)
+        return self._on_communication_stream(lambda stream: self.check(self.lib.srgan_all_reduce_sum(
+            self.comm, tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), wire, stream), 'srgan_all_reduce_sum'), tensor)
+
+    def reduce_scatter_async(self, shard, tensor):
+        wire = self._wire(tensor)
+        assert shard.dtype == tensor.dtype and shard.numel() * self.world_size == tensor.numel()
+        return self._on_communication_stream(lambda stream: self.check(self.lib.srgan_reduce_scatter_sum(
+            self.comm, tensor.data_ptr(), shard.data_ptr(), shard.numel(), wire, stream), 'srgan_reduce_scatter_sum'), shard, tensor)
+
+    def all_gather_async(self, tensor, shard):
+        wire = self._wire(tensor)
+        assert shard.dtype == tensor.dtype and shard.numel() * self.world_size == tensor.numel()
+        return self._on_communication_stream(lambda stream: self.check(self.lib.srgan_all_gather(
+            self.comm, shard.data_ptr(), tensor.data_ptr(), shard.numel(), wire, stream), 'srgan_all_gather'), shard, tensor)
+
+    def close(self):
+        if self.comm is not None and self.comm.value:
+            torch.cuda.synchronize()
+            self.check(self.lib.srgan_comm_destroy(self.comm), 'srgan_comm_destroy')
+            self.comm = None
+
+
 class DataParallel:
     force = False
+    abi = None           # an AbiCommunicator when the exchanges go through the C ABI's RCCL entry points
 
     def __init__(self, group=None, force=None):
         if not dist.is_initialized():
@@ -174,6 +269,15 @@ class DataParallel:
         # cannot share a device under RCCL, one rank can: this is how a one-GPU box pushes the feature-sum all-reduce, the
         # asynchronous gradient buckets, their stream-side ``wait()`` and the broadcasts through the nccl backend.
         self.force = bool(int(os.environ.get('SRGAN_FORCE_DP', '0'))) if force is None else bool(force)
+        if os.environ.get('SRGAN_ABI_COLLECTIVES') == '1' and torch.cuda.is_available():
+            self.use_abi_collectives()
+
+    def use_abi_collectives(self):
+        """Route the feature-sum all-reduce and the gradient buckets through the C ABI's RCCL entry points
+        (``SRGAN_ABI_COLLECTIVES=1``); rendezvous, broadcasts and barriers stay on the process group."""
+        if self.abi is None:
+            self.abi = AbiCommunicator(self)
+        return self.abi
 
     @property
     def active(self):
@@ -230,16 +334,19 @@ class DataParallel:
         gradient is all-reduced as well -- for a sum that feeds rank-specific terms of a loss that is itself a sum over
         ranks (the ``normalize_feature_norm`` branch, whose distance runs over every rank's own rows)."""
         from .tape import Var, Node, grad_enabled
-        data = var.data.clone()
-        dist.all_reduce(data, op=dist.ReduceOp.SUM, group=self.group)
+        def summed(tensor):
+            tensor = tensor.clone()
+            if self.abi is not None and tensor.is_cuda:
+                return self.abi.all_reduce_sum_(tensor.contiguous())
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+            return tensor
+        data = summed(var.data)
         out = Var(data, requires_grad=grad_enabled() and var.requires_grad)
         if out.requires_grad:
             def backward(g, needs):
                 if not reduce_backward:
                     return (g,)
-                total = g.data.clone()
-                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
-                return (Var(total),)
+                return (Var(summed(g.data)),)
             out.node = Node((var,), backward, 'all_reduce_sum')
         return out
 

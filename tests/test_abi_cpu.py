@@ -71,3 +71,11 @@ def test_argument_errors_are_reported_before_any_device_work(lib):
     assert library.srgan_conv2d_bnrelu_supported(ctypes.byref(huge), 0) == 0
     assert library.srgan_set_workspace(16, 1024, None) == lib.EINVAL                              # smaller than required
     assert library.srgan_set_workspace(8, 64 << 20, None) == lib.EINVAL                           # misaligned
+    # the RCCL entry points check their arguments before they resolve / reach RCCL
+    assert library.srgan_comm_unique_id(None) == lib.EINVAL
+    assert library.srgan_comm_init(None, 1, 0, None) == lib.EINVAL
+    holder = ctypes.c_void_p()
+    assert library.srgan_comm_init(ctypes.byref(holder), 2, 2, b'\0' * 128) == lib.EINVAL          # rank outside the world
+    assert library.srgan_all_reduce_sum(None, 16, 16, 4, 0, None) == lib.EINVAL
+    assert library.srgan_reduce_scatter_sum(16, 16, 16, 4, 5, None) == lib.EINVAL                 # unknown wire dtype
+    assert library.srgan_comm_available() in (0, 1)

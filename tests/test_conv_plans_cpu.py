@@ -138,3 +138,18 @@ def test_fastdiv_exhaustive_edges(emul):
     for d in [1, 2, 3, 5, 7, 9, 16, 49, 147, 1152, 12544, 16384, 262144, 2 ** 30 + 7]:
         for n in list(rng.integers(0, 2 ** 31 - 1, 200)) + [0, 1, d - 1, d, d + 1, 2 ** 31 - 1]:
             assert emul.emul_fastdiv_check(int(d), int(n)) == 1, (d, n)
+
+
+def test_host_plan_code_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """SURVEY.md 5 asks for ``-fsanitize=address`` on the host half of the library: tests/csrc/sanitize_conv_plans.cpp runs
+    the plan builders of conv_plan.h / gather_gemm.h through the CPU emulator on exactly-sized buffers (forward, data and
+    weight gradient of every geometry family incl. the 66 x 200 driving frame, the strided GEMM, the magic-number
+    division), built with ASan + UBSan; any report aborts the program."""
+    binary = str(tmp_path / 'sanitize_conv_plans')
+    subprocess.check_call(['g++', '-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                           '-fno-omit-frame-pointer', '-I' + os.path.join(ROOT, 'sr-gan_amd', 'csrc'),
+                           os.path.join(ROOT, 'tests', 'csrc', 'sanitize_conv_plans.cpp'), '-o', binary])
+    done = subprocess.run([binary], capture_output=True, text=True, timeout=600,
+                          env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1'))
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
+    assert done.stdout.strip().startswith('ok:'), done.stdout

@@ -76,14 +76,17 @@ def _step(dp, queue=None, broadcast=False, streams=False, normalize=False):
     for name, module in (('D', experiment.D), ('DNN', experiment.DNN), ('G', experiment.G)):
         tensors.update({f'{name}/{k}': v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()})
     if queue is not None:
-        queue.put((dp.rank, result, tensors, {name: [list(b) for b in buckets] for name, buckets in launched.items()}))
+        report = {name: [list(b) for b in buckets] for name, buckets in launched.items()}
+        if getattr(dp, 'abi', None) is not None:       # collectives issued through the C ABI's RCCL entry points
+            report['abi_collectives'] = dp.abi.calls
+        queue.put((dp.rank, result, tensors, report))
     return result, tensors
 
 
-def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=False, normalize=False):
+def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=False, normalize=False, abi=False):
     device = rank if backend == 'nccl' else 0          # RCCL: one device per rank; gloo: both ranks on cuda:0
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
-                      LOCAL_RANK=str(device), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      LOCAL_RANK=str(device), HSA_ENABLE_IPC_MODE_LEGACY='0', SRGAN_ABI_COLLECTIVES='1' if abi else '0')
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     torch.cuda.set_device(device)
@@ -93,16 +96,19 @@ def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=
     assert torch.distributed.get_backend() == backend
     if force:                                            # what Experiment.train() does before the first step
         assert dp.broadcast_object({'trial': 'x', 'skip': False}) == {'trial': 'x', 'skip': False}
+    assert (dp.abi is not None) == bool(abi)
     _step(dp, queue, broadcast=force, streams=streams, normalize=normalize)
     dp.barrier()
+    if dp.abi is not None:
+        dp.abi.close()
     torch.distributed.destroy_process_group()
 
 
-def _run_ranks(world_size, backend, force=False, streams=False, normalize=False):
+def _run_ranks(world_size, backend, force=False, streams=False, normalize=False, abi=False):
     context = mp.get_context('spawn')
     queue = context.Queue()
     port = _free_port()
-    workers = [context.Process(target=_worker, args=(rank, world_size, port, queue, backend, force, streams, normalize))
+    workers = [context.Process(target=_worker, args=(rank, world_size, port, queue, backend, force, streams, normalize, abi))
                for rank in range(world_size)]
     for worker in workers:
         worker.start()

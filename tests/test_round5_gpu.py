@@ -82,3 +82,61 @@ def test_ordered_row_reduction_with_poisoned_partials_next_to_a_heavy_stream(pkg
         assert_close(first.cpu().numpy(), want.float().numpy(), rtol=2e-6, what=f'squared norms {rows} x {length}')
         for iteration, result in enumerate(results):
             assert torch.equal(result, first), f'{rows} x {length}: launch {iteration} differs from the first ({result} vs {first})'
+
+
+def test_rccl_entry_points_of_the_abi_on_one_rank(pkg):
+    """include/srgan_hip.h "collectives": a communicator of ONE rank from a unique id (two ranks cannot share a device under
+    RCCL, one rank can); all-reduce, reduce-scatter and all-gather in fp32 and bf16 on the caller's stream are the identity
+    there, and they must leave exactly that; argument errors come back as -1 before RCCL is reached."""
+    import ctypes
+    from srgan_amd import _lib
+    lib = _lib.library()
+    assert lib.srgan_comm_available() == 1
+    identifier = ctypes.create_string_buffer(128)
+    _lib.check(lib.srgan_comm_unique_id(identifier), 'srgan_comm_unique_id')
+    assert any(identifier.raw)
+    comm = ctypes.c_void_p()
+    _lib.check(lib.srgan_comm_init(ctypes.byref(comm), 1, 0, identifier.raw), 'srgan_comm_init')
+    world = ctypes.c_int32()
+    _lib.check(lib.srgan_comm_world_size(comm, ctypes.byref(world)), 'srgan_comm_world_size')
+    assert world.value == 1
+    stream = torch.cuda.current_stream().cuda_stream
+    for dtype, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+        source = torch.randn(100003, device='cuda').to(dtype)
+        out = torch.zeros_like(source)
+        _lib.check(lib.srgan_all_reduce_sum(comm, source.data_ptr(), out.data_ptr(), source.numel(), code, stream), 'all_reduce')
+        assert torch.equal(out, source)
+        in_place = source.clone()
+        _lib.check(lib.srgan_all_reduce_sum(comm, in_place.data_ptr(), in_place.data_ptr(), source.numel(), code, stream), 'all_reduce')
+        assert torch.equal(in_place, source)
+        shard = torch.zeros_like(source)
+        _lib.check(lib.srgan_reduce_scatter_sum(comm, source.data_ptr(), shard.data_ptr(), source.numel(), code, stream), 'reduce_scatter')
+        gathered = torch.zeros_like(source)
+        _lib.check(lib.srgan_all_gather(comm, shard.data_ptr(), gathered.data_ptr(), source.numel(), code, stream), 'all_gather')
+        assert torch.equal(gathered, source)
+    assert lib.srgan_all_reduce_sum(comm, source.data_ptr(), out.data_ptr(), 4, 7, stream) == _lib.EINVAL     # unknown dtype
+    assert lib.srgan_all_reduce_sum(None, source.data_ptr(), out.data_ptr(), 4, 0, stream) == _lib.EINVAL
+    torch.cuda.synchronize()
+    _lib.check(lib.srgan_comm_destroy(comm), 'srgan_comm_destroy')
+
+
+@pytest.mark.parametrize('streams', [False, True])
+def test_data_parallel_step_through_the_abi_collectives_equals_the_plain_step(streams):
+    """`SRGAN_ABI_COLLECTIVES=1`: the feature-sum all-reduce of the forward pass and every asynchronous gradient bucket go
+    through srgan_all_reduce_sum on an RCCL communicator the ABI created (world size 1, exchanges forced on; the process
+    group only carries the unique id, the broadcasts and the barrier) -- losses and updated weights equal the plain step."""
+    import test_parallel_gpu as parallel_tests
+    reference_result, reference_tensors = parallel_tests._step(None)
+    (rank, result, tensors, launched), = parallel_tests._run_ranks(1, 'nccl', force=True, streams=streams, abi=True)
+    assert launched['DNN'] and launched['D'] and launched['G'], launched
+    buckets = sum(len(b) for name, runs in launched.items() if name != 'abi_collectives' for b in runs)
+    assert launched['abi_collectives'] >= buckets + 3, launched          # the buckets + the forward feature sums
+    for key, value in reference_result.items():
+        assert abs(result[key] - value) <= 1e-4 * max(abs(value), 1e-6), (key, result[key], value)
+    for key, value in reference_tensors.items():
+        limit = 2.2e-4 + 1e-3 * float(np.abs(value).max())
+        assert float(np.abs(tensors[key] - value).max()) <= limit, key
+    import conftest
+    conftest.PARITY_NOTES.append(f'data-parallel step with every exchange through the C ABI\'s RCCL entry points (world size 1, forced): '
+                                 f'{launched["abi_collectives"]} collectives, {buckets} gradient buckets, losses equal the plain step '
+                                 f'(side streams {"on" if streams else "off"})')
