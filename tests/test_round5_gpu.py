@@ -140,3 +140,39 @@ def test_data_parallel_step_through_the_abi_collectives_equals_the_plain_step(st
     conftest.PARITY_NOTES.append(f'data-parallel step with every exchange through the C ABI\'s RCCL entry points (world size 1, forced): '
                                  f'{launched["abi_collectives"]} collectives, {buckets} gradient buckets, losses equal the plain step '
                                  f'(side streams {"on" if streams else "off"})')
+
+
+def test_age_vgg_fp32_step_at_batch_128_matches_the_oracle(pkg, monkeypatch):
+    """BASELINE.json configs[1] at its STATED batch against the ORACLE (the batch-128 steps were only
+    compared with the product's own fp32 step): VGG-16 discriminator on 64 x 64 faces, 128 examples, fp32 -- the five
+    logged losses within 1e-3 and the post-Adam weights of all three networks against the PyTorch-CPU restatement."""
+    import srgan_amd.age.srgan as age
+    from oracle import models as OM
+    from test_steps_gpu import _hip_and_oracle_step
+    monkeypatch.setattr(age, 'model_architecture', 'vgg')
+
+    def configure(experiment):
+        experiment.image_size = 64
+    _hip_and_oracle_step(age.AgeExperiment, configure,
+                         lambda: (OM.DCGANGenerator(image_size=64), OM.VGG16(1, 64), OM.VGG16(1, 64)),
+                         size=64, batch=128, d_scale=1.3)
+    import conftest
+    conftest.PARITY_NOTES.append('config 2 (age, VGG-16 @ 64 x 64) fp32 step at batch 128 checked against the CPU oracle')
+
+
+def test_driving_fp32_step_at_batch_128_matches_the_oracle(pkg):
+    """BASELINE.json configs[4] at its stated per-device batch against the ORACLE: the DCGAN pair on 64 x 192 frames, 128
+    examples, fp32."""
+    from srgan_amd.driving.srgan import DrivingExperiment
+    from oracle import models as OM
+    from test_steps_gpu import _hip_and_oracle_step
+    size = (64, 192)
+
+    def configure(experiment):
+        experiment.image_size = size
+    _hip_and_oracle_step(DrivingExperiment, configure,
+                         lambda: (OM.DCGANGenerator(image_size=size), OM.DCGANDiscriminator(image_size=size),
+                                  OM.DCGANDiscriminator(image_size=size)),
+                         size=size, batch=128, d_scale=2.2)
+    import conftest
+    conftest.PARITY_NOTES.append('config 5 (driving, DCGAN @ 64 x 192) fp32 step at batch 128 checked against the CPU oracle')
