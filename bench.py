@@ -557,7 +557,7 @@ def main():
 
     for step in range(args.warmup):
         one_step(experiment, labeled, unlabeled, step)
-    if args.step_graph and world == 1:
+    if args.step_graph:
         # graph capture is set-up, not a step: make sure the timed region only replays
         for extra in range(4):
             if getattr(experiment, '_captured_iteration', None) is not None and experiment._captured_iteration.replays:
@@ -572,8 +572,11 @@ def main():
                 for module in (experiment.D, experiment.DNN, experiment.G)]
     torch.cuda.synchronize()
     start = time.perf_counter()
+    host_seconds = 0.0                      # what the host spends enqueueing (eager: the Python tape; replay: one graph launch)
     for step in range(args.steps):
+        enqueue_start = time.perf_counter()
         one_step(experiment, labeled, unlabeled, args.warmup + step)
+        host_seconds += time.perf_counter() - enqueue_start
         if step % RESTORE_PERIOD == RESTORE_PERIOD - 1 and step + 1 < args.steps:
             experiment.join_dnn_stream()
             for live, saved in snapshot:
@@ -635,6 +638,7 @@ def main():
                                        'step) so that RCCL\'s communication stream has the fourth hardware queue to itself')
     result['config']['launch'] = (f'HIP graph replay ({captured.replays} replayed, {captured.eager_iterations} eager iterations)'
                                   if captured is not None else 'eager (Python tape enqueues every kernel)')
+    result['config']['host_ms_per_step'] = round(1e3 * host_seconds / args.steps, 3)
     result['config']['schedule_check'] = check if check is not None else 'not applicable: the timed region ran on one stream, eagerly'
     if dp is not None:
         import torch.distributed as dist

@@ -1,11 +1,14 @@
-"""Which host call sites issue large torch copies (hipMemcpyAsync -> __amd_rocclr_copyBuffer) during one training iteration?
-Wraps Tensor.copy_ / clone / contiguous / to and prints the call stack of every call that moves >= 1M elements."""
-import argparse
+"""Which host call sites run torch (aten) operations on large tensors during one training iteration?  The library's own
+launches do not go through aten; what shows here is torch arithmetic / copies left on the hot path (the three image-sized
+__amd_rocclr_copyBuffer launches per iteration in the kernel trace).  A TorchDispatchMode logs every aten op whose largest
+tensor argument has >= 1M elements, with the Python stack."""
 import os
 import sys
 import traceback
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+from torch.utils._pytree import tree_flatten
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,22 +27,22 @@ torch.cuda.synchronize()
 seen = {}
 
 
-def wrap(name):
-    original = getattr(torch.Tensor, name)
-
-    def wrapper(self, *a, **k):
-        if self.numel() >= (1 << 20) and self.is_cuda:
-            stack = ''.join(traceback.format_stack(limit=7)[:-1])
-            key = (name, stack)
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        flat, _ = tree_flatten((args, kwargs or {}))
+        largest = max([t.numel() for t in flat if isinstance(t, torch.Tensor)] or [0])
+        name = str(func)
+        if largest >= (1 << 20) and not any(k in name for k in ('aten.view', 'aten.detach', 'aten.slice', 'aten.select', 'aten.alias',
+                                                                   'aten._unsafe_view', 'aten.as_strided', 'aten.expand', 'aten.t.')):
+            stack = ''.join(traceback.format_stack(limit=9)[:-1])
+            key = (name, largest, stack)
             seen[key] = seen.get(key, 0) + 1
-        return original(self, *a, **k)
-    setattr(torch.Tensor, name, wrapper)
+        return func(*args, **(kwargs or {}))
 
 
-for name in ('copy_', 'clone', 'contiguous', 'to', 'zero_', 'fill_'):
-    wrap(name)
-bench.one_step(experiment, labeled, unlabeled, 1)
-experiment.join_dnn_stream()
+with Log():
+    bench.one_step(experiment, labeled, unlabeled, 1)
+    experiment.join_dnn_stream()
 torch.cuda.synchronize()
-for (name, stack), count in sorted(seen.items(), key=lambda kv: -kv[1]):
-    print(f'==== {name} x {count}\n{stack}')
+for (name, largest, stack), count in sorted(seen.items(), key=lambda kv: -kv[0][1]):
+    print(f'==== {name} x {count}, largest tensor {largest} elements\n{stack}')

@@ -20,7 +20,12 @@ together on replay instead of in the order Python reaches them.
 
 Iterations whose host-side behaviour differs run eagerly: summary steps (they read losses back), and a graph is keyed
 by everything the captured launches baked in (input shapes, whether the generator trains this step, learning rates).
-Data-parallel runs stay eager (their gradient exchange is driven from the tape).
+Data-parallel runs (round 5): the exchanges are captured too when they are launches on streams this process owns -- the C
+ABI's RCCL entry points on the communicator's stream (``parallel.AbiCommunicator``; forked into the capture by the event
+wait in front of a collective, joined by the ``wait()`` of its work object) -- so that eight Python ranks on a 16-CPU
+quota replay instead of enqueueing ~4000 launches each; every captured iteration ends with ALL pending optimizer updates
+applied (the generator's exchange, which the eager loop hides under the next iteration's DNN step, completes inside the
+graph).  Over gloo (host collectives) a data-parallel run stays eager.
 """
 import torch
 
@@ -153,6 +158,9 @@ class CapturedIteration:
             with torch.cuda.graph(graph, pool=pool):
                 e.dnn_training_step(static_inputs[0], static_inputs[1], step)
                 e.gan_training_step(static_inputs[0], static_inputs[1], static_inputs[2], step)
+                # data parallel: a replay is a closed unit -- the generator's gradient exchange and update, which the
+                # eager loop finishes when G is next used (under the next iteration's DNN step), end inside the graph
+                e.finish_update()
             advanced = [optimizer.step_count - count for optimizer, count in zip(optimizers, before)]
         finally:
             e.injected_draws = injected

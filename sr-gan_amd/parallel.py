@@ -225,8 +225,9 @@ class AbiCommunicator:
         self.calls += 1
         self.stream.wait_stream(torch.cuda.current_stream())
         launch(self.stream.cuda_stream)
-        for tensor in tensors:
-            tensor.record_stream(self.stream)
+        if not torch.cuda.is_current_stream_capturing():      # (a capture's pool is not recycled before the graph is done)
+            for tensor in tensors:
+                tensor.record_stream(self.stream)
         event = torch.cuda.Event()
         event.record(self.stream)
         return _StreamWork(event)

@@ -251,14 +251,24 @@ class Experiment(ABC):
         """The body of the reference's loop (srgan.py:104-118): the DNN step, then the GAN step.  With
         ``settings.step_graph`` on a single device the iteration is captured once as a HIP graph and replayed
         (``graph.CapturedIteration``); summary steps and the first ``settings.step_graph_warmup`` iterations run eagerly."""
-        if getattr(self.settings, 'step_graph', False) and examples_on_gpu() and \
-                not self.parallel:
+        if getattr(self.settings, 'step_graph', False) and examples_on_gpu() and self._exchanges_are_capturable():
             if getattr(self, '_captured_iteration', None) is None:
                 from .graph import CapturedIteration
                 self._captured_iteration = CapturedIteration(self)
             return self._captured_iteration.run(labeled_examples, labels, unlabeled_examples, step)
         self.dnn_training_step(labeled_examples, labels, step)
         self.gan_training_step(labeled_examples, labels, unlabeled_examples, step)
+
+    def _exchanges_are_capturable(self):
+        """A HIP graph can hold the data-parallel exchanges only as launches on streams this process owns: the C ABI's RCCL
+        entry points on the communicator's stream (``DataParallel.use_abi_collectives``; round 5).  Collectives that go
+        through a host-side process group (gloo, or torch's own NCCL work queue) keep the run eager."""
+        if not self.parallel:
+            return True
+        if getattr(self.dp, 'abi', None) is None and torch.distributed.get_backend(self.dp.group) == 'nccl' and \
+                getattr(self.settings, 'step_graph_collectives', 'abi') == 'abi':
+            self.dp.use_abi_collectives()
+        return getattr(self.dp, 'abi', None) is not None
 
     def prepare_optimizers(self):
         """Adam for D (with coupled L2), G and DNN (reference srgan.py:131-138) on the flat arenas."""

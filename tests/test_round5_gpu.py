@@ -176,3 +176,86 @@ def test_driving_fp32_step_at_batch_128_matches_the_oracle(pkg):
                          size=size, batch=128, d_scale=2.2)
     import conftest
     conftest.PARITY_NOTES.append('config 5 (driving, DCGAN @ 64 x 192) fp32 step at batch 128 checked against the CPU oracle')
+
+
+def _graph_under_dp_worker(port, queue, streams):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.set_device(0)
+    import srgan_amd  # noqa: F401
+    from srgan_amd.parallel import DataParallel
+    from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
+    from srgan_amd.utility import seed_all
+    from test_steps_gpu import make_experiment, finish_setup, crowd_inputs
+    dp = DataParallel.from_environment('nccl', force=True)
+    size, batch, iterations = 64, 2, 5
+
+    def run(step_graph):
+        experiment = make_experiment(
+            lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
+            dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2, gradient_penalty_multiplier=1e2,
+                 map_multiplier=1e-3, step_graph=step_graph, step_graph_warmup=1, steps_to_run=10 ** 9,
+                 overlap_dnn_step=streams, overlap_gradient_penalty=streams), crowd=True)
+        experiment.dp = dp
+        with torch.no_grad():
+            for module in experiment.D.modules():
+                if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                    module.weight.mul_(1.27)
+        finish_setup(experiment)
+        for writer in (experiment.dnn_summary_writer, experiment.gan_summary_writer):
+            writer.summary_period, writer.steps_to_run = 10 ** 9, 10 ** 9
+        seed_all(5)
+        generator = torch.Generator().manual_seed(11)
+        losses = []
+        for step in range(1, iterations + 1):
+            x, labels, u = crowd_inputs(generator, batch, size)
+            experiment.training_iteration(x.cuda(), tuple(t.cuda() for t in labels), u.cuda(), step)
+            losses.append({name: float(value.item()) for name, value in experiment.last_losses.items() if value is not None})
+        experiment.finish_update()
+        experiment.join_dnn_stream()
+        torch.cuda.synchronize()
+        captured = getattr(experiment, '_captured_iteration', None)
+        return losses, {name: getattr(experiment, name)._srgan_arena.data.cpu().numpy() for name in ('D', 'DNN', 'G')}, \
+            (captured.replays, captured.eager_iterations) if captured is not None else None
+
+    eager = run(False)
+    calls_before = dp.abi.calls if dp.abi is not None else 0
+    replayed = run(True)
+    queue.put((eager, replayed, dp.abi is not None, (dp.abi.calls if dp.abi is not None else 0) - calls_before))
+    dp.barrier()
+    if dp.abi is not None:
+        dp.abi.close()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('streams', [False, True])
+def test_graph_replay_under_data_parallelism_over_rccl(streams):
+    """`settings.step_graph` with the data-parallel exchanges on (nccl = RCCL, world size 1, forced): the iteration -- feature-sum
+    all-reduces, asynchronous gradient buckets, their waits, the three optimizer updates -- is captured ONCE as a HIP graph
+    with the collectives as launches of the C ABI's RCCL entry points on the communicator's stream, and four replays leave
+    the losses and weights of the eager data-parallel run."""
+    import multiprocessing as mp
+    import test_parallel_gpu as parallel_tests
+    context = mp.get_context('spawn')
+    queue = context.Queue()
+    worker = context.Process(target=_graph_under_dp_worker, args=(parallel_tests._free_port(), queue, streams))
+    worker.start()
+    (eager_losses, eager_weights, eager_captured), (losses, weights, captured), abi, calls_during_replays = queue.get(timeout=900)
+    worker.join(timeout=120)
+    assert worker.exitcode == 0
+    assert eager_captured is None and captured == (4, 1), captured            # one eager warm-up iteration, four replays
+    assert abi and calls_during_replays > 0                                   # (collectives issued while capturing + the eager one)
+    for step, (a, b) in enumerate(zip(eager_losses, losses)):
+        rtol = 5e-3 if step <= 1 else 0.2                                     # (cf. test_step_graph_gpu: Adam amplifies rounding)
+        for name in a:
+            assert np.isclose(a[name], b[name], rtol=rtol, atol=1e-6), f'step {step} {name}: {a[name]} vs {b[name]}'
+    assert losses[-1]['gradient_penalty'] > 0.0 and losses[-1] != losses[-2]
+    for name in ('D', 'DNN', 'G'):
+        difference = np.abs(eager_weights[name] - weights[name])
+        assert float(difference.max()) <= 2.2e-4 * 5 and float(difference.mean()) <= 0.5e-4, name
+    import conftest
+    conftest.PARITY_NOTES.append(f'HIP-graph replay of the data-parallel iteration (RCCL through the C ABI, world size 1, forced; side '
+                                 f'streams {"on" if streams else "off"}): 4 replays equal the eager run')
