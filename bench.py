@@ -212,7 +212,12 @@ def one_step(experiment, labeled, unlabeled, step, eager=False):
 
 
 STREAM_SETTINGS = ('overlap_dnn_step', 'wgrad_stream', 'overlap_generator_forwards', 'overlap_gradient_penalty')
-SCHEDULE_CHECK_LIMIT = 1e-4
+# Round 5: on a stream with a workspace every K split finishes in a fixed order (csrc/split_finish.h), so the five losses an
+# iteration computes before the discriminator's update are the same bits on any schedule and the sixth differs by the
+# rounding of the parameter-gradient sums (still fp32 atomics): 1e-7 measured -- the limit is 1e-5.  With the round-4
+# atomics (SRGAN_ATOMIC_SPLIT=1) a ReLU mask may flip between two runs of ONE schedule: 1e-4 there.
+SCHEDULE_CHECK_LIMIT = 1e-5
+SCHEDULE_CHECK_LIMIT_ATOMIC_SPLIT = 1e-4
 
 
 def schedule_check(experiment, labeled, unlabeled, step):
@@ -266,6 +271,8 @@ def schedule_check(experiment, labeled, unlabeled, step):
     finally:
         for name, value in flags.items():
             setattr(experiment.settings, name, value)
+    from srgan_amd import _lib
+    ordered = bool(_lib.library().srgan_split_is_ordered(_lib.stream_handle()))
     worst = difference(timed_losses, single_losses)
     single_floor = difference(again_losses, single_losses)
     timed_floor = difference(timed_again, timed_losses)
@@ -284,7 +291,8 @@ def schedule_check(experiment, labeled, unlabeled, step):
     # defect the check exists to catch.
     return {'max_relative_loss_difference': worst, 'max_weight_difference': weight_difference,
             'single_stream_twice': single_floor, 'timed_schedule_twice': timed_floor,
-            'limit': max(SCHEDULE_CHECK_LIMIT, 4.0 * single_floor),
+            'limit': max(SCHEDULE_CHECK_LIMIT if ordered else SCHEDULE_CHECK_LIMIT_ATOMIC_SPLIT, 4.0 * single_floor),
+            'split_k_finish': 'fixed order through the workspace (no atomics on data)' if ordered else 'fp32 atomics',
             'what': 'one iteration on the timed schedule vs the same iteration on ONE stream (eager), from the same weights, '
                     'Adam state, batch and draws, after the timed region; *_twice = a schedule against its own repetition',
             'losses_timed_schedule': timed_losses, 'losses_single_stream': single_losses}

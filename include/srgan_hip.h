@@ -69,6 +69,12 @@ int srgan_capabilities(srgan_capabilities_t* out, int32_t out_bytes);
  * NULL unregisters.  Launches on one stream are ordered, so one block per stream is enough. */
 int64_t srgan_workspace_bytes(void);
 int srgan_set_workspace(void* workspace, int64_t bytes, void* stream);
+/* Round 5: a contraction that splits K over several workgroups (few output tiles: the small planes) finishes in a FIXED
+ * order on a stream that has a workspace: every slice leaves its partial tile there, the tile's last workgroup adds the
+ * slices in slice order and stores -- one launch, no zero-filled output, bit-identical from run to run (the reference's CPU
+ * path is repeatable; fp32 atomics are not).  Returns 1 when launches on `stream` do so, 0 when they fall back to fp32
+ * atomics into a zero-filled output (no workspace registered, or SRGAN_ATOMIC_SPLIT=1). */
+int srgan_split_is_ordered(void* stream);
 
 /* ---- convolution ------------------------------------------------------------------------------------------
  * Geometry of y = conv2d(x, w): x [N,C,H,W], w [K,C,R,S], y [N,K,OH,OW].  Batch strides (elements) allow a

@@ -14,6 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+THRESHOLD = 1 << 20
+if '--threshold' in sys.argv:
+    at = sys.argv.index('--threshold')
+    THRESHOLD = int(sys.argv[at + 1])
+    del sys.argv[at:at + 2]
 sys.argv = ['bench.py', '--no-cpu-baseline', '--no-roofline'] + sys.argv[1:]
 args = bench.parse()
 bench.ensure_library()
@@ -32,9 +37,9 @@ class Log(TorchDispatchMode):
         flat, _ = tree_flatten((args, kwargs or {}))
         largest = max([t.numel() for t in flat if isinstance(t, torch.Tensor)] or [0])
         name = str(func)
-        if largest >= (1 << 20) and not any(k in name for k in ('aten.view', 'aten.detach', 'aten.slice', 'aten.select', 'aten.alias',
+        if largest >= THRESHOLD and not any(k in name for k in ('aten.view', 'aten.detach', 'aten.slice', 'aten.select', 'aten.alias',
                                                                    'aten._unsafe_view', 'aten.as_strided', 'aten.expand', 'aten.t.')):
-            stack = ''.join(traceback.format_stack(limit=9)[:-1])
+            stack = ''.join(traceback.format_stack(limit=9)[:-1]) if THRESHOLD else ' < '.join(f'{os.path.basename(f.filename)}:{f.lineno}' for f in reversed(traceback.extract_stack(limit=7)[:-1]))
             key = (name, largest, stack)
             seen[key] = seen.get(key, 0) + 1
         return func(*args, **(kwargs or {}))
@@ -44,5 +49,5 @@ with Log():
     bench.one_step(experiment, labeled, unlabeled, 1)
     experiment.join_dnn_stream()
 torch.cuda.synchronize()
-for (name, largest, stack), count in sorted(seen.items(), key=lambda kv: -kv[0][1]):
+for (name, largest, stack), count in sorted(seen.items(), key=lambda kv: (-kv[1], -kv[0][1])):
     print(f'==== {name} x {count}, largest tensor {largest} elements\n{stack}')

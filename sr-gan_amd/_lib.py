@@ -96,6 +96,7 @@ SIGNATURES = {
     'srgan_capabilities': ([ctypes.POINTER(Capabilities), i32], ctypes.c_int),
     'srgan_workspace_bytes': ([], ctypes.c_int64),
     'srgan_set_workspace': ([vp, i64, vp], ctypes.c_int),
+    'srgan_split_is_ordered': ([vp], ctypes.c_int),
     'srgan_crowd_density_label': ([vp, i32, i32, i32, f32, vp, i32, vp, vp, vp], ctypes.c_int),
     'srgan_crowd_iknn_map': ([vp, i32, i32, i32, i32, f32, f32, vp, vp], ctypes.c_int),
     'srgan_crowd_extract_patches': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),

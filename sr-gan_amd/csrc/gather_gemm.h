@@ -99,7 +99,11 @@ inline Dec3 dec_3d(int32_t count_c, int32_t A, int32_t B, int32_t off_c, int32_t
   return d;
 }
 
-enum StoreMode { GG_STORE = 0, GG_ACCUMULATE = 1, GG_ATOMIC = 2, GG_PARTIAL = 3 };
+// GG_ORDERED_*: a K split whose slices meet in a fixed order inside the launch (split_finish.h): partial tiles through
+// `partial`, one ticket per output tile in `tickets`, the tile's last workgroup stores / accumulates the total.
+enum StoreMode { GG_STORE = 0, GG_ACCUMULATE = 1, GG_ATOMIC = 2, GG_PARTIAL = 3, GG_ORDERED_STORE = 4, GG_ORDERED_ACCUMULATE = 5 };
+// How the K slices of a split launch are combined (GatherGemm::use_partial, chosen by gg_prepare)
+enum SplitCombine { GG_COMBINE_ATOMIC = 0, GG_COMBINE_PARTIAL_TINY = 1, GG_COMBINE_PARTIAL_WIDE = 2, GG_COMBINE_ORDERED = 3 };
 
 struct GatherGemm {
   const float* A; Dec3 am, ak;
@@ -112,8 +116,9 @@ struct GatherGemm {
   int32_t mode;                                          // StoreMode
   int32_t split_k, k_per_split;                          // filled by the launcher
   int32_t debug;                                         // tuning experiments (SRGAN_GG_DEBUG): 1 no re-staging, 2 no MFMA
-  float* partial;                                        // GG_PARTIAL: K-slice z stores to partial[(z*M + i)*N + j]
-  int32_t use_partial;                                   // launcher: combine K-slices through a workspace, not atomics
+  float* partial;                                        // GG_PARTIAL: K-slice z stores to partial[(z*M + i)*N + j]; GG_ORDERED_*: [tile][slice][accumulators]
+  unsigned int* tickets;                                 // GG_ORDERED_*: one per output tile
+  int32_t use_partial;                                   // launcher: SplitCombine -- how the K slices are combined
   int64_t b_unique;                                      // distinct B elements the gather touches (0: K * N); bookkeeping
   int32_t precision;                                     // MFMA operand type: 0 fp32 (exact), 1 bf16, 2 fp16 (fp32 accumulate,
 };                                                       //   for the live profile only.  precision: fp32 data in HBM and LDS, rounded when the MFMA operands are formed

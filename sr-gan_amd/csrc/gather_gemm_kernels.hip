@@ -10,6 +10,7 @@
 // Roofline (MI355X_MICROARCH.md): fp32 MFMA 157.3 TF/s; the gather adds ~30 VALU ops per staged element,
 // which overlaps with the 64-cycle MFMAs of the other waves on the SIMD.
 #include "common.h"
+#include "split_finish.h"
 #include "gather_gemm.h"
 #include "conv_plan.h"
 #include <stdarg.h>
@@ -281,7 +282,17 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
   }
 
   // Epilogue: C/D fragment of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+  int mode = p.mode;
+  if (mode >= GG_ORDERED_STORE) {     // K split, ordered finish: the tile's last workgroup goes on with the sum of all slices
+    constexpr int COUNT = MI * NI * 16;
+    if (!split_finish_ordered<COUNT, 256>(p.partial + (int64_t)blockIdx.x * gridDim.y * (COUNT * 256), (int)blockIdx.y,
+                                          (int)gridDim.y, p.tickets + blockIdx.x,
+                                          [&](int i) { return acc[i / (NI * 16)][(i / 16) % NI][i % 16]; },
+                                          [&](int i, float v) { acc[i / (NI * 16)][(i / 16) % NI][i % 16] = v; }))
+      return;
+    mode -= GG_ORDERED_STORE;
+  }
+  const bool add_bias = p.bias != nullptr && (blockIdx.y == 0 || p.mode >= GG_ORDERED_STORE);
   Side sn[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) sn[ni] = decode(p.cn, n0 + wn0 + ni * 32 + l31);
@@ -298,13 +309,13 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
         if (!sn[ni].valid) continue;
         float v = acc[mi][ni][r] + row_bias;
         if (add_bias && p.bias_cols) v += p.bias[sn[ni].c];
-        if (p.mode == GG_PARTIAL) {
+        if (mode == GG_PARTIAL) {
           p.partial[((int64_t)blockIdx.y * p.M + i) * p.N + (n0 + wn0 + ni * 32 + l31)] = v;
           continue;
         }
         float* dst = p.C + (uint32_t)(sm.off + sn[ni].off);
-        if (p.mode == GG_STORE) *dst = v;
-        else if (p.mode == GG_ACCUMULATE) *dst += v;
+        if (mode == GG_STORE) *dst = v;
+        else if (mode == GG_ACCUMULATE) *dst += v;
         else unsafeAtomicAdd(dst, v);
       }
     }
@@ -327,6 +338,10 @@ __global__ __launch_bounds__(256) void gg_direct_kernel(const GatherGemm p) {
     acc = fmaf(gg_a(p, am, ak), gg_b(p, bk, bn), acc);
   }
   if (p.bias != nullptr && blockIdx.z == 0) acc += p.bias[p.bias_cols ? cn.c : cm.c];
+  if (p.mode == GG_PARTIAL) {
+    p.partial[((int64_t)blockIdx.z * p.M + i) * p.N + j] = acc;
+    return;
+  }
   float* dst = p.C + (uint32_t)(cm.off + cn.off);
   if (p.mode == GG_STORE) *dst = acc;
   else if (p.mode == GG_ACCUMULATE) *dst += acc;
@@ -394,6 +409,10 @@ __global__ __launch_bounds__(256) void gg_rows_kernel(const GatherGemm p) {
     if (!cm.valid) continue;
     float v = acc[i];
     if (add_bias) v += p.bias[p.bias_cols ? cn.c : cm.c];
+    if (p.mode == GG_PARTIAL) {
+      p.partial[((int64_t)blockIdx.y * p.M + i) * p.N + j] = v;
+      continue;
+    }
     float* dst = p.C + (uint32_t)(cm.off + cn.off);
     if (p.mode == GG_STORE) *dst = v;
     else if (p.mode == GG_ACCUMULATE) *dst += v;
@@ -459,7 +478,8 @@ __global__ __launch_bounds__(256) void gg_dot_kernel(const GatherGemm p) {
         float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         if (p.bias != nullptr && blockIdx.x == 0) v += p.bias[p.bias_cols ? cn.c : cm.c];
         float* dst = p.C + (uint32_t)(cm.off + cn.off);
-        if (gridDim.x > 1) unsafeAtomicAdd(dst, v);
+        if (p.mode == GG_PARTIAL) p.partial[((int64_t)blockIdx.x * p.M + i) * p.N + j] = v;
+        else if (gridDim.x > 1) unsafeAtomicAdd(dst, v);
         else if (p.mode == GG_ACCUMULATE) *dst += v;
         else *dst = v;
       }
@@ -502,13 +522,37 @@ __global__ __launch_bounds__(256) void gg_reduce_partials_kernel(const GatherGem
   *dst = p.mode == GG_ACCUMULATE ? *dst + total : total;
 }
 
+// The same second stage for outputs of any size (weight gradients of the strided / transposed convolutions: up to a few
+// hundred thousand outputs x up to a few hundred slices): one thread per output, consecutive threads on consecutive
+// outputs (coalesced over every slice), the slices added in slice order -- four loads in flight, one fixed order.
+__global__ __launch_bounds__(256) void gg_reduce_partials_wide_kernel(const GatherGemm p, const float* __restrict__ ws) {
+  const int64_t mn = (int64_t)p.M * p.N;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= mn) return;
+  float total = ws[idx];
+  int z = 1;
+  for (; z + 3 < p.split_k; z += 4) {
+    const float a = ws[(int64_t)z * mn + idx], b = ws[(int64_t)(z + 1) * mn + idx];
+    const float c = ws[(int64_t)(z + 2) * mn + idx], d = ws[(int64_t)(z + 3) * mn + idx];
+    total = (((total + a) + b) + c) + d;
+  }
+  for (; z < p.split_k; ++z) total += ws[(int64_t)z * mn + idx];
+  const int i = (int)(idx / p.N), j = (int)(idx - (int64_t)i * p.N);
+  const Side sm = decode(p.cm, i), sn = decode(p.cn, j);
+  if (!sm.valid || !sn.valid) return;
+  float* dst = p.C + (uint32_t)(sm.off + sn.off);
+  *dst = p.mode == GG_ACCUMULATE ? *dst + total : total;
+}
+
+__device__ unsigned int g_gg_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_TILES];
+
 // Partial sums that a second small kernel combines go through a workspace the CALLER owns (srgan_set_workspace: one
 // block per (device, stream), at least srgan_workspace_bytes() long; launches on one stream are ordered, so reuse is
 // safe): the K-slices of split-K launches with a tiny output (M*N < 512 outputs x at most 1024 slices x 4 B = 2 MiB) and
 // the per-workgroup batch-norm parameter sums of the fused data-gradient epilogues (2 x column blocks x channels x 4 B =
 // at most 1/32 of the gradient tensor's bytes: 64 MiB covers tensors of up to 2^29 elements; larger ones report "unsupported"
 // from srgan_conv2d_bnrelu_supported and take the two-kernel form).  The library never allocates device memory.
-constexpr size_t WORKSPACE_BYTES = (size_t)64 << 20;
+constexpr size_t WORKSPACE_BYTES = (size_t)128 << 20;     // (round 5: 128 MiB -- the ordered / partial finish of every K split lives here)
 struct WorkspaceSlot { float* ptr = nullptr; size_t bytes = 0; int index = -1; };
 static std::mutex g_workspace_mutex;
 static std::map<std::pair<int, hipStream_t>, WorkspaceSlot> g_workspaces;
@@ -662,24 +706,51 @@ static void launch_mfma(const GatherGemm& p, dim3 grid, hipStream_t stream) {
 
 // Plans one launch: fills split_k / k_per_split; returns whether the launch needs a zeroed (or live) C because
 // it combines K-slices with atomics.
-bool gg_prepare(GatherGemm& p, int force, GGConfig* out) {
+// The launch's accumulators per workgroup for the ordered finish (see gg_mfma_kernel: MI x NI fragments of 16 per lane).
+static int64_t mfma_tile_floats(const GGConfig& c) { return (int64_t)c.bm * c.bn; }
+
+// Plans one launch: fills split_k / k_per_split and how its K slices are combined (p.use_partial, a SplitCombine); returns
+// whether the launch needs a zeroed (or live) C because it combines them with fp32 atomics -- only when the stream has
+// no workspace (or SRGAN_ATOMIC_SPLIT=1): otherwise the slices meet in a fixed order, through the workspace.
+bool gg_prepare(GatherGemm& p, int force, GGConfig* out, hipStream_t stream) {
   static const int debug = getenv("SRGAN_GG_DEBUG") ? atoi(getenv("SRGAN_GG_DEBUG")) : 0;
   p.debug = debug;
+  p.tickets = nullptr;
   GGConfig c = choose_config(p, force);
-  if (c.kind == 9) {                       // workgroups of 256 k-lanes, ~16 k per thread, combined with atomics
+  if (c.kind == 9) {                       // workgroups of 256 k-lanes, ~16 k per thread
     int groups = (p.K + 4095) / 4096;
     if (groups > 1024) groups = 1024;
-    p.split_k = groups; p.k_per_split = p.K; p.use_partial = 0;
-    if (out) *out = c;
-    return p.split_k > 1;
+    p.split_k = groups; p.k_per_split = p.K;
+  } else {
+    choose_split(p, c, true);
   }
-  choose_split(p, c, true);
   if (out) *out = c;
+  p.use_partial = GG_COMBINE_ATOMIC;
+  if (p.split_k <= 1) return false;
   static const bool no_partial = getenv("SRGAN_NO_PARTIAL") != nullptr;
+  const int64_t mn = (int64_t)p.M * p.N;
+  const bool fits = (size_t)mn * p.split_k * sizeof(float) <= WORKSPACE_BYTES;
   // (up to 4096 outputs: at 960 outputs x 1024 slices the atomics still serialised -- 310 us for 36 MB of operands)
-  p.use_partial = !no_partial && c.kind == 1 && p.split_k >= 16 && (int64_t)p.M * p.N <= 4096 &&
-                  (size_t)p.M * p.N * p.split_k * sizeof(float) <= WORKSPACE_BYTES;
-  return p.split_k > 1 && !p.use_partial;
+  if (!no_partial && c.kind == 1 && p.split_k >= 16 && mn <= 4096 && fits) {
+    p.use_partial = GG_COMBINE_PARTIAL_TINY;
+    return false;
+  }
+  const bool have_workspace = !split_atomics_forced() && partial_workspace(1, stream) != nullptr;
+  if (have_workspace) {
+    // few slices of an MFMA launch: the tile's last workgroup adds them (one launch); many slices, or the VALU kernels:
+    // partial outputs + a second kernel that adds the slices of every output in slice order
+    int set = -1;
+    if (c.kind == 1 && p.split_k <= 16 &&
+        split_workspace(c.tiles, p.split_k, mfma_tile_floats(c), 0, stream, &set) != nullptr) {
+      p.use_partial = GG_COMBINE_ORDERED;
+      return false;
+    }
+    if (fits) {
+      p.use_partial = (c.kind == 1 && mn <= 4096) ? GG_COMBINE_PARTIAL_TINY : GG_COMBINE_PARTIAL_WIDE;
+      return false;
+    }
+  }
+  return true;
 }
 
 // ---- optional live timing of every contraction launch with HIP events on the launch stream -------------------
@@ -752,7 +823,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
                 int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
                 const BnBackwardEpilogue* epilogue = nullptr, int precision = 0, const struct Conv3Placement* placement = nullptr);
-struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off; };
+struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off, in_h, in_w; };
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 int64_t conv3x3_epilogue_tiles(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 int64_t pointwise_epilogue_tiles(int32_t N, int32_t HW);
@@ -871,6 +942,34 @@ int gg_launch(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
 
 static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return SRGAN_OK;
+  if (p.split_k > 1 && (p.use_partial == GG_COMBINE_PARTIAL_TINY || p.use_partial == GG_COMBINE_PARTIAL_WIDE)) {
+    // every slice stores its partial output to the workspace, a second kernel adds the slices in slice order
+    SRGAN_REQUIRE(p.mode == GG_STORE || p.mode == GG_ACCUMULATE, SRGAN_EINVAL, "partial-sum launch mode");
+    const int64_t mn = (int64_t)p.M * p.N;
+    float* ws = partial_workspace((size_t)mn * p.split_k * sizeof(float), stream);
+    SRGAN_REQUIRE(ws != nullptr, SRGAN_EINVAL,
+                  "split-K workspace: call srgan_set_workspace(ptr, >= srgan_workspace_bytes(), stream) for this stream first");
+    GatherGemm q = p;
+    q.mode = GG_PARTIAL; q.partial = ws; q.use_partial = GG_COMBINE_ATOMIC;
+    const int status = gg_launch_unprofiled(q, c, stream);
+    if (status != SRGAN_OK) return status;
+    if (p.use_partial == GG_COMBINE_PARTIAL_TINY)
+      hipLaunchKernelGGL(gg_reduce_partials_kernel, dim3((unsigned)((mn + 15) / 16)), dim3(256), 0, stream, p, ws);
+    else
+      hipLaunchKernelGGL(gg_reduce_partials_wide_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, p, ws);
+    return launch_status();
+  }
+  if (p.split_k > 1 && p.use_partial == GG_COMBINE_ORDERED) {
+    SRGAN_REQUIRE(c.kind == 1 && (p.mode == GG_STORE || p.mode == GG_ACCUMULATE), SRGAN_EINVAL, "ordered split launch mode");
+    int set = -1;
+    float* ws = split_workspace(c.tiles, p.split_k, mfma_tile_floats(c), 0, stream, &set);
+    unsigned int* tickets = ws ? device_tickets(g_gg_split_tickets) : nullptr;
+    SRGAN_REQUIRE(ws != nullptr && tickets != nullptr, SRGAN_EINVAL, "ordered split-K: the stream's workspace went away");
+    GatherGemm q = p;
+    q.mode = p.mode == GG_ACCUMULATE ? GG_ORDERED_ACCUMULATE : GG_ORDERED_STORE;
+    q.partial = ws; q.tickets = tickets + (size_t)set * SPLIT_TICKET_TILES; q.use_partial = GG_COMBINE_ATOMIC;
+    return gg_launch_unprofiled(q, c, stream);
+  }
   if (c.kind == 0) {
     dim3 grid((p.N + 255) / 256, p.M, p.split_k);
     SRGAN_REQUIRE(p.M <= 65535 && p.split_k <= 65535, SRGAN_ERANGE, "direct gather-gemm grid");
@@ -888,19 +987,6 @@ static int gg_launch_unprofiled(const GatherGemm& p, const GGConfig& c, hipStrea
     else hipLaunchKernelGGL(gg_rows_kernel<8>, grid, dim3(256), 0, stream, p);
     return launch_status();
   }
-  if (p.use_partial && p.split_k > 1) {
-    SRGAN_REQUIRE(p.mode == GG_STORE || p.mode == GG_ACCUMULATE, SRGAN_EINVAL, "partial-sum launch mode");
-    const int64_t mn = (int64_t)p.M * p.N;
-    float* ws = partial_workspace((size_t)mn * p.split_k * sizeof(float), stream);
-    SRGAN_REQUIRE(ws != nullptr, SRGAN_EINVAL,
-                  "split-K workspace: call srgan_set_workspace(ptr, >= srgan_workspace_bytes(), stream) for this stream first");
-    GatherGemm q = p;
-    q.mode = GG_PARTIAL; q.partial = ws; q.use_partial = 0;
-    const int status = gg_launch_unprofiled(q, c, stream);
-    if (status != SRGAN_OK) return status;
-    hipLaunchKernelGGL(gg_reduce_partials_kernel, dim3((unsigned)((mn + 15) / 16)), dim3(256), 0, stream, p, ws);
-    return launch_status();
-  }
   if (c.bm == 128 && c.bn == 128) launch_mfma<128, 128, 2>(p, grid, stream);
   else if (c.bm == 128 && c.bn == 64) launch_mfma<128, 64, 2>(p, grid, stream);
   else if (c.bm == 64 && c.bn == 128) launch_mfma<64, 128, 2>(p, grid, stream);
@@ -916,11 +1002,11 @@ int gg_run_group(std::vector<GatherGemm>& plans, float* c_base, int64_t c_elems,
                  hipStream_t stream) {
   std::vector<GGConfig> configs(plans.size());
   bool any_atomic = false;
-  for (size_t i = 0; i < plans.size(); ++i) any_atomic |= gg_prepare(plans[i], force, &configs[i]);
+  for (size_t i = 0; i < plans.size(); ++i) any_atomic |= gg_prepare(plans[i], force, &configs[i], stream);
   if (any_atomic && !accumulate) if (const int status = zero_floats(c_base, c_elems, stream)) return status;
   for (size_t i = 0; i < plans.size(); ++i) {
     GatherGemm& p = plans[i];
-    if (p.split_k > 1 && !p.use_partial) p.mode = GG_ATOMIC;
+    if (p.split_k > 1 && p.use_partial == GG_COMBINE_ATOMIC) p.mode = GG_ATOMIC;
     else p.mode = accumulate ? GG_ACCUMULATE : GG_STORE;
     const int status = gg_launch(p, configs[i], stream);
     if (status != SRGAN_OK) return status;
@@ -934,6 +1020,8 @@ int gg_run_group(std::vector<GatherGemm>& plans, float* c_base, int64_t c_elems,
 using namespace srgan;
 
 extern "C" {
+
+int srgan_split_is_ordered(void* stream);
 
 struct srgan_conv_desc {
   int32_t N, C, H, W, K, R, S, stride_h, stride_w, pad_h, pad_w, OH, OW;
@@ -987,6 +1075,20 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   if (force_kernel == 0 && dtype == 0 && bias == nullptr && stem7x7_enabled() &&
       stem7x7_geometry(g.C, g.K, g.R, g.S, g.sh, g.sw, g.ph, g.pw))
     return stem7x7_fwd_run(x, g.x_bs, w, y, g.y_bs, g.N, g.H, g.W, g.K, g.OH, g.OW, (hipStream_t)stream);
+  // k4 / s2 / p1 (the DCGAN discriminators' convolutions, reference age/models.py:61-65; the data gradient of the generators'
+  // transposed convolutions, crowd/models.py:132-136): out[o, y, x] = the 2 x 2 window over the space-to-depth view of the
+  // input -- four pixel parities per channel, read in place by the patch staging of the LDS-halo kernel -- instead of a
+  // gathered GEMM with an address decode per element (round 4: 87 TF/s in fp16, 48.9 TF/s in fp32).
+  static const bool no_k4s2_fwd = getenv("SRGAN_NO_K4S2") != nullptr || getenv("SRGAN_NO_K4S2_FWD") != nullptr;
+  if (force_kernel == 0 && !no_k4s2_fwd && conv3x3_enabled() && g.R == 4 && g.S == 4 && g.sh == 2 && g.sw == 2 && g.ph == 1 &&
+      g.pw == 1 && g.H == 2 * g.OH && g.W == 2 * g.OW && g.OW >= 8 && g.K >= 16) {
+    Conv3Placement placement;
+    placement.taps = 0x1B0;
+    placement.out_plane = g.OH * g.OW; placement.out_sy = g.OW; placement.out_sx = 1; placement.out_off = 0;
+    placement.in_h = g.H; placement.in_w = g.W;
+    return conv3x3_run(x, g.x_bs, w, 0, g.C * 16, 16, 4, 1, bias, y, g.y_bs, g.N, 4 * g.C, g.K, g.OH, g.OW, 0,
+                       (hipStream_t)stream, nullptr, nullptr, dtype, &placement);
+  }
   std::vector<GatherGemm> plans{plan_conv_fwd(g, x, w, bias, y)};
   plans[0].precision = dtype;
   // A strided-batch output view (a channel slice of a wider buffer) is zeroed with a 2-D memset when the launch
@@ -994,7 +1096,7 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   const bool dense_out = g.y_bs == (int64_t)g.K * g.OH * g.OW;
   if (!dense_out) {
     GGConfig c;
-    const bool atomic = gg_prepare(plans[0], force_kernel, &c);
+    const bool atomic = gg_prepare(plans[0], force_kernel, &c, (hipStream_t)stream);
     if (atomic) {
       if (const int status = zero_rows(y, g.y_bs, (int64_t)g.K * g.OH * g.OW, g.N, (hipStream_t)stream)) return status;
       plans[0].mode = GG_ATOMIC;
@@ -1029,11 +1131,13 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
   if (force_kernel == 0 && !no_k4s2 && conv3x3_enabled() && g.R == 4 && g.S == 4 && g.sh == 2 && g.sw == 2 && g.ph == 1 &&
       g.pw == 1 && g.H == 2 * g.OH && g.W == 2 * g.OW && g.OW >= 8 && (g.C >= 8 || dtype) && !accumulate) {   // (mixed: also the 3-channel image gradient)
     // small problems split the input channels over the grid and add with atomics: the output is zeroed once for all classes
-    const bool split = conv3x3_splits(g.N, g.K, g.C, g.OH, g.OW, dtype) > 1;
+    // (only when the split adds with atomics: with a workspace the slices meet in a fixed order and the sums are stored)
+    const bool split = conv3x3_splits(g.N, g.K, g.C, g.OH, g.OW, dtype) > 1 && !srgan_split_is_ordered(stream);
     if (split) if (const int status = zero_floats(gx, (int64_t)g.N * g.x_bs, (hipStream_t)stream)) return status;
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) {
         Conv3Placement placement;
+        placement.in_h = placement.in_w = 0;
         placement.taps = (0x01B << (3 * a)) << b;
         placement.out_plane = g.H * g.W; placement.out_sy = 2 * g.W; placement.out_sx = 2; placement.out_off = a * g.W + b;
         const int status = conv3x3_run(gy, g.y_bs, w, (3 + a) * 4 + (3 + b), 16, g.C * 16, -8, -2, bias, gx, g.x_bs, g.N, g.K,
@@ -1333,6 +1437,14 @@ int srgan_set_workspace(void* workspace, int64_t bytes, void* stream) {
                 "srgan_set_workspace: at least srgan_workspace_bytes() bytes");
   SRGAN_REQUIRE(((uintptr_t)workspace & 15) == 0, SRGAN_EINVAL, "srgan_set_workspace: 16-byte alignment");
   return workspace_register((float*)workspace, (size_t)(bytes > 0 ? bytes : 0), (hipStream_t)stream);
+}
+
+// 1 when a K split on this stream is finished in a fixed order through the registered workspace (split_finish.h): such a
+// launch stores whole sums -- no zero-filled output needed, the same bits every run; 0: fp32 atomics into a zeroed output.
+int srgan_split_is_ordered(void* stream) {
+  if (split_atomics_forced()) return 0;
+  const int set = workspace_index((hipStream_t)stream);
+  return set >= 0 && set < SPLIT_TICKET_SETS ? 1 : 0;
 }
 
 struct srgan_capabilities_t {

@@ -19,6 +19,7 @@
 //     half-wave); in a data gradient the batch-norm + ReLU backward of the layer in front is applied on the way (EPI).
 // Roofline: fp32 MFMA 157.3 TF/s, or HBM when CI is small; algorithmic bytes 4 * (CI + CO) per pixel.
 #include "common.h"
+#include "split_finish.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -39,7 +40,9 @@ struct PointwiseParams {
   int32_t xcd_remap;    // grid.x is a multiple of 8 and tiles_m > 1: XCD-aware workgroup order
   int32_t m_base;       // first output row of this launch (a second launch covers a shorter remainder tile)
   int32_t k_per_split;
-  int32_t mode;         // 0 store, 1 accumulate, 2 atomic
+  int32_t mode;         // 0 store, 1 accumulate, 2 atomic; K split with the ordered finish (split_finish.h): 3 store, 4 accumulate
+  float* split_ws;      // modes 3 / 4: [tiles][splits][accumulators of a workgroup] partials in the caller's workspace
+  unsigned int* split_tickets;
   int32_t wide_out;     // out rows / batch stride 16-byte aligned: modes 0 and 1 store float4 rows through LDS
   // PRO: the input is relu(batch_norm_eval(in)) computed on the fly (per input channel; NULL otherwise)
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
@@ -50,6 +53,8 @@ struct PointwiseParams {
   float* epi_partial; int32_t epi_cols;
   int32_t epi_ragged;   // epi_x / out rows are not whole aligned float4s: the RAGROW variant
 };
+
+__device__ unsigned int g_pointwise_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_TILES];
 
 // PRO = frozen batch-norm + ReLU fused into the B-operand stream (reference crowd/models.py:338-341: norm1, relu1,
 // conv1): the per-channel (a, b) of the slice are staged in LDS next to the weight tile and every activation goes
@@ -309,7 +314,16 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     else emit(std::true_type{});
     return;
   }
-  if (STAGED && p.wide_out && p.mode != 2) {
+  int mode = p.mode;
+  if (mode >= 3) {       // K split, ordered finish (split_finish.h): the tile's last workgroup goes on with the sum of all slices
+    constexpr int COUNT = MI * NI * 16;
+    if (!split_finish_ordered<COUNT, 256>(p.split_ws + (int64_t)bid * gridDim.y * (COUNT * 256), (int)blockIdx.y, (int)gridDim.y,
+                                          p.split_tickets + bid, [&](int i) { return acc[i / (NI * 16)][(i / 16) % NI][i % 16]; },
+                                          [&](int i, float v) { acc[i / (NI * 16)][(i / 16) % NI][i % 16] = v; }))
+      return;
+    mode -= 3;
+  }
+  if (STAGED && p.wide_out && mode != 2) {
     // Store / accumulate through LDS as float4 rows (see the EPI epilogue: 512 contiguous bytes per access, a quarter
     // of the instructions); rows and batch strides are 16-byte aligned (checked by the launcher).
     __syncthreads();
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     float* out_lane = p.out + (int64_t)my_n * p.out_bs + my_start;
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f olds[RPT];
-    if (p.mode == 1) {
+    if (mode == 1) {
 #pragma unroll
       for (int e = 0; e < RPT; ++e)
         olds[e] = *reinterpret_cast<const v4f*>(out_lane + (int64_t)min(m0 + half + 8 * e, p.CO - 1) * p.HW);
@@ -342,13 +356,13 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
       v4f v = *reinterpret_cast<const v4f*>(tile + row * LDT + q4);
       if (p.bias) v += p.bias[o];
       v4f* dst = reinterpret_cast<v4f*>(out_lane + (int64_t)o * p.HW);
-      if (p.mode == 1) *dst = olds[e] + v;
+      if (mode == 1) *dst = olds[e] + v;
       else __builtin_nontemporal_store(v, dst);                    // consumed by a later kernel
     }
     return;
   }
   if (!live) return;
-  const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+  const bool add_bias = p.bias != nullptr && (blockIdx.y == 0 || p.mode >= 3);
   float* out_lane = p.out + (int64_t)n * p.out_bs + pix;
   // Three straight-line passes selected once (store / accumulate / atomic): with the mode tested per element the
   // 16 * MI stores of a lane are separated by branches and cannot be issued back to back.
@@ -374,8 +388,8 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
     }
   };
   auto emit_mode = [&](auto check_lane) {
-    if (p.mode == 0) emit([](float* dst, float v) { __builtin_nontemporal_store(v, dst); }, check_lane);   // consumed by a later kernel
-    else if (p.mode == 1) emit([](float* dst, float v) { *dst += v; }, check_lane);
+    if (mode == 0) emit([](float* dst, float v) { __builtin_nontemporal_store(v, dst); }, check_lane);   // consumed by a later kernel
+    else if (mode == 1) emit([](float* dst, float v) { *dst += v; }, check_lane);
     else emit([](float* dst, float v) { unsafeAtomicAdd(dst, v); }, check_lane);
   };
   if (ragged) emit_mode(std::true_type{});
@@ -605,10 +619,22 @@ int pointwise_run(const float* in, int64_t in_bs, const float* w, int32_t w_so, 
     *plan_only_split = split;
     return SRGAN_OK;
   }
+  p.split_ws = nullptr; p.split_tickets = nullptr;
   if (split > 1) {
-    if (accumulate == 0)
-      if (const int status = zero_rows(out, out_bs, (int64_t)CO * HW, N, stream)) return status;
-    p.mode = 2;
+    // Ordered finish (split_finish.h): partial tiles through the workspace, summed in slice order by the tile's last
+    // workgroup -- one launch, no zero-fill, the same bits every run.  Without a workspace: zero-fill + fp32 atomics.
+    int ticket_set = -1;
+    float* ws = split_workspace(blocks, split, (int64_t)mi * ni * 16 * 256, 0, stream, &ticket_set);
+    unsigned int* tickets = ws ? device_tickets(g_pointwise_split_tickets) : nullptr;
+    if (ws && tickets) {
+      p.mode = accumulate == 1 ? 4 : 3;
+      p.split_ws = ws;
+      p.split_tickets = tickets + (size_t)ticket_set * SPLIT_TICKET_TILES;
+    } else {
+      if (accumulate == 0)
+        if (const int status = zero_rows(out, out_bs, (int64_t)CO * HW, N, stream)) return status;
+      p.mode = 2;
+    }
   } else {
     p.mode = accumulate == 1 ? 1 : 0;
   }

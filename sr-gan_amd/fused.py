@@ -297,8 +297,10 @@ def dense_block(x, layers):
     b1_all = None
     if prologue:
         last_cin = c0 + (len(layers) - 1) * growth
-        zero_b1 = lib.srgan_conv2d_fwd_bnrelu_splits(_desc(n, last_cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0)) > 1
-        zero_new = lib.srgan_conv2d_fwd_bnrelu_splits(probe2) > 1
+        # (round 5: on a stream with a workspace a K split finishes in a fixed order and STORES whole sums -- no zero-fill)
+        atomics = not lib.srgan_split_is_ordered(stream)
+        zero_b1 = atomics and lib.srgan_conv2d_fwd_bnrelu_splits(_desc(n, last_cin, h, w, width, 1, 1, 1, 0, buffer_bs, 0)) > 1
+        zero_new = atomics and lib.srgan_conv2d_fwd_bnrelu_splits(probe2) > 1
         if zero_new:
             F._call('srgan_fill', buffer.data_ptr(), buffer.numel(), 0.0, stream)
         if zero_b1:

@@ -109,6 +109,15 @@ CONV_CASES = [
     (4, 3, 96, 96, 16, 7, 7, (2, 2), (3, 3)),        # stem: the 3-row image gradient takes the few-rows kernel
     (2, 5, 72, 72, 7, 3, 3, (1, 1), (1, 1)),         # 5 and 7 rows (MR = 8) in the few-rows kernel
     (8, 2, 256, 128, 3, 2, 2, (2, 2), (0, 0)),       # weight gradient 3 x 8 over K = 65536 pixels: lanes-along-K kernel
+    # k4 / s2 / p1 FORWARD on the LDS-halo kernel over the space-to-depth view of the input (round 5; reference
+    # age/models.py:61-65 on 64 x 192 driving frames and 128 x 128 faces, crowd/models.py:132-136 backwards): three input
+    # channels (12 virtual ones: a partial chunk), 16- and 32-wide tiles, ragged tiles, 32- / 64- / 128-row tiles, a K split
+    (3, 3, 64, 192, 64, 4, 4, (2, 2), (1, 1)),
+    (2, 64, 32, 96, 128, 4, 4, (2, 2), (1, 1)),
+    (2, 128, 16, 48, 256, 4, 4, (2, 2), (1, 1)),
+    (2, 256, 16, 24, 512, 4, 4, (2, 2), (1, 1)),
+    (5, 20, 36, 44, 24, 4, 4, (2, 2), (1, 1)),
+    (1, 64, 128, 128, 32, 4, 4, (2, 2), (1, 1)),
     # the LDS-DMA 1x1 kernel (pointwise_ring.hip; whole 128-row tiles, >= 192 workgroups): 128- and 64-pixel tiles, weights
     # k-contiguous (forward) and m-contiguous (data gradient), several row tiles, remainder rows of 32 / 96 on the old kernel
     (16, 128, 64, 64, 128, 1, 1, (1, 1), (0, 0)),

@@ -243,7 +243,17 @@ def test_graph_replay_under_data_parallelism_over_rccl(streams):
     queue = context.Queue()
     worker = context.Process(target=_graph_under_dp_worker, args=(parallel_tests._free_port(), queue, streams))
     worker.start()
-    (eager_losses, eager_weights, eager_captured), (losses, weights, captured), abi, calls_during_replays = queue.get(timeout=900)
+    import queue as queue_module
+    import time
+    deadline = time.monotonic() + 600
+    while True:                       # (a worker that died must not hold the suite for the whole time limit)
+        try:
+            result = queue.get(timeout=5)
+            break
+        except queue_module.Empty:
+            assert worker.is_alive() or not queue.empty(), f'the rank died (exit code {worker.exitcode})'
+            assert time.monotonic() < deadline, 'the rank is still running after ten minutes'
+    (eager_losses, eager_weights, eager_captured), (losses, weights, captured), abi, calls_during_replays = result
     worker.join(timeout=120)
     assert worker.exitcode == 0
     assert eager_captured is None and captured == (4, 1), captured            # one eager warm-up iteration, four replays
@@ -259,3 +269,72 @@ def test_graph_replay_under_data_parallelism_over_rccl(streams):
     import conftest
     conftest.PARITY_NOTES.append(f'HIP-graph replay of the data-parallel iteration (RCCL through the C ABI, world size 1, forced; side '
                                  f'streams {"on" if streams else "off"}): 4 replays equal the eager run')
+
+
+SPLIT_CASES = [
+    # what, x shape, weight shape, stride, padding      (every one splits K over several workgroups at these sizes)
+    ('3x3 growth convolution on small planes (conv3x3_lds_kernel, ordered finish)', (2, 128, 32, 32), (32, 128, 3, 3), 1, 1),
+    ('3x3 on 16 x 16 planes', (4, 128, 16, 16), (32, 128, 3, 3), 1, 1),
+    ('1x1 bottleneck on ragged 14 x 14 planes (pointwise_kernel, ordered finish)', (4, 512, 14, 14), (128, 512, 1, 1), 1, 0),
+    ('1x1 on 7 x 7 planes', (4, 896, 7, 7), (128, 896, 1, 1), 1, 0),
+    ('k4 / s2 / p1 strided convolution (gg_mfma_kernel, ordered finish)', (2, 64, 16, 16), (128, 64, 4, 4), 2, 1),
+    ('7x7 / s2 / p3 on a small image (generic kernel)', (1, 8, 30, 30), (16, 8, 7, 7), 2, 3),
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES, ids=[c[0].split(' (')[0] for c in SPLIT_CASES])
+def test_split_k_contractions_finish_in_a_fixed_order(pkg, case):
+    """A contraction that splits K over several workgroups (split_finish.h; reference: every nn.Conv2d / ConvTranspose2d call
+    of the small planes, e.g. crowd/models.py:344-345) gives the SAME BITS on every run -- with NaN in the workspace in front of
+    every launch and a copy loop hammering HBM on a second stream -- for the forward pass, the data gradient and the weight
+    gradient, and the values are torch's.  (Round 4: fp32 atomics in arrival order; two runs differed at rounding level.)"""
+    from srgan_amd import functional as F, _lib
+    what, x_shape, w_shape, stride, padding = case
+    assert _lib.library().srgan_split_is_ordered(_lib.stream_handle()) == 1
+    generator = torch.Generator().manual_seed(17)
+    x = torch.randn(x_shape, generator=generator)
+    w = torch.randn(w_shape, generator=generator) / (w_shape[1] * w_shape[2] * w_shape[3]) ** 0.5
+    y_ref = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, padding)
+    gy = torch.randn(y_ref.shape, generator=generator)
+    gx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), stride, padding)
+    gw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), stride, padding)
+    xv, wv, gv = F.leaf(x.cuda()), F.leaf(w.cuda()), F.leaf(gy.cuda())
+    handle = _lib.stream_handle()
+    workspace = _lib._workspaces[(torch.cuda.current_device(), handle)]
+    source = torch.empty(1 << 27, dtype=torch.float32, device='cuda').normal_()
+    sink = torch.empty_like(source)
+    side = torch.cuda.Stream()
+    runs = []
+    for iteration in range(12):
+        if iteration % 4 == 0:
+            with torch.cuda.stream(side):
+                sink.copy_(source)
+        outputs = []
+        for launch in (lambda: F.conv2d(xv, wv, None, stride, padding),
+                       lambda: F.conv2d_backward_data(gv, wv, x.shape, stride, padding),
+                       lambda: F.conv2d_backward_weight(xv, gv, w.shape, stride, padding)):
+            workspace.fill_(float('nan'))
+            outputs.append(launch().data.clone())
+        runs.append(outputs)
+    torch.cuda.synchronize()
+    for got, want, name in zip(runs[0], (y_ref, gx_ref, gw_ref), ('forward', 'data gradient', 'weight gradient')):
+        scale = float(want.abs().max())
+        assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * scale, f'{what}: {name}'
+    for iteration, outputs in enumerate(runs[1:], 1):
+        for got, first, name in zip(outputs[:2], runs[0][:2], ('forward', 'data gradient')):
+            assert torch.equal(got, first), f'{what}: {name} of run {iteration} differs from run 0'
+
+
+def test_losses_of_one_iteration_are_repeatable_across_schedules(pkg):
+    """The five losses an iteration computes BEFORE the discriminator's update (DNN, labeled, unlabeled, fake, gradient
+    penalty: functions of the weights, the batch and the draws through forward passes and data gradients only) are now the
+    same bits whether the chains run on one stream or on four -- round 4 saw the penalty move by up to 6e-4 between two runs
+    because split-K atomics in arrival order flipped ReLU masks (crowd 64 x 64, batch 2: every plane K-split)."""
+    import test_parallel_gpu as parallel_tests
+    first, _ = parallel_tests._step(None)
+    again, _ = parallel_tests._step(None)
+    streamed, _ = parallel_tests._step(None, streams=True)
+    for key in ('dnn_loss', 'labeled_loss', 'unlabeled_loss', 'fake_loss', 'gradient_penalty'):
+        assert first[key] == again[key], (key, first[key], again[key])
+        assert first[key] == streamed[key], (key, 'one stream vs four', first[key], streamed[key])
+    assert first['gradient_penalty'] > 0.0
