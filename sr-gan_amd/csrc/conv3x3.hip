@@ -49,13 +49,6 @@ struct Conv3Params {
   // other pixel of a 2H x 2W plane) and `taps` is the 9-bit mask of the window positions (kh * 3 + kw) that exist.
   int32_t out_plane, out_sy, out_sx, out_off;
   int32_t taps;
-  // S2D (k4 / s2 / p1 strided convolutions, reference age/models.py:61-65, crowd/models.py:132-136 backwards): the kernel
-  // walks the OUTPUT grid H x W = OH x OW and its input channels are VIRTUAL -- v = 4 c + 2 a + b is pixel parity (a, b) of
-  // real channel c: x'[v, i, j] = x[c, 2 i + a - 1, 2 j + b - 1] (space to depth, never materialised: the patch staging
-  // reads the real tensor of in_h x in_w pixels with these addresses) -- so that out[o, y, x] = sum over v and the 2 x 2
-  // window p, q in {0, 1} of w[o, c, 2 p + a, 2 q + b] * x'[v, y + p, x + q]: the taps (kh, kw) = (p + 1, q + 1) of the
-  // LDS-halo kernel (mask 0x1B0), CI = 4 x the real channel count.
-  int32_t in_h, in_w;
   // XCD-aware order: hardware workgroup b runs on XCD b % 8, so logical tile = (b % 8) * (grid / 8) + b / 8 gives every
   // XCD one contiguous band of tiles -- neighbouring tiles (which share halo rows / columns and the 128-byte lines of a
   // 32-pixel tile row) then read them through ONE L2 instead of two (round 2 PMC: 1.9x the algorithmic bytes).
@@ -67,7 +60,7 @@ constexpr int CONV3_PRO_MAX_CI = 512;
 __device__ unsigned int g_conv3_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_TILES];
 
 // A stride-2 class of a k4 / s2 / p1 transposed convolution as a 2x2 sub-window of the 3x3 kernel (see conv3x3_run).
-struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off, in_h, in_w; };   // (in_h > 0: space-to-depth input, Conv3Params::in_h)   // channels of one workgroup's K range whose (a, b) fit the LDS table
+struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off; };   // channels of one workgroup's K range whose (a, b) fit the LDS table
 
 // PRO = frozen batch-norm + ReLU fused into the patch staging (reference crowd/models.py:342-345: norm2, relu2,
 // conv2): the (a, b) of the workgroup's input channels sit in a small LDS table and every patch element goes through
@@ -79,11 +72,10 @@ struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off, in_h, 
 // two parameter-gradient row sums (store mode only, no split over input channels).
 // TAPS: compile-time mask of the window positions the inner loop multiplies (0x1FF = the full 3x3 window; the four
 // stride-2 classes of a k4 / s2 / p1 transposed convolution are 2x2 sub-windows: 0x01B, 0x036, 0x0D8, 0x1B0).
-template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false, int TAPS = 0x1FF, bool S2D = false>
+template <int BM, int TH, int CI_T, bool PRO, int TW, bool EPI = false, int TAPS = 0x1FF>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p) {
   static_assert(!EPI || !PRO, "the batch-norm backward epilogue pairs with the plain kernel");
   static_assert(TAPS == 0x1FF || (!EPI && !PRO), "tap subsets pair with the plain kernel");
-  static_assert(!S2D || (TAPS == 0x1B0 && CI_T % 4 == 0), "space-to-depth input: the 2 x 2 window of a k4 / s2 / p1 convolution");
   constexpr int RPB = 32 / TW;                    // image rows per 32-lane column block
   constexpr int ROWS = TH * RPB;                  // image rows of the workgroup's tile
   constexpr int PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
@@ -108,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
   const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
   const int cbeg = (int)blockIdx.y * p.ci_per_split;
   const int cend = min(p.CI, cbeg + p.ci_per_split);
-  const int HW = S2D ? p.in_h * p.in_w : p.H * p.W;      // the input plane
+  const int HW = p.H * p.W;
 
   // Per-thread staging offsets (relative to the chunk's first channel), computed once.
   int poff[NP], woff[NW];
@@ -117,16 +109,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     const int flat = e * 256 + tid;
     const int c = flat / PHPW, rem = flat - c * PHPW;
     const int py = rem / PW, px = rem - py * PW;
-    int y = y0 - 1 + py, x = x0 - 1 + px;
-    if (S2D) {                                 // virtual channel c = 4 c' + 2 a + b of the chunk: parity (a, b) of real channel c'
-      y = 2 * y + ((c >> 1) & 1) - 1;
-      x = 2 * x + (c & 1) - 1;
-      const bool ok = flat < PATCH && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
-      poff[e] = ok ? (c >> 2) * HW + y * p.in_w + x : -1;
-    } else {
-      const bool ok = flat < PATCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      poff[e] = ok ? c * HW + y * p.W + x : -1;
-    }
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool ok = flat < PATCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    poff[e] = ok ? c * HW + y * p.W + x : -1;
   }
 #pragma unroll
   for (int e = 0; e < NW; ++e) {
@@ -135,14 +120,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     const int ci = r / 9, tap = r - ci * 9;
     const int kh = tap / 3, kw = tap - kh * 3;
     const bool ok = flat < WTS && (m0 + o) < p.CO && ((p.taps >> tap) & 1);     // (a missing tap stages zeros)
-    if (S2D)      // window position (kh - 1, kw - 1) of parity (a, b) = tap (2 (kh - 1) + a, 2 (kw - 1) + b) of the 4 x 4 kernel
-      woff[e] = ok ? p.w_base + (m0 + o) * p.w_so + (ci >> 2) * p.w_si + (2 * (kh - 1) + ((ci >> 1) & 1)) * p.w_skh +
-                         (2 * (kw - 1) + (ci & 1)) * p.w_skw : -1;
-    else
-      woff[e] = ok ? p.w_base + (m0 + o) * p.w_so + ci * p.w_si + kh * p.w_skh + kw * p.w_skw : -1;
+    woff[e] = ok ? p.w_base + (m0 + o) * p.w_so + ci * p.w_si + kh * p.w_skh + kw * p.w_skw : -1;
   }
   const float* in_n = p.in + (int64_t)n * p.in_bs;
-  constexpr int CSHIFT = S2D ? 2 : 0;            // virtual -> real channel of a chunk's first channel (chunks are multiples of 4)
 
   // Raw loads only in fetch(); validity is applied when the registers are written to LDS (any use of a loaded value
   // before the MFMA loop would make the compiler wait for the loads there instead of overlapping them).
@@ -153,14 +133,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     for (int e = 0; e < NP; ++e) {
       const int flat = e * 256 + tid;
       const bool ok = poff[e] >= 0 && flat / PHPW < room;
-      rp[e] = in_n[(int64_t)(c0 >> CSHIFT) * HW + (ok ? poff[e] : 0)];
+      rp[e] = in_n[(int64_t)c0 * HW + (ok ? poff[e] : 0)];
     }
 #pragma unroll
     for (int e = 0; e < NW; ++e) {
       const int flat = e * 256 + tid;
       const int ci = (flat % (CI_T * 9)) / 9;
       const bool ok = woff[e] >= 0 && ci < room;
-      rw[e] = p.w[ok ? woff[e] + (c0 >> CSHIFT) * p.w_si : 0];
+      rw[e] = p.w[ok ? woff[e] + c0 * p.w_si : 0];
     }
   };
   auto stage = [&](int c0) {
@@ -378,7 +358,7 @@ __device__ __forceinline__ Half8 pack8(const float (&x)[8]) {
 // tap `tap` of output channel o, rounded to the operand type (zero beyond CI).  One thread per slot: the gather over the
 // strided fp32 weight tensor happens ONCE per convolution call here (a few microseconds) instead of in every workgroup of
 // the convolution, whose weight staging then is a handful of coalesced 16-byte loads per chunk.
-template <int PREC, bool S2D = false>
+template <int PREC>
 __global__ __launch_bounds__(256) void conv3x3_pack_weights_kernel(const Conv3Params p, Half8* __restrict__ packed, int slots) {
   const int slot = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (slot >= slots) return;
@@ -390,19 +370,13 @@ __global__ __launch_bounds__(256) void conv3x3_pack_weights_kernel(const Conv3Pa
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = chunk * 16 + g * 8 + j;
-    const bool ok = c < p.CI && ((p.taps >> tap) & 1);
-    if (S2D)      // virtual channel c = parity (a, b) of real channel c >> 2; window position (kh - 1, kw - 1): see Conv3Params::in_h
-      v[j] = ok ? p.w[p.w_base + o * p.w_so + (c >> 2) * p.w_si + (2 * (kh - 1) + ((c >> 1) & 1)) * p.w_skh +
-                      (2 * (kw - 1) + (c & 1)) * p.w_skw] : 0.f;
-    else
-      v[j] = ok ? p.w[p.w_base + o * p.w_so + c * p.w_si + kh * p.w_skh + kw * p.w_skw] : 0.f;
+    v[j] = (c < p.CI && ((p.taps >> tap) & 1)) ? p.w[p.w_base + o * p.w_so + c * p.w_si + kh * p.w_skh + kw * p.w_skw] : 0.f;
   }
   packed[slot] = pack8<PREC>(v);
 }
 
-template <int BM, int TH, int TW, int PREC, int TAPS = 0x1FF, bool S2D = false>
+template <int BM, int TH, int TW, int PREC, int TAPS = 0x1FF>
 __global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params p) {
-  static_assert(!S2D || TAPS == 0x1B0, "space-to-depth input: the 2 x 2 window of a k4 / s2 / p1 convolution");
   constexpr int RPB = 32 / TW, ROWS = TH * RPB, PH = ROWS + 2, PW = TW + 2, PHPW = PH * PW;
   constexpr int MI = BM / 32, NI = TH / 4;
   constexpr int PATCH_Q = 2 * PHPW, WT_Q = 9 * 2 * BM, STAGE_Q = PATCH_Q + WT_Q;       // in 16-byte slots
@@ -421,31 +395,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params
   const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
   const int cbeg = (int)blockIdx.y * p.ci_per_split;
   const int cend = min(p.CI, cbeg + p.ci_per_split);
-  const int HW = S2D ? p.in_h * p.in_w : p.H * p.W;      // the input plane
+  const int HW = p.H * p.W;
 
   // staging slots of this thread: patch (group, pixel) and weight (tap, group, output channel)
   int poff[NP], pgrp[NP], woff[NW];
-  int pvalid[NP];                              // S2D: which of the four pixel parities (a, b) of the slot exist (bit 2 a + b)
 #pragma unroll
   for (int e = 0; e < NP; ++e) {
     const int flat = e * 256 + tid;
     const int g = flat / PHPW, pix = flat - g * PHPW;
     const int py = pix / PW, px = pix - py * PW;
     const int y = y0 - 1 + py, x = x0 - 1 + px;
-    if (S2D) {        // the slot's 8 virtual channels = 2 real channels x parities (a, b): real pixel (2 y + a - 1, 2 x + b - 1)
-      const int ry = 2 * y - 1, rx = 2 * x - 1;
-      int valid = 0;
-#pragma unroll
-      for (int ab = 0; ab < 4; ++ab)
-        if (flat < PATCH_Q && (unsigned)(ry + (ab >> 1)) < (unsigned)p.in_h && (unsigned)(rx + (ab & 1)) < (unsigned)p.in_w)
-          valid |= 1 << ab;
-      pvalid[e] = valid;
-      poff[e] = ry * p.in_w + rx;                // (may be negative: only ever used with a valid parity's offset added)
-    } else {
-      const bool ok = flat < PATCH_Q && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      poff[e] = ok ? y * p.W + x : -1;
-      pvalid[e] = 0;
-    }
+    const bool ok = flat < PATCH_Q && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    poff[e] = ok ? y * p.W + x : -1;
     pgrp[e] = g;
   }
 #pragma unroll
@@ -466,13 +427,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = c0 + 8 * pgrp[e] + j;
-        if (S2D) {       // (c0 and 8 g are multiples of 4: parity = j & 3, real channel = c >> 2)
-          const bool ok = ((pvalid[e] >> (j & 3)) & 1) && c < cend;
-          rp[e][j] = in_n[ok ? (int64_t)(c >> 2) * HW + poff[e] + ((j >> 1) & 1) * p.in_w + (j & 1) : 0];
-        } else {
-          const bool ok = poff[e] >= 0 && c < cend;
-          rp[e][j] = in_n[ok ? (int64_t)c * HW + poff[e] : 0];
-        }
+        const bool ok = poff[e] >= 0 && c < cend;
+        rp[e][j] = in_n[ok ? (int64_t)c * HW + poff[e] : 0];
       }
 #pragma unroll
     for (int e = 0; e < NW; ++e) rw[e] = packed[(int64_t)(c0 / 16) * (18 * p.CO) + (woff[e] >= 0 ? woff[e] : 0)];
@@ -483,10 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mixed_kernel(const Conv3Params
       const int flat = e * 256 + tid;
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool ok = (S2D ? ((pvalid[e] >> (j & 3)) & 1) != 0 : poff[e] >= 0) && c0 + 8 * pgrp[e] + j < cend;
-        v[j] = ok ? rp[e][j] : 0.f;
-      }
+      for (int j = 0; j < 8; ++j) v[j] = (poff[e] >= 0 && c0 + 8 * pgrp[e] + j < cend) ? rp[e][j] : 0.f;
       if (flat < PATCH_Q) stage_base[flat] = pack8<PREC>(v);
     }
 #pragma unroll
@@ -737,11 +690,6 @@ static void launch_conv3_w(const Conv3Params& p, int th, dim3 grid, hipStream_t 
   } else if (p.bn_mean) {
     if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, true, TW>), grid, dim3(256), 0, stream, p);
-  } else if (p.in_h > 0) {       // k4 / s2 / p1 forward: the 2 x 2 window over the space-to-depth view of the input
-    if constexpr (CI_T % 4 == 0) {
-      if (th == 8) hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 8, CI_T, false, TW, false, 0x1B0, true>), grid, dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((conv3x3_lds_kernel<BM, 4, CI_T, false, TW, false, 0x1B0, true>), grid, dim3(256), 0, stream, p);
-    }
   } else {
     switch (p.taps) {            // the full window, or one of the four 2x2 sub-windows of a stride-2 transposed convolution
       case 0x01B: launch_conv3_plain<BM, CI_T, TW, 0x01B>(p, th, grid, stream); break;
@@ -768,12 +716,6 @@ static void launch_conv3_mixed_taps(const Conv3Params& p, int th, int tw, dim3 g
 
 template <int BM, int PREC>
 static void launch_conv3_mixed_bm(const Conv3Params& p, int th, int tw, dim3 grid, hipStream_t stream) {
-  if (p.in_h > 0) {              // k4 / s2 / p1 forward over the space-to-depth view of the input
-    if (tw == 16) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 16, PREC, 0x1B0, true>), grid, dim3(256), 0, stream, p);
-    else if (th == 8) hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 8, 32, PREC, 0x1B0, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv3x3_mixed_kernel<BM, 4, 32, PREC, 0x1B0, true>), grid, dim3(256), 0, stream, p);
-    return;
-  }
   switch (p.taps) {
     case 0x01B: launch_conv3_mixed_taps<BM, PREC, 0x01B>(p, th, tw, grid, stream); break;
     case 0x036: launch_conv3_mixed_taps<BM, PREC, 0x036>(p, th, tw, grid, stream); break;
@@ -903,9 +845,6 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
   p.out_sy = placement ? placement->out_sy : W;
   p.out_sx = placement ? placement->out_sx : 1;
   p.out_off = placement ? placement->out_off : 0;
-  p.in_h = placement ? placement->in_h : 0;
-  p.in_w = placement ? placement->in_w : 0;
-  SRGAN_REQUIRE(p.in_h == 0 || (p.taps == 0x1B0 && p.in_w > 0 && CI % 4 == 0), SRGAN_EINVAL, "conv3x3 space-to-depth input");
   SRGAN_REQUIRE(placement == nullptr || (bn == nullptr && epilogue == nullptr), SRGAN_EUNSUPPORTED,
                 "conv3x3 tap subsets / strided output: plain kernel only");
   SRGAN_REQUIRE(precision == 0 || (bn == nullptr && epilogue == nullptr), SRGAN_EUNSUPPORTED,
@@ -971,11 +910,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
     Half8* packed = reinterpret_cast<Half8*>(partial_workspace((size_t)slots * sizeof(Half8), stream));
     SRGAN_REQUIRE(packed, SRGAN_EINVAL, "conv3x3 mixed precision: register a workspace for this stream first "
                   "(srgan_set_workspace, >= srgan_workspace_bytes(); the packed weights take 2 bytes per element)");
-    if (p.in_h > 0) {
-      if (precision == 1) hipLaunchKernelGGL((conv3x3_pack_weights_kernel<1, true>), dim3((slots + 255) / 256), dim3(256), 0, stream, p, packed, slots);
-      else hipLaunchKernelGGL((conv3x3_pack_weights_kernel<2, true>), dim3((slots + 255) / 256), dim3(256), 0, stream, p, packed, slots);
-    }
-    else if (precision == 1) hipLaunchKernelGGL(conv3x3_pack_weights_kernel<1>, dim3((slots + 255) / 256), dim3(256), 0, stream, p, packed, slots);
+    if (precision == 1) hipLaunchKernelGGL(conv3x3_pack_weights_kernel<1>, dim3((slots + 255) / 256), dim3(256), 0, stream, p, packed, slots);
     else hipLaunchKernelGGL(conv3x3_pack_weights_kernel<2>, dim3((slots + 255) / 256), dim3(256), 0, stream, p, packed, slots);
     p.w_packed = packed;
     if (plan.small && W == 4) launch_conv3_mixed_small<4>(p, bm, precision, grid, stream);

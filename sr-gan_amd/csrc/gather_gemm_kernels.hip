@@ -823,7 +823,7 @@ int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, 
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
                 int32_t W, int accumulate, hipStream_t stream, const float* const* bn = nullptr,
                 const BnBackwardEpilogue* epilogue = nullptr, int precision = 0, const struct Conv3Placement* placement = nullptr);
-struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off, in_h, in_w; };
+struct Conv3Placement { int32_t taps, out_plane, out_sy, out_sx, out_off; };
 bool conv3x3_epilogue_supported(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 int64_t conv3x3_epilogue_tiles(int32_t N, int32_t CI, int32_t CO, int32_t H, int32_t W);
 int64_t pointwise_epilogue_tiles(int32_t N, int32_t HW);
@@ -1075,20 +1075,6 @@ int srgan_conv2d_fwd(const srgan_conv_desc* desc, const float* x, const float* w
   if (force_kernel == 0 && dtype == 0 && bias == nullptr && stem7x7_enabled() &&
       stem7x7_geometry(g.C, g.K, g.R, g.S, g.sh, g.sw, g.ph, g.pw))
     return stem7x7_fwd_run(x, g.x_bs, w, y, g.y_bs, g.N, g.H, g.W, g.K, g.OH, g.OW, (hipStream_t)stream);
-  // k4 / s2 / p1 (the DCGAN discriminators' convolutions, reference age/models.py:61-65; the data gradient of the generators'
-  // transposed convolutions, crowd/models.py:132-136): out[o, y, x] = the 2 x 2 window over the space-to-depth view of the
-  // input -- four pixel parities per channel, read in place by the patch staging of the LDS-halo kernel -- instead of a
-  // gathered GEMM with an address decode per element (round 4: 87 TF/s in fp16, 48.9 TF/s in fp32).
-  static const bool no_k4s2_fwd = getenv("SRGAN_NO_K4S2") != nullptr || getenv("SRGAN_NO_K4S2_FWD") != nullptr;
-  if (force_kernel == 0 && !no_k4s2_fwd && conv3x3_enabled() && g.R == 4 && g.S == 4 && g.sh == 2 && g.sw == 2 && g.ph == 1 &&
-      g.pw == 1 && g.H == 2 * g.OH && g.W == 2 * g.OW && g.OW >= 8 && g.K >= 16) {
-    Conv3Placement placement;
-    placement.taps = 0x1B0;
-    placement.out_plane = g.OH * g.OW; placement.out_sy = g.OW; placement.out_sx = 1; placement.out_off = 0;
-    placement.in_h = g.H; placement.in_w = g.W;
-    return conv3x3_run(x, g.x_bs, w, 0, g.C * 16, 16, 4, 1, bias, y, g.y_bs, g.N, 4 * g.C, g.K, g.OH, g.OW, 0,
-                       (hipStream_t)stream, nullptr, nullptr, dtype, &placement);
-  }
   std::vector<GatherGemm> plans{plan_conv_fwd(g, x, w, bias, y)};
   plans[0].precision = dtype;
   // A strided-batch output view (a channel slice of a wider buffer) is zeroed with a 2-D memset when the launch
@@ -1137,7 +1123,6 @@ int srgan_conv2d_bwd_data(const srgan_conv_desc* desc, const float* gy, const fl
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) {
         Conv3Placement placement;
-        placement.in_h = placement.in_w = 0;
         placement.taps = (0x01B << (3 * a)) << b;
         placement.out_plane = g.H * g.W; placement.out_sy = 2 * g.W; placement.out_sx = 2; placement.out_off = a * g.W + b;
         const int status = conv3x3_run(gy, g.y_bs, w, (3 + a) * 4 + (3 + b), 16, g.C * 16, -8, -2, bias, gx, g.x_bs, g.N, g.K,

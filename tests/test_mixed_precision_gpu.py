@@ -42,7 +42,7 @@ CONVS = [  # (n, c, h, w, k, r, stride, pad): VGG 3x3 (32-, 16-, 8- and 4-wide p
     (19, 40, 4, 4, 72, 3, 1, 1), (5, 136, 8, 8, 24, 3, 1, 1), (32, 256, 4, 4, 128, 3, 1, 1), (9, 32, 8, 8, 200, 3, 1, 1),
     # three input channels: the data gradient has three output rows (the image gradient of the penalty chain)
     (3, 3, 24, 40, 48, 3, 1, 1), (2, 3, 32, 48, 64, 4, 2, 1),
-    # k4 / s2 / p1 forward over the space-to-depth view (round 5): the DCGAN discriminator's layers on driving frames
+    # k4 / s2 / p1 at the DCGAN discriminator's shapes on driving frames (round 5)
     (2, 64, 32, 96, 128, 4, 2, 1), (2, 128, 16, 48, 256, 4, 2, 1), (3, 20, 36, 44, 24, 4, 2, 1)]
 
 

@@ -109,9 +109,9 @@ CONV_CASES = [
     (4, 3, 96, 96, 16, 7, 7, (2, 2), (3, 3)),        # stem: the 3-row image gradient takes the few-rows kernel
     (2, 5, 72, 72, 7, 3, 3, (1, 1), (1, 1)),         # 5 and 7 rows (MR = 8) in the few-rows kernel
     (8, 2, 256, 128, 3, 2, 2, (2, 2), (0, 0)),       # weight gradient 3 x 8 over K = 65536 pixels: lanes-along-K kernel
-    # k4 / s2 / p1 FORWARD on the LDS-halo kernel over the space-to-depth view of the input (round 5; reference
-    # age/models.py:61-65 on 64 x 192 driving frames and 128 x 128 faces, crowd/models.py:132-136 backwards): three input
-    # channels (12 virtual ones: a partial chunk), 16- and 32-wide tiles, ragged tiles, 32- / 64- / 128-row tiles, a K split
+    # k4 / s2 / p1 at the DCGAN pair's own shapes (reference age/models.py:61-65 on 64 x 192 driving frames and 128 x 128
+    # faces, crowd/models.py:132-136 backwards): three input channels, rectangular and ragged planes, 24- to 512-row outputs,
+    # K splits with the ordered finish
     (3, 3, 64, 192, 64, 4, 4, (2, 2), (1, 1)),
     (2, 64, 32, 96, 128, 4, 4, (2, 2), (1, 1)),
     (2, 128, 16, 48, 256, 4, 4, (2, 2), (1, 1)),
