@@ -174,13 +174,18 @@ int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int3
  * together) lets the plan give each problem fewer workgroups of its own.  bn == NULL plans the plain weight gradient
  * (x used as is; srgan_wgrad_group_run with fused_bn = 0): the double backward's gradients w.r.t. the scaled weights.
  * gw == NULL: the gradient goes to gw_base + gw_offset of the launch (a per-step buffer) instead of a fixed address.  sum_co_ci_taps / pixels / operand_elements only feed
- * the profile (logical FLOPs = 2 * sum_co_ci_taps * pixels; elements of x and gy read once). */
+ * the profile (logical FLOPs = 2 * sum_co_ci_taps * pixels; elements of x and gy read once).
+ * Round 5, the ORDERED form: the K-slice workers of a problem no longer meet in gw through fp32 atomics -- each keeps its
+ * partial tile in the stream's workspace and a second launch adds them in slice order (bit-identical from run to run).  The
+ * caller lays the problems' partial regions out back to back: partial_offset = the sum of the *partial_floats the earlier
+ * problems of the group returned, and srgan_wgrad_group_run gets the group's total (0, a total beyond the workspace, or no
+ * workspace on the stream: fp32 atomics as before). */
 int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
-                           int64_t gw_offset, int32_t group_size, void* job, int32_t* grid_x, int32_t* grid_y,
-                           int32_t* ragged);
+                           int64_t gw_offset, int32_t group_size, int64_t partial_offset, void* job, int32_t* grid_x,
+                           int32_t* grid_y, int32_t* ragged, int64_t* partial_floats);
 int srgan_wgrad_group_run(const void* jobs, int32_t count, int32_t kernel_size, int32_t grid_x, int32_t grid_y, int32_t ragged,
                           int32_t fused_bn, const float* x_base, const float* gy_base, float* gw_base, int64_t sum_co_ci_taps,
-                          int64_t pixels, int64_t operand_elements, void* stream);
+                          int64_t pixels, int64_t operand_elements, int64_t partial_floats, void* stream);
 
 /* ---- strided GEMM  C[i*sci + j*scj] (=,+=) sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] + bias ----------------
  * C must be a dense M x N matrix (row- or column-major).  bias is indexed by row i, or by column j when

@@ -13,6 +13,7 @@
 // (raw loads from clamped addresses; the validity mask is applied when the registers are written to LDS -- a use of
 // the loaded value before the MFMA loop would make the compiler wait for the loads there).
 #include "common.h"
+#include "split_finish.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -29,6 +30,8 @@ struct Wgrad3Params {
   int32_t N, CI, CO, H, W;
   int32_t tiles_x, tiles_y, tiles;
   int32_t debug;                  // tuning experiments (SRGAN_WGRAD3_DEBUG): 1 skip the atomic pass
+  float* partial;                 // non-NULL (round 5): walker `w` of channel chunk `c` stores its 32 x 288 block at
+                                  // partial[(c * walkers + w) * 9216 ...]; conv3x3_wgrad_finish adds the walkers in order
   // x is relu(batch_norm_eval(x)) computed on the fly (per input channel) when bn_mean != NULL
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
@@ -316,6 +319,15 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const Wgrad3Params& p, const 
       for (int kw = 0; kw < 3; ++kw) smem[co * OUT_ROW + l31 * 9 + kh * 3 + kw] = acc[kw][r];
     }
     __syncthreads();
+    if (p.partial) {       // the ordered form: this walker's block, coalesced; a second kernel adds the walkers in order
+      float* mine = p.partial + ((int64_t)(co_chunk * ((p.CI + WG3_CI - 1) / WG3_CI) + ci_chunk) * tile_stride + first_tile) *
+                                    (WG3_CO * WG3_CI * 9) + half * (OUT_HALF * WG3_CI * 9);
+      for (int idx = tid; idx < OUT_HALF * WG3_CI * 9; idx += WG3_THREADS) {
+        const int co = idx / (WG3_CI * 9), within = idx - co * (WG3_CI * 9);
+        mine[idx] = smem[co * OUT_ROW + within];
+      }
+      continue;
+    }
     for (int idx = tid; idx < OUT_HALF * WG3_CI * 9; idx += WG3_THREADS) {
       const int co = idx / (WG3_CI * 9), within = idx - co * (WG3_CI * 9);
       const int row = co0 + OUT_HALF * half + co;
@@ -323,6 +335,35 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const Wgrad3Params& p, const 
         unsafeAtomicAdd(p.gw + ((int64_t)row * p.CI + ci0) * 9 + within, smem[co * OUT_ROW + within]);
     }
   }
+}
+
+// Second stage of the ordered form: gw[channel chunk] += its walkers' 32 x 288 blocks, added in walker order.  One thread per
+// element of the block (`slab` = which 256 of its 9216), the walkers' blocks read with lanes along the elements.
+__device__ __forceinline__ void conv3x3_wgrad_finish_chunk(const float* __restrict__ partial, float* __restrict__ gw, int chunk,
+                                                           int slab, int walkers, int ci_chunks, int CO, int CI) {
+  constexpr int BLOCK = WG3_CO * WG3_CI * 9;
+  const int co_chunk = chunk / ci_chunks, ci_chunk = chunk - co_chunk * ci_chunks;
+  const int co0 = co_chunk * WG3_CO, ci0 = ci_chunk * WG3_CI;
+  const int run = min(WG3_CI, CI - ci0) * 9;
+  const int idx = slab * 256 + (int)threadIdx.x;
+  const int co = idx / (WG3_CI * 9), within = idx - co * (WG3_CI * 9);
+  if (co0 + co >= CO || within >= run) return;
+  const float* mine = partial + (int64_t)chunk * walkers * BLOCK + idx;
+  float total = mine[0];
+  int w = 1;
+  for (; w + 3 < walkers; w += 4) {              // four loads in flight, one fixed order
+    const float a = mine[(int64_t)w * BLOCK], b = mine[(int64_t)(w + 1) * BLOCK];
+    const float c = mine[(int64_t)(w + 2) * BLOCK], d = mine[(int64_t)(w + 3) * BLOCK];
+    total = (((total + a) + b) + c) + d;
+  }
+  for (; w < walkers; ++w) total += mine[(int64_t)w * BLOCK];
+  gw[((int64_t)(co0 + co) * CI + ci0) * 9 + within] += total;
+}
+
+constexpr int WG3_FINISH_SLABS = WG3_CO * WG3_CI * 9 / 256;       // 36
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_finish_kernel(const Wgrad3Params p, const int walkers, const int ci_chunks) {
+  conv3x3_wgrad_finish_chunk(p.partial, p.gw, (int)blockIdx.y, (int)blockIdx.x, walkers, ci_chunks, p.CO, p.CI);
 }
 
 // One-dimensional grid in XCD-aware order (hardware workgroup b runs on XCD b % 8): the walkers go round-robin to the XCDs and
@@ -349,7 +390,8 @@ struct Wgrad3Job {
   int64_t x_off, gy_off, x_bs, gy_bs;
   float* gw;
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
-  int32_t N, CI, CO, H, W, tiles_x, tiles_y, tiles, walkers, ci_chunks, co_chunks, pad[3];
+  int32_t N, CI, CO, H, W, tiles_x, tiles_y, tiles, walkers, ci_chunks, co_chunks, pad;
+  int64_t partial_off;            // ordered form: this job's partial blocks start here (floats) in the launch's workspace region
 };
 static_assert(sizeof(Wgrad3Job) == 128, "one 128-byte table slot per job");
 
@@ -364,7 +406,7 @@ template <bool RAGGED>
 __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_grouped_kernel(const Wgrad3Job* __restrict__ jobs,
                                                                                const float* x_base, const float* gy_base,
                                                                                float* gw_base, const int grid_x, const int grid_y,
-                                                                               const int count) {
+                                                                               const int count, float* partial_base) {
   __shared__ float smem[Wgrad3Lds<4, 0, RAGGED>::SMEM];
   const int xcd = (int)blockIdx.x & 7, within_xcd = (int)blockIdx.x >> 3;
   const int per_unit = WG3_UNIT * grid_y, units_per_job = (grid_x + WG3_UNIT - 1) / WG3_UNIT;
@@ -381,8 +423,19 @@ __global__ __launch_bounds__(WG3_THREADS, 3) void conv3x3_wgrad_grouped_kernel(c
   p.N = job.N; p.CI = job.CI; p.CO = job.CO; p.H = job.H; p.W = job.W;
   p.tiles_x = job.tiles_x; p.tiles_y = job.tiles_y; p.tiles = job.tiles; p.debug = 0;
   p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
+  p.partial = partial_base ? partial_base + job.partial_off : nullptr;
   const int co_chunk = chunk / job.ci_chunks;
   conv3x3_wgrad_body<4, 0, RAGGED>(p, walker, job.walkers, chunk - co_chunk * job.ci_chunks, co_chunk, smem);
+}
+
+// blockIdx.x = 256-element slab of a block, blockIdx.y = channel chunk, blockIdx.z = job: the second stage of a grouped launch.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_grouped_finish_kernel(const Wgrad3Job* __restrict__ jobs, float* gw_base,
+                                                                           const float* __restrict__ partial_base) {
+  const Wgrad3Job job = jobs[blockIdx.z];
+  if ((int)blockIdx.y >= job.ci_chunks * job.co_chunks) return;
+  float* gw = gw_base ? gw_base + (int64_t)(intptr_t)job.gw : job.gw;
+  conv3x3_wgrad_finish_chunk(partial_base + job.partial_off, gw, (int)blockIdx.y, (int)blockIdx.x, job.walkers, job.ci_chunks, job.CO,
+                             job.CI);
 }
 
 int profile_bracket_begin(hipStream_t stream);
@@ -437,6 +490,10 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   p.tiles = (int)tiles;
   const int walkers = conv3x3_wgrad_walkers(p.tiles, ci_chunks, co_chunks);
   if (!accumulate) if (const int status = zero_floats(gw, (int64_t)CO * CI * 9, stream)) return status;
+  // several walkers per channel chunk: each keeps its 32 x 288 block in the workspace, a second kernel adds them in order
+  p.partial = nullptr;
+  if (walkers > 1 && !split_atomics_forced() && !(p.debug & 1))
+    p.partial = partial_workspace((size_t)ci_chunks * co_chunks * walkers * (WG3_CO * WG3_CI * 9) * sizeof(float), stream);
   const int64_t blocks = (int64_t)((walkers + 7) / 8) * 8 * ci_chunks * co_chunks;
   SRGAN_REQUIRE(blocks < ((int64_t)1 << 31), SRGAN_ERANGE, "conv3x3 wgrad grid");
   dim3 grid((unsigned)blocks, 1, 1);
@@ -449,6 +506,9 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   else if (th == 4) SRGAN_WG3_LAUNCH(4);
   else SRGAN_WG3_LAUNCH(2);
 #undef SRGAN_WG3_LAUNCH
+  if (p.partial)
+    hipLaunchKernelGGL(conv3x3_wgrad_finish_kernel, dim3(WG3_FINISH_SLABS, (unsigned)(ci_chunks * co_chunks)), dim3(256), 0, stream, p,
+                       walkers, ci_chunks);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, CO, (int64_t)CI * 9, (int64_t)N * H * W, 4, th, WG3_TW, walkers, 0, 0, 0, precision);
   return status;
@@ -456,8 +516,8 @@ int conv3x3_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
 
 // One entry of a grouped launch's table (see pointwise_wgrad_group_plan); the weight gradient is ACCUMULATED into gw.
 int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int64_t gw_off, int32_t N, int32_t CI,
-                             int32_t CO, int32_t H, int32_t W, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
-                             int32_t* grid_y, int32_t* ragged) {
+                             int32_t CO, int32_t H, int32_t W, const float* const* bn, int32_t group, int64_t partial_offset, void* job_out,
+                             int32_t* grid_x, int32_t* grid_y, int32_t* ragged, int64_t* partial_floats) {
   Wgrad3Job job;
   job.x_off = x_off; job.gy_off = gy_off; job.x_bs = x_bs; job.gy_bs = gy_bs;
   job.gw = gw ? gw : reinterpret_cast<float*>((intptr_t)gw_off);
@@ -470,7 +530,9 @@ int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_
   SRGAN_REQUIRE(tiles < (int64_t)1 << 31 && (int64_t)job.ci_chunks * job.co_chunks <= 65535, SRGAN_ERANGE, "conv3x3 wgrad grid");
   job.tiles = (int)tiles;
   job.walkers = conv3x3_wgrad_walkers(job.tiles, job.ci_chunks, job.co_chunks, group);
-  job.pad[0] = job.pad[1] = job.pad[2] = 0;
+  job.pad = 0;
+  job.partial_off = partial_offset;
+  *partial_floats = (int64_t)job.walkers * job.ci_chunks * job.co_chunks * (WG3_CO * WG3_CI * 9);
   static_assert(sizeof(Wgrad3Job) <= 128, "job slot");
   memset(job_out, 0, 128);
   memcpy(job_out, &job, sizeof(job));
@@ -481,8 +543,11 @@ int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_
 
 int conv3x3_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
                             const float* x_base, const float* gy_base, float* gw_base, int64_t flops_mn, int64_t pixels,
-                            int64_t elements, hipStream_t stream) {
+                            int64_t elements, int64_t partial_floats, hipStream_t stream) {
   SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped conv3x3 wgrad grid");
+  float* partial_base = nullptr;          // the ordered form (see pointwise_wgrad_group_run)
+  if (partial_floats > 0 && grid_x > 1 && !split_atomics_forced())
+    partial_base = partial_workspace((size_t)partial_floats * sizeof(float), stream);
   const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
   // one-dimensional: 8 XCDs x (units per XCD, rounded up) x (WG3_UNIT walkers x channel chunks) -- see the kernel
   const int64_t units = (int64_t)((grid_x + WG3_UNIT - 1) / WG3_UNIT) * count, rounds = (units + 7) / 8;
@@ -490,9 +555,12 @@ int conv3x3_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int
   dim3 grid((unsigned)(rounds * 8 * WG3_UNIT * grid_y), 1, 1);
   const int profile_slot = profile_bracket_begin(stream);
   if (rag) hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<true>), grid, dim3(WG3_THREADS), 0, stream,
-                              reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base, grid_x, grid_y, count);
+                              reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base, grid_x, grid_y, count, partial_base);
   else hipLaunchKernelGGL((conv3x3_wgrad_grouped_kernel<false>), grid, dim3(WG3_THREADS), 0, stream,
-                          reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base, grid_x, grid_y, count);
+                          reinterpret_cast<const Wgrad3Job*>(jobs), x_base, gy_base, gw_base, grid_x, grid_y, count, partial_base);
+  if (partial_base)
+    hipLaunchKernelGGL(conv3x3_wgrad_grouped_finish_kernel, dim3(WG3_FINISH_SLABS, (unsigned)grid_y, (unsigned)count), dim3(256), 0, stream,
+                       reinterpret_cast<const Wgrad3Job*>(jobs), gw_base, partial_base);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 4, 4, WG3_TW, grid_x, 0, 0, elements > pixels ? elements - pixels : 0);
   return status;

@@ -552,7 +552,7 @@ __device__ unsigned int g_gg_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_TILE
 // the per-workgroup batch-norm parameter sums of the fused data-gradient epilogues (2 x column blocks x channels x 4 B =
 // at most 1/32 of the gradient tensor's bytes: 64 MiB covers tensors of up to 2^29 elements; larger ones report "unsupported"
 // from srgan_conv2d_bnrelu_supported and take the two-kernel form).  The library never allocates device memory.
-constexpr size_t WORKSPACE_BYTES = (size_t)128 << 20;     // (round 5: 128 MiB -- the ordered / partial finish of every K split lives here)
+constexpr size_t WORKSPACE_BYTES = (size_t)256 << 20;     // (round 5: 256 MiB -- the partial tiles of every K split / grouped weight gradient live here)
 struct WorkspaceSlot { float* ptr = nullptr; size_t bytes = 0; int index = -1; };
 static std::mutex g_workspace_mutex;
 static std::map<std::pair<int, hipStream_t>, WorkspaceSlot> g_workspaces;
@@ -907,17 +907,17 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
                         int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
 
 int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int64_t gw_off, int32_t N, int32_t CI,
-                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
-                               int32_t* grid_y, int32_t* ragged);
+                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, int64_t partial_offset, void* job_out,
+                               int32_t* grid_x, int32_t* grid_y, int32_t* ragged, int64_t* partial_floats);
 int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged, int32_t fused_bn,
                               const float* x_base, const float* gy_base, float* gw_base, int64_t flops_mn, int64_t pixels,
-                              int64_t elements, hipStream_t stream);
+                              int64_t elements, int64_t partial_floats, hipStream_t stream);
 int conv3x3_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int64_t gw_off, int32_t N, int32_t CI,
-                             int32_t CO, int32_t H, int32_t W, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
-                             int32_t* grid_y, int32_t* ragged);
+                             int32_t CO, int32_t H, int32_t W, const float* const* bn, int32_t group, int64_t partial_offset, void* job_out,
+                             int32_t* grid_x, int32_t* grid_y, int32_t* ragged, int64_t* partial_floats);
 int conv3x3_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged,
                             const float* x_base, const float* gy_base, float* gw_base, int64_t flops_mn, int64_t pixels,
-                            int64_t elements, hipStream_t stream);
+                            int64_t elements, int64_t partial_floats, hipStream_t stream);
 
 static bool pointwise_wgrad_geometry(const ConvGeom& g) {
   static const bool no_ragged = getenv("SRGAN_PWG_NO_RAGGED") != nullptr;
@@ -1298,33 +1298,34 @@ int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, 
 
 // ---- grouped weight gradients: all the norm -> relu -> conv weight gradients of a dense block's backward in two launches
 int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
-                           int64_t gw_offset, int32_t group_size, void* job, int32_t* grid_x, int32_t* grid_y,
-                           int32_t* ragged) {
+                           int64_t gw_offset, int32_t group_size, int64_t partial_offset, void* job, int32_t* grid_x, int32_t* grid_y,
+                           int32_t* ragged, int64_t* partial_floats) {
   ConvGeom g;
   SRGAN_GEOM(desc, g, "srgan_wgrad_group_plan");
-  SRGAN_REQUIRE(job && grid_x && grid_y && ragged && (bn == nullptr || bn_ok(bn)) && x_offset >= 0 && gy_offset >= 0 &&
-                gw_offset >= 0 && group_size >= 1, SRGAN_EINVAL, "srgan_wgrad_group_plan arguments");
+  SRGAN_REQUIRE(job && grid_x && grid_y && ragged && partial_floats && (bn == nullptr || bn_ok(bn)) && x_offset >= 0 &&
+                gy_offset >= 0 && gw_offset >= 0 && partial_offset >= 0 && group_size >= 1, SRGAN_EINVAL,
+                "srgan_wgrad_group_plan arguments");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 2), SRGAN_EUNSUPPORTED, "srgan_wgrad_group_plan geometry support");
   const float* const coefficients[4] = {bn ? bn->mean : nullptr, bn ? bn->inv_std : nullptr, bn ? bn->gamma : nullptr,
                                         bn ? bn->beta : nullptr};
   const float* const* fused = bn ? coefficients : nullptr;
   if (pointwise(g))
     return pointwise_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, gw_offset, g.N, g.C, g.K, g.H * g.W, fused,
-                                      group_size, job, grid_x, grid_y, ragged);
+                                      group_size, partial_offset, job, grid_x, grid_y, ragged, partial_floats);
   return conv3x3_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, gw_offset, g.N, g.C, g.K, g.H, g.W, fused, group_size,
-                                  job, grid_x, grid_y, ragged);
+                                  partial_offset, job, grid_x, grid_y, ragged, partial_floats);
 }
 
 int srgan_wgrad_group_run(const void* jobs, int32_t count, int32_t kernel_size, int32_t grid_x, int32_t grid_y, int32_t ragged,
                           int32_t fused_bn, const float* x_base, const float* gy_base, float* gw_base, int64_t sum_co_ci_taps,
-                          int64_t pixels, int64_t operand_elements, void* stream) {
-  SRGAN_REQUIRE(jobs && x_base && gy_base && count >= 1 && grid_x >= 1 && grid_y >= 1 && (kernel_size == 1 || kernel_size == 3),
-                SRGAN_EINVAL, "srgan_wgrad_group_run arguments");
+                          int64_t pixels, int64_t operand_elements, int64_t partial_floats, void* stream) {
+  SRGAN_REQUIRE(jobs && x_base && gy_base && count >= 1 && grid_x >= 1 && grid_y >= 1 && (kernel_size == 1 || kernel_size == 3) &&
+                partial_floats >= 0, SRGAN_EINVAL, "srgan_wgrad_group_run arguments");
   if (kernel_size == 1)
     return pointwise_wgrad_group_run(jobs, count, grid_x, grid_y, ragged, fused_bn, x_base, gy_base, gw_base, sum_co_ci_taps,
-                                     pixels, operand_elements, (hipStream_t)stream);
+                                     pixels, operand_elements, partial_floats, (hipStream_t)stream);
   return conv3x3_wgrad_group_run(jobs, count, grid_x, grid_y, ragged, x_base, gy_base, gw_base, sum_co_ci_taps, pixels,
-                                 operand_elements, (hipStream_t)stream);
+                                 operand_elements, partial_floats, (hipStream_t)stream);
 }
 
 int srgan_profile_begin(void) {

@@ -397,29 +397,51 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
 }
 
 // Second level of the fused batch-norm backward's parameter gradients: column sums of partial[q][column block][CO]
-// (lanes along the channels: coalesced rows), a few segments of column blocks per channel, one atomic per segment.
+// (lanes along the channels: coalesced rows).  Round 5, ORDERED form (the default): ONE workgroup owns 16 channels, its 16
+// column-block lanes walk all the blocks, the sixteen sums meet in a fixed order and the workgroup adds the total to the
+// gradient -- one adder per channel and launch, the same bits every run.  With SRGAN_ATOMIC_SPLIT=1: round 4's form, a
+// few segments of column blocks per channel, 64 channels x 4 lanes per workgroup, one fp32 atomic per segment.
+template <bool ORDERED>
+__device__ __forceinline__ void bn_partial_reduce_body(const float* __restrict__ partial, int cols, int CO,
+                                                       const float* __restrict__ inv_std, float* __restrict__ g_gamma,
+                                                       float* __restrict__ g_beta, int first, int last, int block_x,
+                                                       float (*scratch)[256]) {
+  constexpr int LANES_C = ORDERED ? 16 : 64, LANES_T = 256 / LANES_C;
+  const int lane_c = (int)threadIdx.x % LANES_C, rl = (int)threadIdx.x / LANES_C;
+  const int c = block_x * LANES_C + lane_c;
+  float plain = 0.f, centred = 0.f;
+  if (c < CO)
+    for (int cb = first + rl; cb < last; cb += LANES_T) {
+      plain += partial[(int64_t)cb * CO + c];
+      centred += partial[((int64_t)cols + cb) * CO + c];
+    }
+  scratch[0][rl * LANES_C + lane_c] = plain;
+  scratch[1][rl * LANES_C + lane_c] = centred;
+  __syncthreads();
+  if (rl != 0 || c >= CO) return;
+  plain = centred = 0.f;
+#pragma unroll
+  for (int r = 0; r < LANES_T; ++r) {                         // fixed order
+    plain += scratch[0][r * LANES_C + lane_c];
+    centred += scratch[1][r * LANES_C + lane_c];
+  }
+  if (ORDERED) {
+    g_beta[c] += plain;
+    g_gamma[c] += centred * inv_std[c];
+  } else {
+    unsafeAtomicAdd(g_beta + c, plain);
+    unsafeAtomicAdd(g_gamma + c, centred * inv_std[c]);
+  }
+}
+
+template <bool ORDERED>
 __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __restrict__ partial, int cols, int CO,
                                                                 const float* __restrict__ inv_std,
                                                                 float* __restrict__ g_gamma, float* __restrict__ g_beta,
                                                                 int cols_per_segment) {
-  __shared__ float scratch[2][4][64];
-  const int lane_c = (int)threadIdx.x & 63, rl = (int)threadIdx.x >> 6;
-  const int c = (int)blockIdx.x * 64 + lane_c;
+  __shared__ float scratch[2][256];
   const int first = (int)blockIdx.y * cols_per_segment, last = min(cols, first + cols_per_segment);
-  float plain = 0.f, centred = 0.f;
-  if (c < CO)
-    for (int cb = first + rl; cb < last; cb += 4) {
-      plain += partial[(int64_t)cb * CO + c];
-      centred += partial[((int64_t)cols + cb) * CO + c];
-    }
-  scratch[0][rl][lane_c] = plain;
-  scratch[1][rl][lane_c] = centred;
-  __syncthreads();
-  if (rl != 0 || c >= CO) return;
-  plain = (scratch[0][0][lane_c] + scratch[0][1][lane_c]) + (scratch[0][2][lane_c] + scratch[0][3][lane_c]);
-  centred = (scratch[1][0][lane_c] + scratch[1][1][lane_c]) + (scratch[1][2][lane_c] + scratch[1][3][lane_c]);
-  unsafeAtomicAdd(g_beta + c, plain);
-  unsafeAtomicAdd(g_gamma + c, centred * inv_std[c]);
+  bn_partial_reduce_body<ORDERED>(partial, cols, CO, inv_std, g_gamma, g_beta, first, last, (int)blockIdx.x, scratch);
 }
 
 int profile_bracket_begin(hipStream_t stream);
@@ -437,10 +459,15 @@ int pointwise_ring_run(const float* in, int64_t in_bs, const float* w, int32_t w
 // g_beta[c] += sum_t partial[0][t][c];  g_gamma[c] += inv_std[c] * sum_t partial[1][t][c]   (t = workgroup tiles)
 void bn_partial_reduce_run(const float* partial, int tiles, int CO, const float* inv_std, float* g_gamma, float* g_beta,
                            hipStream_t stream) {
+  if (!split_atomics_forced()) {           // ordered: one workgroup per 16 channels walks every tile
+    hipLaunchKernelGGL(bn_partial_reduce_kernel<true>, dim3((CO + 15) / 16, 1), dim3(256), 0, stream, partial, tiles, CO, inv_std,
+                       g_gamma, g_beta, tiles);
+    return;
+  }
   int segments = tiles / 32;
   segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
   const int per = (tiles + segments - 1) / segments;
-  hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((CO + 63) / 64, (unsigned)((tiles + per - 1) / per)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bn_partial_reduce_kernel<false>, dim3((CO + 63) / 64, (unsigned)((tiles + per - 1) / per)), dim3(256), 0, stream,
                      partial, tiles, CO, inv_std, g_gamma, g_beta, per);
 }
 
@@ -450,40 +477,34 @@ void bn_partial_reduce_run(const float* partial, int tiles, int CO, const float*
 // region and the arena pointers do not change between steps).
 struct BnReduceJob { int64_t partial_offset; int32_t tiles, channels; const float* inv_std; float* g_gamma; float* g_beta; };
 
+template <bool ORDERED>
 __global__ __launch_bounds__(256) void bn_partial_reduce_batched_kernel(const BnReduceJob* __restrict__ jobs,
                                                                         const float* __restrict__ scratch) {
-  __shared__ float buffer[2][4][64];
+  __shared__ float buffer[2][256];
   const BnReduceJob job = jobs[blockIdx.z];
-  int segments = job.tiles / 32;
-  segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
-  const int per = (job.tiles + segments - 1) / segments;
-  const int first = (int)blockIdx.y * per;
-  if ((int)blockIdx.x * 64 >= job.channels || first >= job.tiles) return;        // (workgroup-uniform)
-  const int last = min(job.tiles, first + per);
-  const float* partial = scratch + job.partial_offset;
-  const int lane_c = (int)threadIdx.x & 63, rl = (int)threadIdx.x >> 6;
-  const int c = (int)blockIdx.x * 64 + lane_c;
-  float plain = 0.f, centred = 0.f;
-  if (c < job.channels)
-    for (int t = first + rl; t < last; t += 4) {
-      plain += partial[(int64_t)t * job.channels + c];
-      centred += partial[((int64_t)job.tiles + t) * job.channels + c];
-    }
-  buffer[0][rl][lane_c] = plain;
-  buffer[1][rl][lane_c] = centred;
-  __syncthreads();
-  if (rl != 0 || c >= job.channels) return;
-  plain = (buffer[0][0][lane_c] + buffer[0][1][lane_c]) + (buffer[0][2][lane_c] + buffer[0][3][lane_c]);
-  centred = (buffer[1][0][lane_c] + buffer[1][1][lane_c]) + (buffer[1][2][lane_c] + buffer[1][3][lane_c]);
-  unsafeAtomicAdd(job.g_beta + c, plain);
-  unsafeAtomicAdd(job.g_gamma + c, centred * job.inv_std[c]);
+  int first = 0, last = job.tiles;
+  if (!ORDERED) {
+    int segments = job.tiles / 32;
+    segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
+    const int per = (job.tiles + segments - 1) / segments;
+    first = (int)blockIdx.y * per;
+    last = min(job.tiles, first + per);
+  }
+  if ((int)blockIdx.x * (ORDERED ? 16 : 64) >= job.channels || first >= job.tiles) return;        // (workgroup-uniform)
+  bn_partial_reduce_body<ORDERED>(scratch + job.partial_offset, job.tiles, job.channels, job.inv_std, job.g_gamma, job.g_beta,
+                                  first, last, (int)blockIdx.x, buffer);
 }
 
 int bn_partial_reduce_batched_run(const void* jobs, int count, int max_channels, int max_tiles, const float* scratch,
                                   hipStream_t stream) {
+  if (!split_atomics_forced()) {
+    hipLaunchKernelGGL(bn_partial_reduce_batched_kernel<true>, dim3((max_channels + 15) / 16, 1, count), dim3(256), 0, stream,
+                       reinterpret_cast<const BnReduceJob*>(jobs), scratch);
+    return launch_status();
+  }
   int segments = max_tiles / 32;
   segments = segments < 1 ? 1 : (segments > 64 ? 64 : segments);
-  hipLaunchKernelGGL(bn_partial_reduce_batched_kernel, dim3((max_channels + 63) / 64, segments, count), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bn_partial_reduce_batched_kernel<false>, dim3((max_channels + 63) / 64, segments, count), dim3(256), 0, stream,
                      reinterpret_cast<const BnReduceJob*>(jobs), scratch);
   return launch_status();
 }

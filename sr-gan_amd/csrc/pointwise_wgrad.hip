@@ -11,9 +11,13 @@
 // it).  Every 128-byte line is fetched by exactly one load instruction and used completely.  Each WAVE is an
 // independent worker over its own range of pixel chunks for the workgroup's 64 x 64 output tile; the next chunk is
 // in flight while the current one is in the matrix pipe (explicit ping-pong register sets).  The four waves' tiles
-// are summed through LDS and leave as one coalesced fp32-atomic pass per workgroup.
+// are summed through LDS and leave as one coalesced pass per workgroup: round 5 -- into the caller's workspace (every
+// K-slice worker of an output tile keeps its own 64 x 64 partial there, `pointwise_wgrad_finish_kernel` adds a tile's
+// partials in slice order and accumulates into gw: the same bits on every run); fp32 atomics into gw only when the stream
+// has no workspace (or SRGAN_ATOMIC_SPLIT=1).
 // The generic gather-GEMM staged both operands through LDS with a transpose and reached 55 TF/s on these shapes.
 #include "common.h"
+#include "split_finish.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,6 +32,8 @@ struct PwWgradParams {
   int32_t tiles_n;               // ci tiles
   int32_t chunks, chunks_per_worker, chunks_per_image;
   int32_t mode;                  // 1 accumulate (single K-slice per tile), 2 atomic
+  float* partial;                // non-NULL: K-slice `y` of tile `t` stores its 64 x 64 block at partial[(t * split + y) * 4096 ...]
+  int32_t split;                 //   and pointwise_wgrad_finish adds the slices in order (no atomics)
   // x is relu(batch_norm_eval(x)) computed on the fly (per input channel) when bn_mean != NULL
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
 };
@@ -175,12 +181,44 @@ __device__ __forceinline__ void pointwise_wgrad_body(const PwWgradParams& p, con
     const int idx = tid + 256 * e;
     const int row = idx / COLS, col = idx - row * COLS;
     const float v = red[row * LDR + col] + red[ROWS * LDR + row * LDR + col];
+    if (p.partial) {               // (the whole tile, coalesced: rows / columns outside the matrix hold zeros and are never read back)
+      p.partial[((int64_t)block_x * p.split + block_y) * (ROWS * COLS) + idx] = v;
+      continue;
+    }
     if (co0 + row < p.CO && ci0 + col < p.CI) {
       float* dst = p.gw + (int64_t)(co0 + row) * p.CI + ci0 + col;
       if (p.mode == 2) unsafeAtomicAdd(dst, v);
       else *dst += v;
     }
   }
+}
+
+// Second stage of the ordered form: gw[tile] += the tile's K-slice partials, added in slice order.  One thread per element
+// of the 64 x 64 tile (`slab` = which 256 of its 4096), the slices read with lanes along the elements.
+__device__ __forceinline__ void pointwise_wgrad_finish_tile(const float* __restrict__ partial, float* __restrict__ gw, int tile,
+                                                            int slab, int split, int tiles_n, int CO, int CI) {
+  constexpr int ROWS = PWG_MI * 32, COLS = PWG_NI * 32;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int co0 = tm * ROWS, ci0 = tn * COLS;
+  const int idx = slab * 256 + (int)threadIdx.x;
+  const int row = idx / COLS, col = idx - row * COLS;
+  if (co0 + row >= CO || ci0 + col >= CI) return;
+  const float* mine = partial + (int64_t)tile * split * (ROWS * COLS) + idx;
+  float total = mine[0];
+  int y = 1;
+  for (; y + 3 < split; y += 4) {                // four loads in flight, one fixed order
+    const float a = mine[(int64_t)y * (ROWS * COLS)], b = mine[(int64_t)(y + 1) * (ROWS * COLS)];
+    const float c = mine[(int64_t)(y + 2) * (ROWS * COLS)], d = mine[(int64_t)(y + 3) * (ROWS * COLS)];
+    total = (((total + a) + b) + c) + d;
+  }
+  for (; y < split; ++y) total += mine[(int64_t)y * (ROWS * COLS)];
+  gw[(int64_t)(co0 + row) * CI + ci0 + col] += total;
+}
+
+constexpr int PWG_FINISH_SLABS = PWG_MI * 32 * PWG_NI * 32 / 256;       // 16
+
+__global__ __launch_bounds__(256) void pointwise_wgrad_finish_kernel(const PwWgradParams p) {
+  pointwise_wgrad_finish_tile(p.partial, p.gw, (int)blockIdx.y, (int)blockIdx.x, p.split, p.tiles_n, p.CO, p.CI);
 }
 
 template <bool PRO, bool RAGGED>
@@ -196,7 +234,8 @@ struct PwWgradJob {
   int64_t x_off, gy_off, x_bs, gy_bs;
   float* gw;
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;
-  int32_t N, CI, CO, HW, tiles_n, tiles, chunks, chunks_per_worker, chunks_per_image, mode, split, pad[3];
+  int32_t N, CI, CO, HW, tiles_n, tiles, chunks, chunks_per_worker, chunks_per_image, mode, split, pad;
+  int64_t partial_off;           // ordered form: this job's partial tiles start here (floats) in the launch's workspace region
 };
 static_assert(sizeof(PwWgradJob) == 128, "one 128-byte table slot per job");
 
@@ -214,7 +253,7 @@ template <bool PRO, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const PwWgradJob* __restrict__ jobs,
                                                                          const float* x_base, const float* gy_base,
                                                                          float* gw_base, const int grid_x, const int grid_y,
-                                                                         const int count) {
+                                                                         const int count, float* partial_base) {
   __shared__ float red[2 * PWG_MI * 32 * (PWG_NI * 32 + 1)];
   const int xcd = (int)blockIdx.x & 7, within_xcd = (int)blockIdx.x >> 3;
   const int round = within_xcd / grid_x, tile = within_xcd % grid_x;
@@ -231,7 +270,18 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_grouped_kernel(const P
   p.tiles_n = job.tiles_n; p.chunks = job.chunks; p.chunks_per_worker = job.chunks_per_worker;
   p.chunks_per_image = job.chunks_per_image; p.mode = job.mode;
   p.bn_mean = job.bn_mean; p.bn_inv = job.bn_inv; p.bn_gamma = job.bn_gamma; p.bn_beta = job.bn_beta;
+  p.partial = partial_base ? partial_base + job.partial_off : nullptr; p.split = job.split;
   pointwise_wgrad_body<PRO, RAGGED>(p, tile, y, red);
+}
+
+// blockIdx.x = 256-element slab of a tile, blockIdx.y = tile, blockIdx.z = job: the second stage of a grouped launch.
+__global__ __launch_bounds__(256) void pointwise_wgrad_grouped_finish_kernel(const PwWgradJob* __restrict__ jobs, float* gw_base,
+                                                                             const float* __restrict__ partial_base) {
+  const PwWgradJob job = jobs[blockIdx.z];
+  if ((int)blockIdx.y >= job.tiles) return;
+  float* gw = gw_base ? gw_base + (int64_t)(intptr_t)job.gw : job.gw;
+  pointwise_wgrad_finish_tile(partial_base + job.partial_off, gw, (int)blockIdx.y, (int)blockIdx.x, job.split, job.tiles_n, job.CO,
+                              job.CI);
 }
 
 int profile_bracket_begin(hipStream_t stream);
@@ -290,12 +340,17 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
   if (const int status = pointwise_wgrad_plan(N, CI, CO, HW, p, tiles, split)) return status;
   const bool ragged = pointwise_wgrad_ragged(x, x_bs, gy, gy_bs, HW);
   if (!accumulate) if (const int status = zero_floats(gw, (int64_t)CO * CI, stream)) return status;
+  // K split: every slice's 64 x 64 partial through the workspace, added in slice order by a second kernel (no atomics)
+  p.partial = nullptr; p.split = split;
+  if (split > 1 && !split_atomics_forced())
+    p.partial = partial_workspace((size_t)tiles * split * (PWG_MI * 32 * PWG_NI * 32) * sizeof(float), stream);
   dim3 grid((unsigned)tiles, (unsigned)split, 1);
   const int profile_slot = profile_bracket_begin(stream);
   if (ragged && bn) hipLaunchKernelGGL((pointwise_wgrad_kernel<true, true>), grid, dim3(256), 0, stream, p);
   else if (ragged) hipLaunchKernelGGL((pointwise_wgrad_kernel<false, true>), grid, dim3(256), 0, stream, p);
   else if (bn) hipLaunchKernelGGL((pointwise_wgrad_kernel<true, false>), grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((pointwise_wgrad_kernel<false, false>), grid, dim3(256), 0, stream, p);
+  if (p.partial) hipLaunchKernelGGL(pointwise_wgrad_finish_kernel, dim3(PWG_FINISH_SLABS, (unsigned)tiles), dim3(256), 0, stream, p);
   const int status = launch_status();
   profile_bracket_end(profile_slot, stream, CO, CI, (int64_t)N * HW, 6, PWG_MI * 32, PWG_NI * 32, split);
   return status;
@@ -304,8 +359,8 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
 // One entry of a grouped launch's table (host side; the caller uploads the table once).  x / gy are element offsets from
 // the two base pointers given at launch time; the weight gradient is ACCUMULATED into gw.
 int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int64_t gw_off, int32_t N, int32_t CI,
-                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, void* job_out, int32_t* grid_x,
-                               int32_t* grid_y, int32_t* ragged) {
+                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, int64_t partial_offset, void* job_out,
+                               int32_t* grid_x, int32_t* grid_y, int32_t* ragged, int64_t* partial_floats) {
   PwWgradParams p;
   int tiles = 0, split = 1;
   if (const int status = pointwise_wgrad_plan(N, CI, CO, HW, p, tiles, split, group)) return status;
@@ -316,7 +371,9 @@ int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int6
   job.bn_gamma = bn ? bn[2] : nullptr; job.bn_beta = bn ? bn[3] : nullptr;
   job.N = N; job.CI = CI; job.CO = CO; job.HW = HW; job.tiles_n = p.tiles_n; job.tiles = tiles; job.chunks = p.chunks;
   job.chunks_per_worker = p.chunks_per_worker; job.chunks_per_image = p.chunks_per_image; job.mode = p.mode;
-  job.split = split; job.pad[0] = job.pad[1] = job.pad[2] = 0;
+  job.split = split; job.pad = 0;
+  job.partial_off = partial_offset;
+  *partial_floats = (int64_t)tiles * split * (PWG_MI * 32 * PWG_NI * 32);
   static_assert(sizeof(PwWgradJob) <= 128, "job slot");
   memset(job_out, 0, 128);
   memcpy(job_out, &job, sizeof(job));
@@ -328,8 +385,13 @@ int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int6
 
 int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged, int32_t fused_bn,
                               const float* x_base, const float* gy_base, float* gw_base, int64_t flops_mn, int64_t pixels,
-                              int64_t elements, hipStream_t stream) {
+                              int64_t elements, int64_t partial_floats, hipStream_t stream) {
   SRGAN_REQUIRE(count >= 1 && count <= 65535 && grid_y <= 65535, SRGAN_ERANGE, "grouped pointwise wgrad grid");
+  // the ordered form: every job's K-slice partials in the stream's workspace (the table holds each job's offset), a second
+  // launch adds them in slice order -- when the workspace holds them; otherwise fp32 atomics into gw
+  float* partial_base = nullptr;
+  if (partial_floats > 0 && grid_y > 1 && !split_atomics_forced())
+    partial_base = partial_workspace((size_t)partial_floats * sizeof(float), stream);
   const bool rag = ragged || ((((uintptr_t)x_base | (uintptr_t)gy_base) & 15) != 0);
   // one-dimensional: 8 XCDs x (slices per XCD, rounded up) x tiles (see the kernel)
   const int64_t slices = (int64_t)grid_y * count, rounds = (slices + 7) / 8;
@@ -338,12 +400,15 @@ int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, i
   const PwWgradJob* table = reinterpret_cast<const PwWgradJob*>(jobs);
   const int profile_slot = profile_bracket_begin(stream);
 #define SRGAN_PWG_LAUNCH(PRO, RAG) hipLaunchKernelGGL((pointwise_wgrad_grouped_kernel<PRO, RAG>), grid, dim3(256), 0, stream, \
-                                                      table, x_base, gy_base, gw_base, grid_x, grid_y, count)
+                                                      table, x_base, gy_base, gw_base, grid_x, grid_y, count, partial_base)
   if (fused_bn && rag) SRGAN_PWG_LAUNCH(true, true);
   else if (fused_bn) SRGAN_PWG_LAUNCH(true, false);
   else if (rag) SRGAN_PWG_LAUNCH(false, true);
   else SRGAN_PWG_LAUNCH(false, false);
 #undef SRGAN_PWG_LAUNCH
+  if (partial_base)
+    hipLaunchKernelGGL(pointwise_wgrad_grouped_finish_kernel, dim3(PWG_FINISH_SLABS, (unsigned)grid_x, (unsigned)count), dim3(256), 0, stream, table,
+                       gw_base, partial_base);
   const int status = launch_status();
   // logical shape of the group: M x (sum of the input widths) x pixels, i.e. flops_mn = sum CO * CI
   profile_bracket_end(profile_slot, stream, 1, flops_mn, pixels, 6, PWG_MI * 32, PWG_NI * 32, grid_y, 0, 0,

@@ -3,6 +3,7 @@
 // Max-pool keeps the flat in-plane arg-max so that backward (scatter) and double-backward (gather) reuse
 // the forward's choice; ties resolve to the first maximum in row-major window order, as torch's CPU kernel.
 #include "common.h"
+#include "split_finish.h"
 #include <math.h>
 
 namespace srgan {
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* _
 // parameter sums (beta: sum of the masked S; gamma: inv_std * sum of masked S * (x - mean)) reduced per workgroup and
 // added atomically.  One workgroup = QUADS_PER_BLOCK float4 of ONE plane (blockIdx.y), so a block's sums are one channel's.
 constexpr int POOL_BWD_QUADS = 1024;
+__device__ unsigned int g_pool_finish_tickets[SPLIT_TICKET_SETS * ROW_FINISH_ROWS];
 template <int K, int S, int P>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx,
                                                                   const float* __restrict__ x, const float* __restrict__ mean,
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* __restrict__ gx,
                                                                   float* __restrict__ g_gamma, float* __restrict__ g_beta,
-                                                                  int C, int H, int W, int OH, int OW) {
+                                                                  int C, int H, int W, int OH, int OW, float* finish_partial,
+                                                                  unsigned int* finish_tickets) {
   constexpr int SPAN = (3 + P) / S - (P - K + 1 > 0 ? (P - K + 1 + S - 1) / S : 0) + 2;
   __shared__ float scratch[2][4];
   const uint32_t plane = blockIdx.y, w4 = (uint32_t)W >> 2, plane_quads = (uint32_t)H * w4;
@@ -205,9 +208,21 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
   const int wave = (int)threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { scratch[0][wave] = plain; scratch[1][wave] = centred; }
   __syncthreads();
+  float v[2] = {(scratch[0][0] + scratch[0][1]) + (scratch[0][2] + scratch[0][3]),
+                (scratch[1][0] + scratch[1][1]) + (scratch[1][2] + scratch[1][3])};       // (every thread; thread 0's are used)
+  if (finish_partial) {        // ordered: the channel's workgroups (image x plane block) meet in a fixed order, ONE adder per channel
+    const int parts = (int)(gridDim.y / (unsigned)C) * (int)gridDim.x;
+    const int part = (int)(plane / (uint32_t)C) * (int)gridDim.x + (int)blockIdx.x;
+    __syncthreads();
+    if (ordered_row_finish<2>(v, finish_partial + (int64_t)c * parts * 2, part, parts, finish_tickets + c, &scratch[0][0])) {
+      g_beta[c] += v[0];
+      g_gamma[c] += v[1] * inv_std[c];
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
-    unsafeAtomicAdd(g_beta + c, (scratch[0][0] + scratch[0][1]) + (scratch[0][2] + scratch[0][3]));
-    unsafeAtomicAdd(g_gamma + c, ((scratch[1][0] + scratch[1][1]) + (scratch[1][2] + scratch[1][3])) * inv_std[c]);
+    unsafeAtomicAdd(g_beta + c, v[0]);
+    unsafeAtomicAdd(g_gamma + c, v[1] * inv_std[c]);
   }
 }
 
@@ -247,7 +262,8 @@ __global__ __launch_bounds__(256) void bn_relu_avgpool2_bwd_kernel(const float* 
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float* __restrict__ gx,
                                                                    float* __restrict__ g_gamma, float* __restrict__ g_beta,
-                                                                   int C, int H, int W) {
+                                                                   int C, int H, int W, float* finish_partial,
+                                                                   unsigned int* finish_tickets) {
   __shared__ float scratch[2][4];
   const uint32_t plane = blockIdx.y, w4 = (uint32_t)W >> 2, items = ((uint32_t)H >> 1) * w4;
   const int c = (int)(plane % (uint32_t)C);
@@ -281,9 +297,21 @@ __global__ __launch_bounds__(256) void bn_relu_avgpool2_bwd_kernel(const float* 
   const int wave = (int)threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { scratch[0][wave] = plain; scratch[1][wave] = centred; }
   __syncthreads();
+  float v[2] = {(scratch[0][0] + scratch[0][1]) + (scratch[0][2] + scratch[0][3]),
+                (scratch[1][0] + scratch[1][1]) + (scratch[1][2] + scratch[1][3])};       // (every thread; thread 0's are used)
+  if (finish_partial) {        // ordered: the channel's workgroups (image x plane block) meet in a fixed order, ONE adder per channel
+    const int parts = (int)(gridDim.y / (unsigned)C) * (int)gridDim.x;
+    const int part = (int)(plane / (uint32_t)C) * (int)gridDim.x + (int)blockIdx.x;
+    __syncthreads();
+    if (ordered_row_finish<2>(v, finish_partial + (int64_t)c * parts * 2, part, parts, finish_tickets + c, &scratch[0][0])) {
+      g_beta[c] += v[0];
+      g_gamma[c] += v[1] * inv_std[c];
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
-    unsafeAtomicAdd(g_beta + c, (scratch[0][0] + scratch[0][1]) + (scratch[0][2] + scratch[0][3]));
-    unsafeAtomicAdd(g_gamma + c, ((scratch[1][0] + scratch[1][1]) + (scratch[1][2] + scratch[1][3])) * inv_std[c]);
+    unsafeAtomicAdd(g_beta + c, v[0]);
+    unsafeAtomicAdd(g_gamma + c, v[1] * inv_std[c]);
   }
 }
 
@@ -417,8 +445,10 @@ int srgan_bn_relu_maxpool_bwd(const float* gy, const int32_t* argmax, const floa
                 SRGAN_EUNSUPPORTED, "srgan_bn_relu_maxpool_bwd geometry");
   const uint32_t plane_quads = (uint32_t)H * ((uint32_t)W >> 2);
   dim3 grid((plane_quads + POOL_BWD_QUADS - 1) / POOL_BWD_QUADS, (unsigned)(N * C), 1);
+  unsigned int* tickets = nullptr;
+  float* partial = g_gamma ? row_finish_workspace(C, (int)(grid.x * N), 2, g_pool_finish_tickets, (hipStream_t)stream, &tickets) : nullptr;
   hipLaunchKernelGGL((bn_relu_maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, gy, argmax, x, mean, inv_std,
-                     gamma, beta, gx, g_gamma, g_beta, C, H, W, OH, OW);
+                     gamma, beta, gx, g_gamma, g_beta, C, H, W, OH, OW, partial, tickets);
   return launch_status();
 }
 
@@ -449,8 +479,10 @@ int srgan_bn_relu_avgpool2_bwd(const float* gy, const float* x, const float* mea
                 "srgan_bn_relu_avgpool2_bwd geometry");
   const uint32_t items = ((uint32_t)H >> 1) * ((uint32_t)W >> 2);
   dim3 grid((items + POOL_BWD_QUADS - 1) / POOL_BWD_QUADS, (unsigned)(N * C), 1);
+  unsigned int* tickets = nullptr;
+  float* partial = g_gamma ? row_finish_workspace(C, (int)(grid.x * N), 2, g_pool_finish_tickets, (hipStream_t)stream, &tickets) : nullptr;
   hipLaunchKernelGGL(bn_relu_avgpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, x, mean, inv_std, gamma, beta, gx,
-                     g_gamma, g_beta, C, H, W);
+                     g_gamma, g_beta, C, H, W, partial, tickets);
   return launch_status();
 }
 

@@ -6,6 +6,7 @@
 // per-example norms, full sums), through workspace partials that the row's last workgroup adds in a fixed order.
 // Roofline: HBM; algorithmic bytes = 4 * elements read per operand.
 #include "common.h"
+#include "split_finish.h"
 #include <string.h>
 
 namespace srgan {
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(256) void chan_reduce_rows_kernel(const float* __re
 // usual tree -- and writes (or adds to) out[c].  No zero-fill launch in front, no fp32 atomics: two runs give the same bits,
 // whatever else is in flight.  The tickets are device globals, one set per registered (device, stream) workspace -- launches
 // on a stream are ordered, streams do not share a set -- and the last workgroup puts its row's back to zero.
-constexpr int ROW_TICKETS = 64, TICKET_SETS = 64;
+constexpr int ROW_TICKETS = 2048, TICKET_SETS = 64;      // (round 5: 2048 rows -- bias / parameter sums of wide layers take the ordered form too)
 __device__ unsigned int g_row_tickets[TICKET_SETS * ROW_TICKETS];
+
+__device__ unsigned int g_reduce_finish_tickets[SPLIT_TICKET_SETS * ROW_FINISH_ROWS];
 
 __global__ __launch_bounds__(256) void chan_reduce_rows_ordered_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                        const float* __restrict__ mean,
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
                                                               float* __restrict__ out_gamma,
                                                               float* __restrict__ out_beta, int N, int C, int64_t HW,
                                                               int64_t g_bs, int64_t x_bs, int64_t gx_bs, int accumulate,
-                                                              int unscaled, int images_per_block) {
+                                                              int unscaled, int images_per_block, float* finish_partial,
+                                                              unsigned int* finish_tickets) {
   // One workgroup = channel c of images [n0, n1): several images per workgroup when the planes are small (a
   // 16 x 16 plane is one float4 per four lanes), so that every launch has ~1024 workgroups of useful size.
   __shared__ float scratch[4];
@@ -241,6 +245,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_rows_kernel(const float* __res
   const float total_acc = block_sum_256(acc, scratch);
   __syncthreads();
   const float total_plain = block_sum_256(plain, scratch);
+  if (finish_partial) {      // ordered: the channel's image groups meet in a fixed order, ONE adder per channel (split_finish.h)
+    float v[2] = {total_acc, total_plain};
+    __syncthreads();
+    if (ordered_row_finish<2>(v, finish_partial + (int64_t)c * gridDim.y * 2, (int)blockIdx.y, (int)gridDim.y, finish_tickets + c,
+                              scratch)) {
+      out_gamma[c] += v[0] * inv_std[c];
+      out_beta[c] += v[1];
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     unsafeAtomicAdd(out_gamma + c, total_acc * inv_std[c]);
     unsafeAtomicAdd(out_beta + c, total_plain);
@@ -277,8 +291,11 @@ __global__ __launch_bounds__(256) void chan_reduce_cols_kernel(const float* __re
 //   w_scaled = w * a[ci]                        (the linearised forward runs on the masked UNSCALED tangent)
 //   w_grad  += q * a[ci]                        (q = weight gradient w.r.t. the scaled weights)
 //   gamma_grad[ci] += inv_std[ci] * sum_{co, tap} w * q
-// Lanes along the contiguous inner index; a workgroup covers 64 inner indices x 16 rows of CO (four row-lanes x four
-// independent iterations: the chain of dependent loads, not bandwidth, bounds this tiny kernel), combined through LDS.
+// Lanes along the contiguous inner index.  Round 5: a workgroup covers a span of inner indices that is a WHOLE number of
+// channels (64 - 64 % taps: 64 for the 1x1, 63 = 7 channels for the 3x3 convolutions) and ALL rows of CO -- 16 at a time, four
+// row-lanes x four independent iterations (the chain of dependent loads, not bandwidth, bounds this tiny kernel) -- so that a
+// channel's gamma gradient is completed inside ONE workgroup in a fixed order and added once: no atomics (round 4: one fp32
+// atomic per (channel, tap, 16-row block), in arrival order).
 constexpr int TW_ROWS = 16;
 __device__ __forceinline__ void tangent_weight_body(const float* __restrict__ w, const float* __restrict__ q,
                                                     const float* __restrict__ inv_std, const float* __restrict__ gamma,
@@ -286,39 +303,45 @@ __device__ __forceinline__ void tangent_weight_body(const float* __restrict__ w,
                                                     float* __restrict__ gamma_grad, int CO, int inner, int taps,
                                                     float (*scratch)[64]) {
   const int jl = (int)threadIdx.x & 63, cl = (int)threadIdx.x >> 6;
-  const int j = (int)blockIdx.x * 64 + jl;
-  const bool live = j < inner;
+  const int span = 64 - 64 % taps;                              // (taps <= 64, checked by the launchers)
+  const int j = (int)blockIdx.x * span + jl;
+  const bool live = jl < span && j < inner;
   const int ci = live ? j / taps : 0;
   const float a = __fmul_rn(inv_std[ci], gamma[ci]);
-  const int co0 = (int)blockIdx.y * TW_ROWS + cl;
-  float wv[TW_ROWS / 4], qv[TW_ROWS / 4], gv[TW_ROWS / 4];
-#pragma unroll
-  for (int e = 0; e < TW_ROWS / 4; ++e) {                     // all loads first
-    const int co = co0 + 4 * e;
-    const bool ok = live && co < CO;
-    const int64_t at = ok ? (int64_t)co * inner + j : 0;
-    wv[e] = ok ? w[at] : 0.f;
-    qv[e] = (ok && q) ? q[at] : 0.f;
-    gv[e] = (ok && q) ? w_grad[at] : 0.f;
-  }
   float dot = 0.f;
+  for (int row0 = 0; row0 < CO; row0 += TW_ROWS) {
+    const int co0 = row0 + cl;
+    float wv[TW_ROWS / 4], qv[TW_ROWS / 4], gv[TW_ROWS / 4];
 #pragma unroll
-  for (int e = 0; e < TW_ROWS / 4; ++e) {
-    const int co = co0 + 4 * e;
-    if (!live || co >= CO) continue;
-    const int64_t at = (int64_t)co * inner + j;
-    if (w_scaled) w_scaled[at] = wv[e] * a;
-    if (q) {
-      w_grad[at] = gv[e] + qv[e] * a;
-      dot = fmaf(wv[e], qv[e], dot);
+    for (int e = 0; e < TW_ROWS / 4; ++e) {                     // all loads first
+      const int co = co0 + 4 * e;
+      const bool ok = live && co < CO;
+      const int64_t at = ok ? (int64_t)co * inner + j : 0;
+      wv[e] = ok ? w[at] : 0.f;
+      qv[e] = (ok && q) ? q[at] : 0.f;
+      gv[e] = (ok && q) ? w_grad[at] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < TW_ROWS / 4; ++e) {
+      const int co = co0 + 4 * e;
+      if (!live || co >= CO) continue;
+      const int64_t at = (int64_t)co * inner + j;
+      if (w_scaled) w_scaled[at] = wv[e] * a;
+      if (q) {
+        w_grad[at] = gv[e] + qv[e] * a;
+        dot = fmaf(wv[e], qv[e], dot);
+      }
     }
   }
   if (q == nullptr) return;
-  scratch[cl][jl] = dot;
+  scratch[cl][jl] = live ? dot : 0.f;
   __syncthreads();
-  if (cl != 0 || !live) return;
-  dot = (scratch[0][jl] + scratch[1][jl]) + (scratch[2][jl] + scratch[3][jl]);
-  unsafeAtomicAdd(gamma_grad + ci, dot * inv_std[ci]);
+  if (cl == 0) scratch[0][jl] = (scratch[0][jl] + scratch[1][jl]) + (scratch[2][jl] + scratch[3][jl]);     // (own column only)
+  __syncthreads();
+  if (cl != 0 || !live || j % taps != 0) return;                // the thread of a channel's first tap adds its taps in order
+  float total = scratch[0][jl];
+  for (int t = 1; t < taps; ++t) total += scratch[0][jl + t];   // (the span holds whole channels: jl + t < span)
+  gamma_grad[ci] += total * inv_std[ci];
 }
 
 __global__ __launch_bounds__(256) void tangent_weight_kernel(const float* __restrict__ w, const float* __restrict__ q,
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(256) void tangent_weight_grouped_kernel(const Tange
                                                                      const float* __restrict__ q_base) {
   __shared__ float scratch[4][64];
   const TangentWeightJob job = jobs[blockIdx.z];
-  if ((int64_t)blockIdx.x * 64 >= job.inner || (int)blockIdx.y * TW_ROWS >= job.CO) return;       // (workgroup-uniform)
+  if ((int64_t)blockIdx.x * (64 - 64 % job.taps) >= job.inner) return;                                // (workgroup-uniform)
   tangent_weight_body(job.w, q_base ? q_base + job.offset : nullptr, job.inv_std, job.gamma,
                       scaled_base ? scaled_base + job.offset : nullptr, job.w_grad, job.gamma_grad, job.CO, job.inner,
                       job.taps, scratch);
@@ -379,7 +402,8 @@ __global__ __launch_bounds__(256) void nearest_bin_onehot_kernel(const float* __
 // rows[b] += sum_{hw} (1/Cm) * sum_c |maps[b,c,hw] - target[b,hw]|      (reference crowd/srgan.py:252)
 __global__ __launch_bounds__(256) void crowd_map_l1_kernel(const float* __restrict__ maps,
                                                            const float* __restrict__ target, float* __restrict__ rows,
-                                                           int Cm, int64_t HW, int segs) {
+                                                           int Cm, int64_t HW, int segs, float* finish_partial,
+                                                           unsigned int* finish_tickets) {
   __shared__ float scratch[4];
   const int b = blockIdx.x, seg = blockIdx.y;
   const int64_t beg = (int64_t)seg * RED_SEG, end = beg + RED_SEG < HW ? beg + RED_SEG : HW;
@@ -391,6 +415,12 @@ __global__ __launch_bounds__(256) void crowd_map_l1_kernel(const float* __restri
     acc += s / (float)Cm;
   }
   const float total = block_sum_256(acc, scratch);
+  if (finish_partial) {      // ordered: an example's segments meet in a fixed order (this sum IS the labeled loss's map term)
+    float v[1] = {total};
+    __syncthreads();
+    if (ordered_row_finish<1>(v, finish_partial + (int64_t)b * segs, seg, segs, finish_tickets + b, scratch)) rows[b] += v[0];
+    return;
+  }
   if (threadIdx.x == 0) unsafeAtomicAdd(rows + b, total);
 }
 
@@ -460,15 +490,16 @@ int srgan_bn_conv_tangent_weights(const float* w, const float* q, const float* i
   SRGAN_REQUIRE(q == nullptr || (w_grad && gamma_grad), SRGAN_EINVAL, "srgan_bn_conv_tangent_weights gradient outputs");
   const int64_t inner = (int64_t)CI * taps;
   SRGAN_REQUIRE(inner < ((int64_t)1 << 31), SRGAN_ERANGE, "srgan_bn_conv_tangent_weights size");
-  hipLaunchKernelGGL(tangent_weight_kernel, dim3((unsigned)((inner + 63) / 64), (unsigned)((CO + TW_ROWS - 1) / TW_ROWS)),
-                     dim3(256), 0, (hipStream_t)stream, w, q, inv_std, gamma, w_scaled, w_grad, gamma_grad, CO, (int)inner,
-                     taps);
+  SRGAN_REQUIRE(taps <= 64, SRGAN_EUNSUPPORTED, "srgan_bn_conv_tangent_weights: at most 64 taps");
+  const int span = 64 - 64 % taps;              // whole channels per workgroup, every row of CO: see tangent_weight_body
+  hipLaunchKernelGGL(tangent_weight_kernel, dim3((unsigned)((inner + span - 1) / span), 1), dim3(256), 0, (hipStream_t)stream, w, q,
+                     inv_std, gamma, w_scaled, w_grad, gamma_grad, CO, (int)inner, taps);
   return launch_status();
 }
 
 int srgan_bn_conv_tangent_weights_job(const float* w, const float* inv_std, const float* gamma, float* w_grad,
                                       float* gamma_grad, int64_t offset, int32_t CO, int32_t CI, int32_t taps, void* job) {
-  SRGAN_REQUIRE(w && inv_std && gamma && job && offset >= 0 && CO > 0 && CI > 0 && taps > 0, SRGAN_EINVAL,
+  SRGAN_REQUIRE(w && inv_std && gamma && job && offset >= 0 && CO > 0 && CI > 0 && taps > 0 && taps <= 64, SRGAN_EINVAL,
                 "srgan_bn_conv_tangent_weights_job arguments");
   const int64_t inner = (int64_t)CI * taps;
   SRGAN_REQUIRE(inner < ((int64_t)1 << 31), SRGAN_ERANGE, "srgan_bn_conv_tangent_weights_job size");
@@ -483,9 +514,8 @@ int srgan_bn_conv_tangent_weights_grouped(const void* jobs, int32_t count, int32
                                           const float* q_base, void* stream) {
   SRGAN_REQUIRE(jobs && count >= 1 && count <= 65535 && max_inner >= 1 && max_co >= 1 && (scaled_base || q_base), SRGAN_EINVAL,
                 "srgan_bn_conv_tangent_weights_grouped arguments");
-  const unsigned rows = (unsigned)((max_co + TW_ROWS - 1) / TW_ROWS);
-  SRGAN_REQUIRE(rows <= 65535, SRGAN_ERANGE, "srgan_bn_conv_tangent_weights_grouped grid");
-  hipLaunchKernelGGL(tangent_weight_grouped_kernel, dim3((unsigned)((max_inner + 63) / 64), rows, (unsigned)count), dim3(256), 0,
+  // (a job's span of inner indices per workgroup is 64 - 64 % taps >= 33: the grid covers the smallest)
+  hipLaunchKernelGGL(tangent_weight_grouped_kernel, dim3((unsigned)((max_inner + 32) / 33), 1, (unsigned)count), dim3(256), 0,
                      (hipStream_t)stream, reinterpret_cast<const TangentWeightJob*>(jobs), scaled_base, q_base);
   return launch_status();
 }
@@ -508,12 +538,15 @@ int srgan_bn_act_bwd(const float* g, const float* x, const float* mean, const fl
          (int64_t)C * ((N + 2 * per - 1) / (2 * per)) >= 1024)
     per *= 2;
   const int blocks_n = (N + per - 1) / per;
+  unsigned int* tickets = nullptr;
+  float* partial = (g_gamma && blocks_n > 1) ? row_finish_workspace(C, blocks_n, 2, g_reduce_finish_tickets, (hipStream_t)stream, &tickets)
+                                             : nullptr;
   if (relu) hipLaunchKernelGGL(bn_act_bwd_rows_kernel<true>, dim3(C, blocks_n), dim3(256), 0, (hipStream_t)stream, g, x,
                                mean, inv_std, gamma, beta, gx, g_gamma, g_beta, N, C, HW, g_bs, x_bs, gx_bs, accumulate_gx,
-                               unscaled, per);
+                               unscaled, per, partial, tickets);
   else hipLaunchKernelGGL(bn_act_bwd_rows_kernel<false>, dim3(C, blocks_n), dim3(256), 0, (hipStream_t)stream, g, x, mean,
                           inv_std, gamma, beta, gx, g_gamma, g_beta, N, C, HW, g_bs, x_bs, gx_bs, accumulate_gx, unscaled,
-                          per);
+                          per, partial, tickets);
   return launch_status();
 }
 
@@ -536,7 +569,9 @@ int srgan_crowd_map_l1_fwd(const float* maps, const float* target, float* rows, 
   hipStream_t s = (hipStream_t)stream;
   const int segs = (int)((HW + RED_SEG - 1) / RED_SEG);
   if (const int status = zero_floats(rows, B, s)) return status;
-  hipLaunchKernelGGL(crowd_map_l1_kernel, dim3(B, segs), dim3(256), 0, s, maps, target, rows, Cm, HW, segs);
+  unsigned int* tickets = nullptr;
+  float* partial = segs > 1 ? row_finish_workspace(B, segs, 1, g_reduce_finish_tickets, s, &tickets) : nullptr;
+  hipLaunchKernelGGL(crowd_map_l1_kernel, dim3(B, segs), dim3(256), 0, s, maps, target, rows, Cm, HW, segs, partial, tickets);
   return launch_status();
 }
 

@@ -60,6 +60,44 @@ __device__ __forceinline__ bool split_finish_ordered(float* ws_tile, int split, 
   return true;
 }
 
+// The same idea for a few SCALARS per workgroup that several workgroups add into one output row (the two parameter sums of
+// a batch-norm backward per channel, a per-example loss sum).  Called by ALL 256 threads of the workgroup; thread 0 holds the
+// workgroup's V values.  `partial_row` = the row's [parts][V] slots in the workspace, `ticket` = the row's ticket.  Returns true
+// in thread 0 of the workgroup that drew the last ticket, with v = the sum over all parts: thread t adds the parts t, t + 256,
+// ... and the 256 sums meet in the fixed tree of block_sum_256 -- the same order on every run, and no thread walks the parts
+// alone (a single thread reading 768 parts one acknowledged load at a time cost 2 ms per launch).  The caller then adds v to
+// the output: one adder per row and launch, no atomics on data.
+template <int V>
+__device__ __forceinline__ bool ordered_row_finish(float (&v)[V], float* partial_row, int part, int parts, unsigned int* ticket,
+                                                   float* scratch4) {
+  if (parts == 1) return threadIdx.x == 0;
+  __shared__ int row_finish_last;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) __hip_atomic_store(partial_row + part * V + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    row_finish_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1);
+  }
+  __syncthreads();
+  if (!row_finish_last) return false;
+  float mine[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) mine[i] = 0.f;
+  for (int s = (int)threadIdx.x; s < parts; s += 256)
+#pragma unroll
+    for (int i = 0; i < V; ++i) mine[i] += __hip_atomic_load(partial_row + s * V + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    __syncthreads();                      // (scratch4 is reused)
+    const float total = block_sum_256(mine[i], scratch4);
+    if (threadIdx.x == 0) v[i] = total;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return threadIdx.x == 0;
+}
+
+constexpr int ROW_FINISH_ROWS = 4096;       // output rows (channels / examples) per launch that can use ordered_row_finish
+
 // Host side: the workspace region and the ticket row of a split launch, or nullptr when the ordered finish cannot be used
 // (no workspace registered for the stream, too many tiles / bytes, or SRGAN_ATOMIC_SPLIT=1: the round-4 atomics).
 float* partial_workspace(size_t bytes, hipStream_t stream);
@@ -96,6 +134,20 @@ inline float* split_workspace(int64_t tiles, int splits, int64_t floats_per_tile
   if (!base) return nullptr;
   *ticket_set = set;
   return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + offset_bytes);
+}
+
+// Host side of ordered_row_finish: the [rows][parts][V] region and the launch's ticket row (tickets: a device array of
+// SPLIT_TICKET_SETS * ROW_FINISH_ROWS of the caller's translation unit), or nullptr (no workspace / too many rows / atomics forced).
+template <typename Symbol>
+inline float* row_finish_workspace(int64_t rows, int parts, int values, const Symbol& tickets, hipStream_t stream, unsigned int** ticket_row) {
+  if (split_atomics_forced() || rows > ROW_FINISH_ROWS || parts < 1) return nullptr;
+  const int set = workspace_index(stream);
+  if (set < 0 || set >= SPLIT_TICKET_SETS) return nullptr;
+  float* base = partial_workspace((size_t)rows * parts * values * sizeof(float), stream);
+  unsigned int* all = base ? device_tickets(tickets) : nullptr;
+  if (!base || !all) return nullptr;
+  *ticket_row = all + (size_t)set * ROW_FINISH_ROWS;
+  return base;
 }
 
 }  // namespace srgan

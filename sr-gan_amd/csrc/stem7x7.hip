@@ -14,6 +14,7 @@
 //             atomic pass per workgroup.
 // Roofline: fp32 MFMA (157.3 TF/s): 2 * 147 * 64 FLOP per output pixel, against 4 * (3 * 4 + 64) B of HBM traffic.
 #include "common.h"
+#include "split_finish.h"
 #include <stdlib.h>
 
 namespace srgan {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_fwd_kernel(const StemParams p)
 constexpr int ST_NJ = 5;                             // 5 column blocks of 32 cover the 147 weight positions
 // (32 output channels per workgroup, blockIdx.y selects the 32-channel block: with 64 the 2 x 5 accumulator tiles plus the
 // staged registers spill)
-__global__ __launch_bounds__(256, 2) void stem7x7_wgrad_kernel(const StemParams p) {
+__global__ __launch_bounds__(256, 2) void stem7x7_wgrad_kernel(const StemParams p, float* __restrict__ partial) {
   constexpr int MI = 1;
   constexpr int BM = MI * 32, LDG = ST_TH * ST_TW + 1;
   const int co0 = (int)blockIdx.y * BM;
@@ -238,10 +239,29 @@ __global__ __launch_bounds__(256, 2) void stem7x7_wgrad_kernel(const StemParams 
     }
   }
   __syncthreads();
+  if (partial) {        // round 5, ordered: this walker's [32][147] block goes to the workspace; stem7x7_wgrad_finish_kernel adds
+    float* mine = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (BM * 147);      // the walkers in walker order
+    for (int idx = tid; idx < BM * 147; idx += 256) mine[idx] = red[(idx / 147) * LDR + idx % 147];
+    return;
+  }
   for (int idx = tid; idx < BM * 147; idx += 256) {
     const int co = idx / 147, j = idx - co * 147;
     if (co0 + co < p.K) unsafeAtomicAdd(p.gw + (int64_t)(co0 + co) * 147 + j, red[co * LDR + j]);
   }
+}
+
+// gw[32-channel block] += its walkers' blocks, added in walker order (blockIdx.y = channel block)
+__global__ __launch_bounds__(256) void stem7x7_wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw, int K,
+                                                                   int walkers) {
+  constexpr int BLOCK = 32 * 147;
+  const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (idx >= BLOCK) return;
+  const int co = (int)blockIdx.y * 32 + idx / 147;
+  if (co >= K) return;
+  const float* mine = partial + (int64_t)blockIdx.y * walkers * BLOCK + idx;
+  float total = mine[0];
+  for (int w = 1; w < walkers; ++w) total += mine[(int64_t)w * BLOCK];
+  gw[(int64_t)co * 147 + idx % 147] += total;
 }
 
 // gx[n, c, ih, iw] = sum_{co, kh, kw} gy[n, co, (ih + 3 - kh) / 2, (iw + 3 - kw) / 2] * w[co, c, kh, kw]   (exact divisions only)
@@ -405,9 +425,16 @@ int stem7x7_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t gy_
   SRGAN_REQUIRE((int64_t)N * p.tiles_y * p.tiles_x < ((int64_t)1 << 31), SRGAN_ERANGE, "stem grid");
   if (!accumulate) if (const int status = zero_floats(gw, (int64_t)K * 147, stream)) return status;
   static const int resident = getenv("SRGAN_STEM_WGRAD_WGS") ? atoi(getenv("SRGAN_STEM_WGRAD_WGS")) : 512;
-  const int grid = p.tiles < resident ? p.tiles : resident;
+  int grid = p.tiles < resident ? p.tiles : resident;
   const int slot = profile_bracket_begin(stream);
-  hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(grid, (K + 31) / 32), dim3(256), 0, stream, p);
+  const int co_blocks = (K + 31) / 32;
+  // ordered form: half the walkers (each keeps a 32 x 147 block in the workspace that the finish kernel re-reads)
+  const bool ordered = grid > 1 && !split_atomics_forced() && partial_workspace(1, stream) != nullptr;
+  if (ordered && grid > 256) grid = 256;
+  float* partial = ordered ? partial_workspace((size_t)co_blocks * grid * 32 * 147 * sizeof(float), stream) : nullptr;
+  hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(grid, co_blocks), dim3(256), 0, stream, p, partial);
+  if (partial)
+    hipLaunchKernelGGL(stem7x7_wgrad_finish_kernel, dim3((32 * 147 + 255) / 256, co_blocks), dim3(256), 0, stream, partial, gw, K, grid);
   const int status = launch_status();
   profile_bracket_end(slot, stream, K, 147, (int64_t)N * OH * OW, 11, 32, 160, grid, 0, 0, (int64_t)N * 3 * H * W);
   return status;

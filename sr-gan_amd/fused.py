@@ -177,6 +177,7 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent=None):
         slots = (ctypes.c_byte * (128 * len(layers)))()
         grid_x = grid_y = ragged = 0
         co_ci_taps = elements = 0
+        partial_at = 0                  # the problems' partial-tile regions, back to back in the stream's workspace (floats)
         for index, layer in enumerate(layers):
             cin = c0 + index * growth
             if size == 1:
@@ -198,18 +199,19 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent=None):
                 inv, mean = norm._inverse_std()
                 plan['keep'].append((inv, mean))
                 bn = _lib.BnRelu(mean.data.data_ptr(), inv.data.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr())
-            gx, gy, rg = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            gx, gy, rg, partial = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
             status = lib.srgan_wgrad_group_plan(desc, bn, x_offset, gy_offset, gw.data_ptr() if tangent is None else None,
                                                 0 if tangent is None else tangent['offsets'][index][0 if size == 1 else 1],
-                                                len(layers), ctypes.byref(slots, 128 * index), ctypes.byref(gx),
-                                                ctypes.byref(gy), ctypes.byref(rg))
+                                                len(layers), partial_at, ctypes.byref(slots, 128 * index), ctypes.byref(gx),
+                                                ctypes.byref(gy), ctypes.byref(rg), ctypes.byref(partial))
             if status != 0:
                 plans[key] = None
                 return None
+            partial_at += partial.value
             grid_x, grid_y, ragged = max(grid_x, gx.value), max(grid_y, gy.value), max(ragged, rg.value)
         table = torch.frombuffer(bytearray(bytes(slots)), dtype=torch.uint8).to(device)
         plan[size] = dict(table=table, count=len(layers), grid_x=grid_x, grid_y=grid_y, ragged=ragged, co_ci_taps=co_ci_taps,
-                          pixels=n * hw, elements=elements)
+                          pixels=n * hw, elements=elements, partial_floats=partial_at)
     plans[key] = plan
     return plan
 
@@ -217,7 +219,8 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent=None):
 def _run_wgrad_group(group, size, fused_bn, x_base, gy_base, gw_base, stream):
     F._call('srgan_wgrad_group_run', group['table'].data_ptr(), group['count'], size, group['grid_x'], group['grid_y'],
             group['ragged'], 1 if fused_bn else 0, x_base.data_ptr(), gy_base.data_ptr(),
-            gw_base.data_ptr() if gw_base is not None else None, group['co_ci_taps'], group['pixels'], group['elements'], stream)
+            gw_base.data_ptr() if gw_base is not None else None, group['co_ci_taps'], group['pixels'], group['elements'],
+            group['partial_floats'], stream)
 
 
 def _tangent_plan(layers, c0, growth, device):

@@ -268,7 +268,20 @@ class Experiment(ABC):
         if getattr(self.dp, 'abi', None) is None and torch.distributed.get_backend(self.dp.group) == 'nccl' and \
                 getattr(self.settings, 'step_graph_collectives', 'abi') == 'abi':
             self.dp.use_abi_collectives()
-        return getattr(self.dp, 'abi', None) is not None
+        if getattr(self.dp, 'abi', None) is None:
+            return False
+        # hipStreamEndCapture crashes (ROCm 7.0 runtime, measured round 5: a segmentation fault inside capture_end) when the
+        # capture holds the compute side streams AND the communication stream joined from several of them; one compute
+        # stream + the communication stream captures and replays correctly (tests/test_round5_gpu.py).  A data-parallel run
+        # that asks for the step graph therefore runs its chains on one stream.
+        for name in ('overlap_dnn_step', 'overlap_gradient_penalty', 'overlap_generator_forwards', 'wgrad_stream'):
+            if getattr(self.settings, name, False):
+                if not getattr(self, '_graph_streams_note', False):
+                    print('[srgan_amd] step_graph under data parallelism: side streams off (one compute stream + RCCL\'s)')
+                    self._graph_streams_note = True
+                self.join_dnn_stream()
+                setattr(self.settings, name, False)
+        return True
 
     def prepare_optimizers(self):
         """Adam for D (with coupled L2), G and DNN (reference srgan.py:131-138) on the flat arenas."""

@@ -43,7 +43,7 @@ def test_capabilities_and_build_identity(lib):
     assert caps.abi_version == lib.library().srgan_version() == 100
     assert caps.struct_bytes == ctypes.sizeof(lib.Capabilities) and caps.arch == b'gfx950'
     assert caps.dtypes == 0x7 and caps.features & 0x7 == 0x7
-    assert caps.workspace_bytes == lib.library().srgan_workspace_bytes() == 64 << 20
+    assert caps.workspace_bytes == lib.library().srgan_workspace_bytes() == 256 << 20      # (round 5: the partial tiles of every K split)
     assert caps.max_tensor_elements == 2 ** 31 - 1
     assert lib.library().srgan_build_id().decode() == _build.source_id() == _build.library_id()
     assert lib.library().srgan_capabilities(None, 0) == lib.EINVAL
@@ -70,7 +70,7 @@ def test_argument_errors_are_reported_before_any_device_work(lib):
     assert library.srgan_conv2d_fwd(ctypes.byref(wrong_dtype), 16, 16, None, 16, 0, None) == lib.EINVAL
     assert library.srgan_conv2d_bnrelu_supported(ctypes.byref(huge), 0) == 0
     assert library.srgan_set_workspace(16, 1024, None) == lib.EINVAL                              # smaller than required
-    assert library.srgan_set_workspace(8, 64 << 20, None) == lib.EINVAL                           # misaligned
+    assert library.srgan_set_workspace(8, 256 << 20, None) == lib.EINVAL                          # misaligned
     # the RCCL entry points check their arguments before they resolve / reach RCCL
     assert library.srgan_comm_unique_id(None) == lib.EINVAL
     assert library.srgan_comm_init(None, 1, 0, None) == lib.EINVAL

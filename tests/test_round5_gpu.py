@@ -310,9 +310,10 @@ def test_split_k_contractions_finish_in_a_fixed_order(pkg, case):
             with torch.cuda.stream(side):
                 sink.copy_(source)
         outputs = []
-        for launch in (lambda: F.conv2d(xv, wv, None, stride, padding),
-                       lambda: F.conv2d_backward_data(gv, wv, x.shape, stride, padding),
-                       lambda: F.conv2d_backward_weight(xv, gv, w.shape, stride, padding)):
+        pairs = ((stride, stride), (padding, padding))
+        for launch in (lambda: F.conv2d(xv, wv, None, *pairs),
+                       lambda: F.conv2d_backward_data(gv, wv, x.shape, *pairs),
+                       lambda: F.conv2d_backward_weight(xv, gv, w.shape, *pairs)):
             workspace.fill_(float('nan'))
             outputs.append(launch().data.clone())
         runs.append(outputs)
@@ -321,20 +322,33 @@ def test_split_k_contractions_finish_in_a_fixed_order(pkg, case):
         scale = float(want.abs().max())
         assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * scale, f'{what}: {name}'
     for iteration, outputs in enumerate(runs[1:], 1):
-        for got, first, name in zip(outputs[:2], runs[0][:2], ('forward', 'data gradient')):
+        for got, first, name in zip(outputs, runs[0], ('forward', 'data gradient', 'weight gradient')):
             assert torch.equal(got, first), f'{what}: {name} of run {iteration} differs from run 0'
 
 
-def test_losses_of_one_iteration_are_repeatable_across_schedules(pkg):
-    """The five losses an iteration computes BEFORE the discriminator's update (DNN, labeled, unlabeled, fake, gradient
-    penalty: functions of the weights, the batch and the draws through forward passes and data gradients only) are now the
-    same bits whether the chains run on one stream or on four -- round 4 saw the penalty move by up to 6e-4 between two runs
-    because split-K atomics in arrival order flipped ReLU masks (crowd 64 x 64, batch 2: every plane K-split)."""
+def test_an_iteration_is_bit_reproducible_across_runs_and_schedules(pkg):
+    """The reference's CPU path is bitwise repeatable; round 4's HIP path was not: K slices and parameter sums
+    met through fp32 atomics in arrival order, and a ReLU mask that flipped at rounding level moved the gradient penalty of
+    two runs by up to 6e-4.  Round 5: every K split, every grouped weight gradient and every parameter sum finishes in a
+    fixed order through the stream's workspace (csrc/split_finish.h) -- one full iteration (DNN step, discriminator step with
+    the gradient penalty, generator step, three Adam updates) at crowd 64 x 64, batch 2 (every plane K-split) gives the SAME
+    BITS in all six losses and in every updated weight, run after run, on one stream and on four; between the two schedules
+    the five losses computed before the discriminator's update are the same bits as well."""
     import test_parallel_gpu as parallel_tests
-    first, _ = parallel_tests._step(None)
-    again, _ = parallel_tests._step(None)
-    streamed, _ = parallel_tests._step(None, streams=True)
-    for key in ('dnn_loss', 'labeled_loss', 'unlabeled_loss', 'fake_loss', 'gradient_penalty'):
+    first, first_weights = parallel_tests._step(None)
+    again, again_weights = parallel_tests._step(None)
+    streamed, streamed_weights = parallel_tests._step(None, streams=True)
+    streamed_again, streamed_again_weights = parallel_tests._step(None, streams=True)
+    for key in first:
         assert first[key] == again[key], (key, first[key], again[key])
+        assert streamed[key] == streamed_again[key], (key, 'four streams, two runs', streamed[key], streamed_again[key])
+    # across schedules: the losses computed BEFORE the discriminator's update are functions of the weights, the batch and the
+    # draws alone; the generator loss comes after it, and on four streams the penalty chain's parameter gradients are added to
+    # the other three losses' as a block (srgan.py: gradients_into_alternate) -- another association of the same fp32 sum
+    for key in ('dnn_loss', 'labeled_loss', 'unlabeled_loss', 'fake_loss', 'gradient_penalty'):
         assert first[key] == streamed[key], (key, 'one stream vs four', first[key], streamed[key])
+    assert abs(first['generator_loss'] - streamed['generator_loss']) <= 1e-6 * abs(first['generator_loss'])
     assert first['gradient_penalty'] > 0.0
+    for key, value in first_weights.items():
+        assert np.array_equal(value, again_weights[key]), (key, 'two runs', float(np.abs(value - again_weights[key]).max()))
+        assert np.array_equal(streamed_weights[key], streamed_again_weights[key]), (key, 'four streams, two runs')
