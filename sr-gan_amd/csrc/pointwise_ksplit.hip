@@ -11,12 +11,6 @@
 // (the order of a sum is free as long as A and B agree on it) -- so the main loop has no LDS traffic and no barrier;
 // the next chunk is in flight while the current one is in the matrix pipe.  The four partial tiles are summed through
 // LDS at the end.  No memset, no atomics, the activations are read twice (once per 64-row tile of 128 rows).
-//
-// Round 5: the 32 pixels of a workgroup are 32 consecutive pixels of the FLAT pixel index f = n * HW + p of the batch, not of
-// one image -- a lane owns pixel f = 32 * group + lane wherever it lies (its image offset goes into the per-lane 32-bit
-// offset next to the pixel) -- so planes of any size take the kernel: the 14 x 14 and 7 x 7 planes of the reference's own
-// 224 x 224 patches (reference crowd/models.py:1131-1133: 196 and 49 pixels, not multiples of 32) used to go to the
-// streaming kernel with a ragged last group per image (7 groups for 6.125 of pixels; 2 for 1.53) and a K split over the grid.
 #include "common.h"
 #include <stdlib.h>
 
@@ -31,7 +25,7 @@ struct PwKsplitParams {
   const float* bias;
   int32_t N, K, M, HW;
   int64_t in_bs, out_bs;
-  int32_t total_pixels;   // N * HW: the flat pixel index f = n * HW + p runs over [0, total_pixels)
+  int32_t groups_per_image;
   int32_t accumulate;
   const float* bn_mean; const float* bn_inv; const float* bn_gamma; const float* bn_beta;   // PRO
 };
@@ -52,10 +46,9 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
   const int tid = (int)threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int group = (int)blockIdx.x;
+  const int n = group / p.groups_per_image;
+  const int pix0 = (group - n * p.groups_per_image) * 32;
   const int m0 = (int)blockIdx.y * ROWS;
-  // this lane's pixel of the flat index (clamped: a surplus lane of the last group reads a real pixel and is never stored)
-  const int flat = min(group * 32 + l31, p.total_pixels - 1);
-  const int n_lane = flat / p.HW, p_lane = flat - n_lane * p.HW;
 
   if (PRO) {
     for (int k = tid; k < p.K; k += 256) {
@@ -70,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
   const float* w_lane[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) w_lane[mi] = p.w + (int64_t)min(m0 + mi * 32 + l31, p.M - 1) * p.K + 16 * lhi;
-  const float* x_wave = p.in;
-  const uint32_t x_lane = (uint32_t)n_lane * (uint32_t)p.in_bs + (uint32_t)p_lane + 16u * (uint32_t)lhi * (uint32_t)p.HW;
+  const float* x_wave = p.in + (int64_t)n * p.in_bs + pix0;
+  const uint32_t x_lane = (uint32_t)l31 + 16u * (uint32_t)lhi * (uint32_t)p.HW;
 
   f32x16 acc[MI];
 #pragma unroll
@@ -133,9 +126,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDR + l31] = acc[mi][r];
   __syncthreads();
-  // (a thread's column is the same in every pass: idx & 31 == tid & 31 -- the pixel of lane l31 computed above)
-  const bool pixel_exists = group * 32 + l31 < p.total_pixels;
-  float* out_pixel = p.out + (int64_t)n_lane * p.out_bs + p_lane;
+  float* out_n = p.out + (int64_t)n * p.out_bs + pix0;
 #pragma unroll
   for (int e = 0; e < ROWS * 32 / 256; ++e) {
     const int idx = tid + 256 * e;
@@ -143,9 +134,9 @@ __global__ __launch_bounds__(256, 2) void pointwise_ksplit_kernel(const PwKsplit
     const int at = row * LDR + col;
     float v = (red[at] + red[ROWS * LDR + at]) + (red[2 * ROWS * LDR + at] + red[3 * ROWS * LDR + at]);
     const int o = m0 + row;
-    if (o >= p.M || !pixel_exists) continue;
+    if (o >= p.M) continue;
     if (p.bias) v += p.bias[o];
-    float* dst = out_pixel + (int64_t)o * p.HW;
+    float* dst = out_n + (int64_t)o * p.HW + col;
     if (p.accumulate == 1) *dst += v;
     else __builtin_nontemporal_store(v, dst);
   }
@@ -165,9 +156,9 @@ bool pointwise_ksplit_wanted(int32_t N, int32_t K, int32_t M, int32_t HW, bool f
   // measured (608 ... 992 -> 128 channels, batch 16): 16x16 planes 15.5 vs 26 us for the streaming kernel, 32x32 planes
   // 50 vs 46 us -- the strided weight rows of 1024 workgroups saturate the L2 -> CU path -- so only the smallest take it
   static const int max_groups = getenv("SRGAN_PKS_GROUPS") ? atoi(getenv("SRGAN_PKS_GROUPS")) : 256;
-  if (!pointwise_ksplit_enabled() || K % 32 != 0 || K < 256) return false;
+  if (!pointwise_ksplit_enabled() || K % 32 != 0 || K < 256 || HW % 32 != 0) return false;
   if (fused_bn && K > PKS_MAX_K) return false;
-  const int64_t groups = ((int64_t)N * HW + 31) / 32;          // (flat pixel index: planes of any size)
+  const int64_t groups = (int64_t)N * HW / 32;
   return groups * ((M + 127) / 128) <= max_groups;
 }
 
@@ -179,10 +170,8 @@ int pointwise_ksplit_run(const float* in, int64_t in_bs, const float* w, const f
   p.N = N; p.K = K; p.M = M; p.HW = HW; p.in_bs = in_bs; p.out_bs = out_bs; p.accumulate = accumulate;
   p.bn_mean = bn ? bn[0] : nullptr; p.bn_inv = bn ? bn[1] : nullptr;
   p.bn_gamma = bn ? bn[2] : nullptr; p.bn_beta = bn ? bn[3] : nullptr;
-  SRGAN_REQUIRE((int64_t)N * HW < ((int64_t)1 << 31) && (int64_t)N * in_bs < ((int64_t)1 << 32), SRGAN_ERANGE,
-                "pointwise (K split over waves) extent");
-  p.total_pixels = N * HW;
-  const int64_t groups = ((int64_t)p.total_pixels + 31) / 32;
+  p.groups_per_image = HW / 32;
+  const int64_t groups = (int64_t)N * p.groups_per_image;
   const int tiles_m = (M + PKS_MI * 32 - 1) / (PKS_MI * 32);
   SRGAN_REQUIRE(groups < ((int64_t)1 << 31) && tiles_m <= 65535, SRGAN_ERANGE, "pointwise (K split over waves) grid");
   SRGAN_REQUIRE(K % 32 == 0 && (((uintptr_t)w) & 15) == 0, SRGAN_EINVAL, "pointwise (K split over waves) weights");

@@ -93,8 +93,8 @@ CONV_CASES = [
     (2, 288, 16, 16, 100, 1, 1, (1, 1), (0, 0)),
     (4, 1024, 8, 8, 136, 1, 1, (1, 1), (0, 0)),
     (2, 192, 8, 32, 64, 1, 1, (1, 1), (0, 0)),
-    # the same kernel on planes that are no multiple of 32 pixels (round 5: a workgroup's 32 pixels are consecutive in the FLAT
-    # pixel index of the batch): the 14 x 14 and 7 x 7 planes of the reference's 224 x 224 patches, a last group of 4 pixels
+    # many input channels on planes that are no multiple of 32 pixels (the 14 x 14 and 7 x 7 planes of the reference's 224 x 224
+    # patches): the streaming kernel with ragged pixel groups and a K split finished in a fixed order
     (16, 256, 14, 14, 128, 1, 1, (1, 1), (0, 0)),
     (4, 1024, 7, 7, 128, 1, 1, (1, 1), (0, 0)),
     (3, 512, 14, 14, 136, 1, 1, (1, 1), (0, 0)),
@@ -482,8 +482,8 @@ def test_fused_batch_norm_convolutions(F):
                                       (16, 64, 64, 7, 7, 40, 1), (2, 34, 41, 9, 7, 20, 1),
                                       (2, 128, 128, 14, 14, 32, 3), (3, 128, 128, 7, 7, 32, 3), (2, 40, 57, 7, 9, 33, 3),
                                       (2, 128, 128, 28, 28, 32, 3),
-                                      # many input channels on ragged planes: the wave-split kernel on the flat pixel index
-                                      # (round 5), channel slices of a wider block buffer, a last group of 16 / 12 pixels
+                                      # many input channels on ragged planes (block 3 / 4 of the 224-pixel configuration), channel
+                                      # slices of a wider block buffer
                                       (16, 1024, 1056, 14, 14, 128, 1), (16, 896, 928, 7, 7, 128, 1), (3, 512, 640, 14, 14, 128, 1),
                                       # the LDS-DMA 1x1 kernel with the prologue: 64-pixel tile on a channel slice, 128-pixel
                                       # tile, two row tiles
