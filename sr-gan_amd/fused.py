@@ -145,7 +145,9 @@ def _reduce_plan(layers, n, c0, h, w, growth, buffer_bs, epilogue1, epilogue2, d
 
 GROUPED_WGRAD = not os.environ.get('SRGAN_NO_GROUPED_WGRAD')    # all the weight gradients of a block's backward in two launches (one table per kernel size)
 IN_PLACE_GRADIENT = not os.environ.get('SRGAN_NO_IN_PLACE_GRADIENT')
-GROUPED_TANGENT_LIMIT = int(os.environ.get('SRGAN_GROUPED_TANGENT_LIMIT_MB', '800')) << 20   # bytes of masked tangents kept
+# (round 5: 4096 MB -- with the ordered weight gradients a single-problem launch is two launches (workers + finish), so keeping
+# the masked tangents of the larger blocks for ONE grouped pair pays at 512 x 512 too: 83.7 vs 83.2 images/s; 800 MB before)
+GROUPED_TANGENT_LIMIT = int(os.environ.get('SRGAN_GROUPED_TANGENT_LIMIT_MB', '4096')) << 20   # bytes of masked tangents kept
 
 
 def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent=None):
