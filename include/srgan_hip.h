@@ -62,11 +62,13 @@ typedef struct srgan_capabilities_t {
   int64_t max_tensor_elements;  /* 2^31 - 1 */
 } srgan_capabilities_t;
 int srgan_capabilities(srgan_capabilities_t* out, int32_t out_bytes);
-/* Split-K launches with a tiny output (M*N < 512, >= 32 K-slices: the map heads' weight gradients) write their
- * partial tiles to a workspace and sum them in a second kernel (atomics from a thousand workgroups into a few cache
- * lines serialise in L2).  The caller owns that memory: register one block of >= srgan_workspace_bytes() bytes
- * (16-byte aligned, device memory) per (current device, stream) before the first contraction on that stream;
- * NULL unregisters.  Launches on one stream are ordered, so one block per stream is enough. */
+/* Every sum that several workgroups of one launch share -- the K slices of a split contraction, the workers of a weight
+ * gradient, per-channel parameter sums, per-example loss sums -- goes through a workspace: the workgroups leave their
+ * partial tiles there and the last one (or a second launch) adds them in a fixed order (round 5: no fp32 atomics on data,
+ * bit-reproducible results; round 2 used it only for tiny split-K outputs).  The caller owns that memory: register one
+ * block of >= srgan_workspace_bytes() bytes (256 MiB; 16-byte aligned, device memory) per (current device, stream) before
+ * the first launch on that stream; NULL unregisters.  Launches on one stream are ordered, so one block per stream is
+ * enough.  A stream without a workspace still computes: the sums then meet through fp32 atomics. */
 int64_t srgan_workspace_bytes(void);
 int srgan_set_workspace(void* workspace, int64_t bytes, void* stream);
 /* Round 5: a contraction that splits K over several workgroups (few output tiles: the small planes) finishes in a FIXED
