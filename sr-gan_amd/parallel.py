@@ -182,10 +182,10 @@ class _StreamWork:
 class AbiCommunicator:
     """The data-parallel collectives through the C ABI's RCCL entry points (include/srgan_hip.h, "collectives") instead of
     ``torch.distributed``: one RCCL communicator per rank, created from a unique id that rank 0 makes and the existing
-    process group hands to the others (the rendezvous a reference-side caller would do over its own channel).  The tiny
-    forward all-reduce of the feature sums runs on the caller's stream; gradient buckets run on ONE communication stream
-    (in issue order) that first waits for the compute stream, and return a work object whose ``wait()`` orders the current
-    stream behind them.  Device tensors only, fp32 or bf16."""
+    process group hands to the others (the rendezvous a reference-side caller would do over its own channel).  Every
+    collective runs on ONE communication stream (in issue order) that first waits for the issuing compute stream; gradient
+    buckets return a work object whose ``wait()`` orders the current stream behind them, the tiny forward all-reduce of the
+    feature sums is waited for at once.  Device tensors only, fp32 or bf16."""
 
     def __init__(self, dp):
         import ctypes
@@ -214,11 +214,12 @@ class AbiCommunicator:
         return 0 if tensor.dtype == torch.float32 else 1
 
     def all_reduce_sum_(self, tensor):
-        """In place, on the current stream (the feature sums: F floats)."""
-        self.calls += 1
-        self.check(self.lib.srgan_all_reduce_sum(self.comm, tensor.data_ptr(), tensor.data_ptr(), tensor.numel(),
-                                                 self._wire(tensor), torch.cuda.current_stream().cuda_stream),
-                   'srgan_all_reduce_sum')
+        """In place (the feature sums: F floats).  Issued on the communication stream like every other collective of this
+        communicator -- one communicator must not be driven from two streams at once, and a gradient bucket may be in flight
+        there -- and waited for at once: the current stream continues behind it."""
+        wire = self._wire(tensor)
+        self._on_communication_stream(lambda stream: self.check(self.lib.srgan_all_reduce_sum(
+            self.comm, tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), wire, stream), 'srgan_all_reduce_sum'), tensor).wait()
         return tensor
 
     def _on_communication_stream(self, launch, *tensors):
