@@ -352,3 +352,70 @@ def test_an_iteration_is_bit_reproducible_across_runs_and_schedules(pkg):
     for key, value in first_weights.items():
         assert np.array_equal(value, again_weights[key]), (key, 'two runs', float(np.abs(value - again_weights[key]).max()))
         assert np.array_equal(streamed_weights[key], streamed_again_weights[key]), (key, 'four streams, two runs')
+
+
+def _one_iteration(experiment_class, configure, size, batch, d_scale, overrides=None):
+    """Losses and updated weights of one dnn + gan iteration of a task experiment from seeded weights, inputs and draws."""
+    from srgan_amd.settings import Settings
+    from srgan_amd.utility import SummaryWriter, seed_all
+    from test_steps_gpu import finish_setup
+    settings = Settings()
+    settings.batch_size = batch
+    settings.matching_loss_multiplier, settings.contrasting_loss_multiplier = 1e2, 1e1
+    settings.gradient_penalty_multiplier = 1e2
+    for key, value in (overrides or {}).items():
+        setattr(settings, key, value)
+    experiment = experiment_class(settings)
+    configure(experiment)
+    seed_all(0)
+    experiment.model_setup()
+    with torch.no_grad():
+        for module in experiment.D.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.Linear)):
+                module.weight.mul_(d_scale)
+    experiment.dnn_summary_writer, experiment.gan_summary_writer = SummaryWriter(), SummaryWriter()
+    finish_setup(experiment)
+    height, width = (size, size) if isinstance(size, int) else size
+    generator = torch.Generator().manual_seed(1)
+    x = torch.rand(batch, 3, height, width, generator=generator) * 2 - 1
+    u = torch.rand(batch, 3, height, width, generator=generator) * 2 - 1
+    y = torch.rand(batch, generator=generator) * 85 + 10
+    experiment.injected_draws = {'z_d': torch.randn(batch, 256, generator=generator), 'z_g': torch.randn(batch, 256, generator=generator),
+                                 'alpha': torch.rand(batch, 1, 1, 1, generator=generator)}
+    experiment.dnn_training_step(x.cuda(), y.cuda(), 0)
+    experiment.gan_training_step(x.cuda(), y.cuda(), u.cuda(), 0)
+    experiment.join_dnn_stream()
+    torch.cuda.synchronize()
+    losses = {k: float(v.item()) for k, v in experiment.last_losses.items() if v is not None}
+    weights = {name: getattr(experiment, name)._srgan_arena.data.cpu().numpy().copy() for name in ('D', 'DNN', 'G')}
+    return losses, weights
+
+
+@pytest.mark.parametrize('task', ['driving', 'age-vgg', 'driving-fp16'])
+def test_other_configurations_are_bit_reproducible_too(pkg, monkeypatch, task):
+    """The DCGAN pair on 64 x 192 driving frames (every k4 / s2 convolution, transposed convolution and their weight gradients on
+    the generic kernel: ordered in-kernel finish, partial outputs + ordered reduce, lanes-along-K) in fp32 and in its named
+    fp16 mode, and the age task's VGG-16 discriminator at 64 x 64 (3x3 kernels, linear layers): two runs of one iteration give
+    the same bits in every loss and every updated weight (BASELINE.json configs 2 and 5; the reference's CPU path is
+    repeatable)."""
+    if task.startswith('driving'):
+        from srgan_amd.driving.srgan import DrivingExperiment as experiment_class
+        size, batch, d_scale = (64, 192), 8, 2.2
+
+        def configure(experiment):
+            experiment.image_size = size
+    else:
+        import srgan_amd.age.srgan as age
+        monkeypatch.setattr(age, 'model_architecture', 'vgg')
+        experiment_class, size, batch, d_scale = age.AgeExperiment, 64, 4, 1.3
+
+        def configure(experiment):
+            experiment.image_size = 64
+    overrides = dict(compute_dtype='f16', gradient_penalty_dtype='f32', loss_scale=256.0) if task.endswith('fp16') else None
+    first, first_weights = _one_iteration(experiment_class, configure, size, batch, d_scale, overrides)
+    again, again_weights = _one_iteration(experiment_class, configure, size, batch, d_scale, overrides)
+    assert first['gradient_penalty'] > 0.0 and all(np.isfinite(v) for v in first.values())
+    for key in first:
+        assert first[key] == again[key], (task, key, first[key], again[key])
+    for name in first_weights:
+        assert np.array_equal(first_weights[name], again_weights[name]), (task, name, float(np.abs(first_weights[name] - again_weights[name]).max()))
