@@ -170,10 +170,14 @@ int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int3
  * convolutions of a dense block's backward: reference crowd/models.py:335-353 through loss.backward()) in ONE launch.
  * srgan_wgrad_group_plan fills one 128-byte table slot per problem on the host -- x / gy are ELEMENT OFFSETS from two base
  * pointers given at launch time, gw and the batch-norm vectors are absolute, the gradient is ACCUMULATED into gw -- and
- * returns the grid extent the problem needs and whether it needs the ragged kernel variant; the caller uploads the table
- * once (it does not change between steps when the offsets are relative to per-step buffers) and launches with the maxima
- * over the group.  All problems of a group share the plane size; group_size (the number of problems that will be launched
- * together) lets the plan give each problem fewer workgroups of its own.  bn == NULL plans the plain weight gradient
+ * returns the grid extent the problem needs and, in *ragged, the kernel variant the slot was planned for as a bit (3x3: 0 / 1 =
+ * the ragged variant; 1x1: 1 = the LDS-staged 128 x 128 tiles, 2 = the register-streamed 64 x 64 tiles, 4 = their ragged
+ * variant); the caller uploads the table once (it does not change between steps when the offsets are relative to per-step
+ * buffers) and launches with the maxima of the grid extents and the OR of the variants over the group (a group whose slots
+ * were planned for both 1x1 forms is served by one launch each).  All problems of a group share the plane size; group_size
+ * (the number of problems that will be launched together) lets the plan give each problem fewer workgroups of its own, and
+ * group_weights (the sum of CO x CI x taps over the group, 0 = not known) lets it share them out by work instead of in equal
+ * parts (the staged 1x1 form: the same K range per worker whatever the problem's width).  bn == NULL plans the plain weight gradient
  * (x used as is; srgan_wgrad_group_run with fused_bn = 0): the double backward's gradients w.r.t. the scaled weights.
  * gw == NULL: the gradient goes to gw_base + gw_offset of the launch (a per-step buffer) instead of a fixed address.  sum_co_ci_taps / pixels / operand_elements only feed
  * the profile (logical FLOPs = 2 * sum_co_ci_taps * pixels; elements of x and gy read once).
@@ -183,8 +187,8 @@ int srgan_bn_partial_reduce_batched(const srgan_bn_reduce_job* jobs_device, int3
  * problems of the group returned, and srgan_wgrad_group_run gets the group's total (0, a total beyond the workspace, or no
  * workspace on the stream: fp32 atomics as before). */
 int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
-                           int64_t gw_offset, int32_t group_size, int64_t partial_offset, void* job, int32_t* grid_x,
-                           int32_t* grid_y, int32_t* ragged, int64_t* partial_floats);
+                           int64_t gw_offset, int32_t group_size, int64_t group_weights, int64_t partial_offset, void* job,
+                           int32_t* grid_x, int32_t* grid_y, int32_t* ragged, int64_t* partial_floats);
 int srgan_wgrad_group_run(const void* jobs, int32_t count, int32_t kernel_size, int32_t grid_x, int32_t grid_y, int32_t ragged,
                           int32_t fused_bn, const float* x_base, const float* gy_base, float* gw_base, int64_t sum_co_ci_taps,
                           int64_t pixels, int64_t operand_elements, int64_t partial_floats, void* stream);

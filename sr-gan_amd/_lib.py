@@ -102,7 +102,7 @@ SIGNATURES = {
     'srgan_crowd_extract_patches': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     'srgan_bn_conv_tangent_weights_job': ([vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], ctypes.c_int),
     'srgan_bn_conv_tangent_weights_grouped': ([vp, i32, i32, i32, vp, vp, vp], ctypes.c_int),
-    'srgan_wgrad_group_plan': ([ctypes.POINTER(ConvDesc), ctypes.POINTER(BnRelu), i64, i64, vp, i64, i32, i64, vp, ctypes.POINTER(i32),
+    'srgan_wgrad_group_plan': ([ctypes.POINTER(ConvDesc), ctypes.POINTER(BnRelu), i64, i64, vp, i64, i32, i64, i64, vp, ctypes.POINTER(i32),
                                 ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i64)], ctypes.c_int),
     'srgan_wgrad_group_run': ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, i64, i64, vp], ctypes.c_int),
     'srgan_adam_step': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp], ctypes.c_int),

@@ -907,8 +907,8 @@ int pointwise_wgrad_run(const float* x, int64_t x_bs, const float* gy, int64_t g
                         int32_t CO, int32_t HW, int accumulate, hipStream_t stream, const float* const* bn = nullptr);
 
 int pointwise_wgrad_group_plan(int64_t x_off, int64_t x_bs, int64_t gy_off, int64_t gy_bs, float* gw, int64_t gw_off, int32_t N, int32_t CI,
-                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, int64_t partial_offset, void* job_out,
-                               int32_t* grid_x, int32_t* grid_y, int32_t* ragged, int64_t* partial_floats);
+                               int32_t CO, int32_t HW, const float* const* bn, int32_t group, int64_t group_weights, int64_t partial_offset,
+                               void* job_out, int32_t* grid_x, int32_t* grid_y, int32_t* ragged, int64_t* partial_floats);
 int pointwise_wgrad_group_run(const void* jobs, int32_t count, int32_t grid_x, int32_t grid_y, int32_t ragged, int32_t fused_bn,
                               const float* x_base, const float* gy_base, float* gw_base, int64_t flops_mn, int64_t pixels,
                               int64_t elements, int64_t partial_floats, hipStream_t stream);
@@ -1298,12 +1298,12 @@ int srgan_conv2d_bwd_weight_bnrelu(const srgan_conv_desc* desc, const float* x, 
 
 // ---- grouped weight gradients: all the norm -> relu -> conv weight gradients of a dense block's backward in two launches
 int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn, int64_t x_offset, int64_t gy_offset, float* gw,
-                           int64_t gw_offset, int32_t group_size, int64_t partial_offset, void* job, int32_t* grid_x, int32_t* grid_y,
-                           int32_t* ragged, int64_t* partial_floats) {
+                           int64_t gw_offset, int32_t group_size, int64_t group_weights, int64_t partial_offset, void* job, int32_t* grid_x,
+                           int32_t* grid_y, int32_t* ragged, int64_t* partial_floats) {
   ConvGeom g;
   SRGAN_GEOM(desc, g, "srgan_wgrad_group_plan");
   SRGAN_REQUIRE(job && grid_x && grid_y && ragged && partial_floats && (bn == nullptr || bn_ok(bn)) && x_offset >= 0 &&
-                gy_offset >= 0 && gw_offset >= 0 && partial_offset >= 0 && group_size >= 1, SRGAN_EINVAL,
+                gy_offset >= 0 && gw_offset >= 0 && partial_offset >= 0 && group_size >= 1 && group_weights >= 0, SRGAN_EINVAL,
                 "srgan_wgrad_group_plan arguments");
   SRGAN_REQUIRE(srgan_conv2d_bnrelu_supported(desc, 2), SRGAN_EUNSUPPORTED, "srgan_wgrad_group_plan geometry support");
   const float* const coefficients[4] = {bn ? bn->mean : nullptr, bn ? bn->inv_std : nullptr, bn ? bn->gamma : nullptr,
@@ -1311,7 +1311,7 @@ int srgan_wgrad_group_plan(const srgan_conv_desc* desc, const srgan_bn_relu* bn,
   const float* const* fused = bn ? coefficients : nullptr;
   if (pointwise(g))
     return pointwise_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, gw_offset, g.N, g.C, g.K, g.H * g.W, fused,
-                                      group_size, partial_offset, job, grid_x, grid_y, ragged, partial_floats);
+                                      group_size, group_weights, partial_offset, job, grid_x, grid_y, ragged, partial_floats);
   return conv3x3_wgrad_group_plan(x_offset, g.x_bs, gy_offset, g.y_bs, gw, gw_offset, g.N, g.C, g.K, g.H, g.W, fused, group_size,
                                   partial_offset, job, grid_x, grid_y, ragged, partial_floats);
 }

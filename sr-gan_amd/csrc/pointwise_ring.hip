@@ -27,6 +27,7 @@
 // gradient).
 #include <atomic>
 #include "common.h"
+#include "lds_dma.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -53,27 +54,6 @@ struct RingParams {
   const float* epi_x; int64_t epi_x_bs;
   float* epi_partial; int32_t epi_cols;
 };
-
-// 64 lanes x 16 bytes from (scalar base + per-lane 32-bit byte offset) to LDS at the wave-uniform byte address `lds_dst` +
-// lane * 16.  M0 carries the LDS base and is compiler-reserved: saved and restored inside the statement; the s_nop is the
-// wait state between the M0 write and the DMA (guide 5.7).
-__device__ __forceinline__ void ring_glds16(const void* base, uint32_t lane_byte_offset, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(lane_byte_offset), "s"(base), "s"(lds_dst) : "memory");
-}
-// 64 lanes x 4 bytes from per-lane 64-bit addresses (the four batch-norm vectors of a stage into one table).
-__device__ __forceinline__ void ring_glds4(const float* lane_pointer, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(lane_pointer), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void ring_wait_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
-}
-__device__ __forceinline__ uint32_t ring_lds_address(const void* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
 
 // NI: 32-pixel column blocks per wave (4: 128-pixel tile; 2 / 1: 64- / 32-pixel tiles for launches with few pixel blocks).
 // FUSE: 0 plain, 1 batch-norm + ReLU prologue on the activations, 2 batch-norm + ReLU backward epilogue (NI = 4).

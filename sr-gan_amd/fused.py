@@ -177,9 +177,11 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent=None):
     plan['u1_offsets'], plan['u1_total'] = u1_offsets, u1_at
     for size in (1, 3):
         slots = (ctypes.c_byte * (128 * len(layers)))()
-        grid_x = grid_y = ragged = 0
+        grid_x = grid_y = ragged = 0            # (ragged: the OR of the kernel variants the problems were planned for)
         co_ci_taps = elements = 0
         partial_at = 0                  # the problems' partial-tile regions, back to back in the stream's workspace (floats)
+        # what the group holds (sum of CO x CI x taps): the plan shares the launch's workgroups out by work
+        weights = sum(width * (c0 + i * growth) if size == 1 else growth * width * 9 for i in range(len(layers)))
         for index, layer in enumerate(layers):
             cin = c0 + index * growth
             if size == 1:
@@ -204,13 +206,13 @@ def _wgrad_plan(layers, n, c0, h, w, growth, buffer_bs, device, tangent=None):
             gx, gy, rg, partial = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
             status = lib.srgan_wgrad_group_plan(desc, bn, x_offset, gy_offset, gw.data_ptr() if tangent is None else None,
                                                 0 if tangent is None else tangent['offsets'][index][0 if size == 1 else 1],
-                                                len(layers), partial_at, ctypes.byref(slots, 128 * index), ctypes.byref(gx),
+                                                len(layers), weights, partial_at, ctypes.byref(slots, 128 * index), ctypes.byref(gx),
                                                 ctypes.byref(gy), ctypes.byref(rg), ctypes.byref(partial))
             if status != 0:
                 plans[key] = None
                 return None
             partial_at += partial.value
-            grid_x, grid_y, ragged = max(grid_x, gx.value), max(grid_y, gy.value), max(ragged, rg.value)
+            grid_x, grid_y, ragged = max(grid_x, gx.value), max(grid_y, gy.value), ragged | rg.value
         table = torch.frombuffer(bytearray(bytes(slots)), dtype=torch.uint8).to(device)
         plan[size] = dict(table=table, count=len(layers), grid_x=grid_x, grid_y=grid_y, ragged=ragged, co_ci_taps=co_ci_taps,
                           pixels=n * hw, elements=elements, partial_floats=partial_at)

@@ -419,3 +419,20 @@ def test_other_configurations_are_bit_reproducible_too(pkg, monkeypatch, task):
         assert first[key] == again[key], (task, key, first[key], again[key])
     for name in first_weights:
         assert np.array_equal(first_weights[name], again_weights[name]), (task, name, float(np.abs(first_weights[name] - again_weights[name]).max()))
+
+
+def test_grouped_1x1_weight_gradients_mixing_both_tile_forms(pkg):
+    """A grouped 1x1 weight-gradient launch whose problems were planned for BOTH kernels (`srgan_wgrad_group_plan` returns
+    the variant per slot, the launch gets their OR: the LDS-staged 128 x 128 tiles for the wide layers, the register-streamed
+    64 x 64 tiles for the narrow ones; reference crowd/models.py:340-341 through loss.backward()): the dense-block test with
+    the threshold between the block's layers (32 / 40 / 48 input channels), in a process of its own because the threshold
+    is read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    environment = dict(os.environ, SRGAN_PWL_MIN_CI='40')
+    command = [sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_ops_gpu.py'), '-q', '-x', '-m', 'gpu', '-k',
+               'test_fused_dense_block_with_in_kernel_batch_norm and plane0']
+    done = subprocess.run(command, capture_output=True, text=True, timeout=900, env=environment, cwd=root)
+    assert done.returncode == 0 and '1 passed' in done.stdout, done.stdout[-2000:] + done.stderr[-2000:]
