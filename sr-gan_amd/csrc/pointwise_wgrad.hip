@@ -390,6 +390,7 @@ __device__ __forceinline__ void pointwise_wgrad_lds_body(const PwWgradParams& p,
   }
 }
 
+
 template <bool PRO>
 __device__ __forceinline__ void pointwise_wgrad_lds_tile(const PwWgradParams& p, const int block_x, const int block_y, char* smem) {
   const int tm = block_x / p.tiles_n, tn = block_x - tm * p.tiles_n;
