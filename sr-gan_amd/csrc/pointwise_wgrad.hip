@@ -23,7 +23,7 @@
 // step for 45 GB of operands (profiles/r05z_crowd512_pmc_per_kernel.md), the kernel sat at 4.3 TB/s.  Here a workgroup
 // owns a 128 x 128 tile: a 32-pixel chunk of its 128 gy rows and 128 x rows goes to LDS ONCE by LDS-DMA (32 KB per stage,
 // two stages, two workgroups per CU) and wave w multiplies gy rows 32w..32w+31 by all 128 x rows: 64 operand rows per
-// block of matrix work whatever L2 does.  A lane still owns 16 consecutive pixels of its row (four ds_read_b128 per
+// block of matrix work whatever L2 does (counters: 1.22x the operand bytes, 23.7 ms per step at 0.59 of the fp32 MFMA peak).  A lane still owns 16 consecutive pixels of its row (four ds_read_b128 per
 // chunk and row block); rows are 128 bytes = half a 256-byte bank row, 16-byte slots XOR-swizzled by the bank-row index
 // (applied to the DMA's source addresses, as in pointwise_ring.hip) -- conflict-free.
 #include "common.h"
@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_finish_kernel(const PwWgr
 // ---- the staged form (see the head of the file).  NI: the tile's 32-column blocks that hold input channels (the last
 // tile of a row may hold 1..3); wave w stages the x rows of block w and its own 32 gy rows.
 // A stage = a 32-pixel chunk of the 128 gy rows (16 KB) + of the tile's 32 * NI x rows; two stages, three for the narrow tiles
-// (NI <= 2: a chunk is 32 / 64 matrix instructions per wave -- too short to cover the latency of ONE chunk in flight).
+// (NI <= 2, where three fit beside a second workgroup; measured together with the even spread of the column blocks: 25.9 ->
+// 25.2 ms per step.  More chunks in flight on the full tiles -- gy rows in registers, four stages of x -- measured SLOWER:
+// profiles/r05t_staged_1x1_weight_gradient.md).
 constexpr int PWL_A_BYTES = PWL_TILE * 128, PWL_LDS_BYTES = 3 * (PWL_A_BYTES + 2 * 4096);     // 72 KB (>= 2 * 32 KB)
 
 template <bool PRO, int NI>
