@@ -554,7 +554,7 @@ static int pointwise_wgrad_lds_plan(int32_t N, int32_t CI, int32_t CO, int32_t H
   const int64_t chunks = (int64_t)N * p.chunks_per_image;
   SRGAN_REQUIRE(chunks < ((int64_t)1 << 30) && tiles < (1 << 30), SRGAN_ERANGE, "pointwise wgrad grid");
   p.chunks = (int)chunks;
-  // Two resident workgroups per CU (64 KB of LDS each).  A worker leaves a 64 KB partial tile behind (written once, read once
+  // Two resident workgroups per CU (72 KB of LDS each).  A worker leaves a 64 KB partial tile behind (written once, read once
   // by the finish): at least `min_chunks` chunks (32 KB of operands each) per worker.
   static const int resident = getenv("SRGAN_PWL_WGS") ? atoi(getenv("SRGAN_PWL_WGS")) : 512;
   static const int min_chunks = getenv("SRGAN_PWL_DEPTH") ? atoi(getenv("SRGAN_PWL_DEPTH")) : 8;
@@ -584,7 +584,7 @@ static bool pointwise_wgrad_lds_shape(int32_t CI, int32_t CO, int32_t HW) {
   return !disabled && CI >= min_ci && HW % 32 == 0 && (int64_t)(CI > CO ? CI : CO) * HW * 4 < ((int64_t)1 << 32);
 }
 
-// (64 KB of dynamic LDS is the default limit; set the attribute once per kernel and device all the same, see pointwise_ring.hip)
+// (72 KB of dynamic LDS is beyond the 64 KB a launch gets without the attribute: set once per kernel and device, see pointwise_ring.hip)
 template <typename Kernel>
 static int pointwise_wgrad_lds_configure(Kernel kernel, std::atomic<uint64_t>& configured_devices) {
   int device = 0;
