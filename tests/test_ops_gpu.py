@@ -131,6 +131,13 @@ CONV_CASES = [
     (4, 160, 64, 64, 288, 1, 1, (1, 1), (0, 0)),
     (6, 96, 64, 64, 224, 1, 1, (1, 1), (0, 0)),
     (24, 128, 24, 12, 128, 1, 1, (1, 1), (0, 0)),    # planes of 9 x 32 pixels: the 32-pixel tile, both weight layouts
+    # the map modules' 2x2 / s2 convolutions (reference crowd/models.py:131-133) at their own channel counts: tiny weight
+    # gradients from 10^4 - 10^5 pixels (many K slices, ordered finish), rectangular planes, an odd input height
+    (3, 8, 128, 128, 16, 2, 2, (2, 2), (0, 0)),
+    (2, 16, 64, 128, 32, 2, 2, (2, 2), (0, 0)),
+    (2, 1, 64, 64, 8, 2, 2, (2, 2), (0, 0)),
+    (2, 5, 67, 64, 20, 2, 2, (2, 2), (0, 0)),
+    (1, 3, 4, 64, 7, 2, 2, (2, 2), (0, 0)),
 ]
 
 

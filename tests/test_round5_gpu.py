@@ -279,6 +279,7 @@ SPLIT_CASES = [
     ('1x1 on 7 x 7 planes', (4, 896, 7, 7), (128, 896, 1, 1), 1, 0),
     ('k4 / s2 / p1 strided convolution (gg_mfma_kernel, ordered finish)', (2, 64, 16, 16), (128, 64, 4, 4), 2, 1),
     ('7x7 / s2 / p3 on a small image (generic kernel)', (1, 8, 30, 30), (16, 8, 7, 7), 2, 3),
+    ('2x2 / s2 map-module convolution (1024 K slices of the generic kernel, partial outputs + ordered reduce)', (4, 8, 128, 128), (16, 8, 2, 2), 2, 0),
 ]
 
 
