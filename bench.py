@@ -709,7 +709,7 @@ def main():
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
             'kernel': 'all contraction kernels of one step: srgan::pointwise_ring_kernel / pointwise_kernel / conv3x3_lds_kernel / conv3x3_wgrad_kernel / '
-                      'pointwise_wgrad_kernel / gg_mfma_kernel / gg_rows_kernel (every conv and linear pass)',
+                      'pointwise_wgrad(_lds)_kernel / gg_mfma_kernel / gg_rows_kernel (every conv and linear pass)',
             'launches': launches.value, 'kernel_ms_per_step': kernel_ms.value,
             'executed_gflop_per_step': flops.value / 1e9, 'mfma_share_of_flops': mfma_flops.value / max(flops.value, 1.0),
             'avg_launch_us': 1e3 * kernel_ms.value / max(launches.value, 1),
