@@ -515,12 +515,11 @@ class Experiment(ABC):
                 getattr(self.D, '_srgan_arena', None) is None:
             return None
         if getattr(self, '_gp_stream', None) is None:
-            # The penalty chain (three passes through D) is the longest of the iteration's chains: its stream gets the higher
-            # of the two priorities the runtime offers, so that where kernels of two chains compete the critical one goes
-            # first (measured, same call, A / B / A / B: 512 x 512 86.1 -> 86.7 images/s, 224 x 224 262.1 -> 264.7; high
-            # priority for the main, auxiliary or DNN stream as well, or for the main stream alone, measured lower:
-            # profiles/r05_stream_priority.txt).  SRGAN_GP_STREAM_PRIORITY=0 restores equal priorities.
-            self._gp_stream = torch.cuda.Stream(priority=int(os.environ.get('SRGAN_GP_STREAM_PRIORITY', '-1')))
+            # (SRGAN_GP_STREAM_PRIORITY=-1: the runtime's high priority for this, the longest chain -- an experiment that is NOT the
+            # default: +0.7 % on one GPU in the eager four-stream schedule, but a high-priority stream is one more hardware queue:
+            # -25 % under data parallelism next to RCCL's stream and -18 % / -47 % when the chains are replayed as a HIP graph,
+            # profiles/r05_stream_priority.txt)
+            self._gp_stream = torch.cuda.Stream(priority=int(os.environ.get('SRGAN_GP_STREAM_PRIORITY', '0')))
         return self._gp_stream
 
     def _gradient_penalty_on_its_own_stream(self, stream, fake_examples, unlabeled_examples):
