@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-int srgan_version(void);               /* 100 = ABI 1.0 */
+int srgan_version(void);               /* 110 = ABI 1.1 (see "ABI history" in INTEGRATION.md; 100 = ABI 1.0) */
 /* 16 hex digits: sha256 over the kernel sources this library was compiled from (sr-gan_amd/_build.py source_id()).
  * The Python loader refuses a library whose id differs from the sources next to it: a stale prebuilt .so must not
  * silently run old kernels under new parity tests. */
@@ -52,6 +52,7 @@ const char* srgan_last_error(void);
 #define SRGAN_FEATURE_FUSED_BNRELU 0x1u /* norm -> relu -> conv evaluated inside the convolution kernels */
 #define SRGAN_FEATURE_SPLITK_WORKSPACE 0x2u
 #define SRGAN_FEATURE_LIVE_PROFILE 0x4u
+#define SRGAN_FEATURE_BLOCKED16 0x8u    /* ABI 1.1: the srgan_h_* entry points (16-bit storage in the blocked layout) */
 typedef struct srgan_capabilities_t {
   int32_t abi_version;          /* = srgan_version() */
   int32_t struct_bytes;         /* sizeof(srgan_capabilities_t) as the library was built */
@@ -397,6 +398,49 @@ int srgan_all_reduce_sum(void* comm, const void* send, void* recv, int64_t count
  * of the sum of send[0 .. world * recv_count); all_gather puts rank r's send_count elements at [r, r + 1) * send_count */
 int srgan_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t recv_count, int32_t dtype, void* stream);
 int srgan_all_gather(void* comm, const void* send, void* recv, int64_t send_count, int32_t dtype, void* stream);
+
+/* ---- 16-bit data path (ABI 1.1; BASELINE.json configs[1] "bf16" and configs[4] "fp16") ---------------------------------
+ * "Blocked" tensors: logical [N, C, H, W] stored as [N][ceil(C / 8)][H][W][8] elements of bf16 (`dtype` 1) or fp16 (2); the 8
+ * channels of a group at one pixel are one 16-byte slot = one MFMA operand fragment (sr-gan_amd/csrc/blocked16.h); channels
+ * beyond C inside the last group hold zeros; an [N, F] matrix is the H = W = 1 case (row-major, row pitch ceil(F / 8) slots).
+ * Activations, their gradients and a per-layer shadow of the weights live in this form; master weights, weight / bias
+ * gradients (accumulated into), Adam and the losses stay fp32.  The reference has no analogue (it is fp32-only);
+ * the call sites served are VGG-16's `conv3x3 -> ReLU`, `MaxPool2d(2, 2)` and `Linear -> ReLU` (age/vgg.py:33-41,70-84) and
+ * the DCGAN stacks' `leaky_relu(conv)` (age/models.py:48-50,70-73).
+ * epi (epilogue of a contraction): 0 = store; 1 = + bias (may be NULL), then leaky_relu with `slope` (0 = relu, 1 = identity);
+ * 2 = multiply by the derivative of the activation that produced `ref` (1 where ref > 0, `slope` elsewhere; ref has the
+ * output's shape): the gradient with respect to the PRE-activation tensor leaves the kernel, the un-masked one never exists. */
+int srgan_h_pack(const float* x_nchw, void* out, const void* mask_ref, float slope, int32_t N, int32_t C, int64_t HW, int dtype,
+                 void* stream);                                /* fp32 NCHW -> blocked (times mask(ref) when mask_ref != NULL) */
+int srgan_h_unpack(const void* x, float* out_nchw, int32_t N, int32_t C, int64_t HW, int dtype, void* stream);
+int srgan_h_add(const void* a, const void* b, void* out, int64_t slots, int dtype, void* stream);
+int srgan_h_channel_sums(const void* x, float* out, int32_t N, int32_t C, int64_t HW, int dtype, void* stream);   /* out[c] += ... (bias gradient) */
+/* mode 0: out = max_pool2d(x, 2, 2); mode 2: out = g (shape of x) gathered at the arg-max of x.  planes = N * groups. */
+int srgan_h_maxpool2(const void* x, const void* g, void* out, int64_t planes, int32_t H, int32_t W, int mode, int dtype, void* stream);
+/* gx (shape of x) = gp placed at the arg-max of x (first maximum in scan order, torch's rule), times mask(x, slope) if masked */
+int srgan_h_maxpool2_bwd(const void* x, const void* gp, void* gx, int64_t planes, int32_t H, int32_t W, int masked, float slope,
+                         int dtype, void* stream);
+/* The 16-bit shadow of conv2d weights w[K][C][R][S] in operand slots; transposed = 1: the data-gradient operand (rows = C,
+ * reduced over K, taps mirrored).  srgan_h_conv_weight_slots(rows, reduced, R, S) 16-byte slots. */
+int64_t srgan_h_conv_weight_slots(int32_t rows, int32_t reduced, int32_t R, int32_t S);
+int srgan_h_pack_conv_weights(const float* w, void* packed, int32_t K, int32_t C, int32_t R, int32_t S, int transposed, int dtype,
+                              void* stream);
+/* out[N, C_out, H, W] = epi(conv2d 3x3 / stride 1 / pad 1 of x[N, C_in, H, W]) with a packed operand of `rows` rows. */
+int srgan_h_conv3x3(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi, void* out,
+                    int32_t N, int32_t C_in, int32_t C_out, int32_t rows, int32_t H, int32_t W, int dtype, void* stream);
+/* gw[C_out][C_in][3][3] (fp32) += weight gradient from x[N, C_in, H, W] and gy[N, C_out, H, W] (fixed summation order) */
+int srgan_h_conv3x3_wgrad(const void* x, const void* gy, float* gw, int32_t N, int32_t C_in, int32_t C_out, int32_t H, int32_t W,
+                          int dtype, void* stream);
+/* out16[rows][cols] = src[map(r, row_plane) * row_stride + map(c, col_plane) * col_stride] (0 outside rows_real x cols_real);
+ * map(i, P) = NCHW-flattened index of element i of a flattened blocked tensor with P pixels per channel (P <= 1: i). */
+int srgan_h_pack_matrix(const float* src, void* out, int64_t rows, int64_t cols, int64_t rows_real, int64_t cols_real,
+                        int64_t row_stride, int64_t col_stride, int32_t row_plane, int32_t col_plane, int dtype, void* stream);
+/* out[N][out_cols] = epi(B[N][K] * A[M][K]^T): torch.nn.functional.linear (age/vgg.py:33-41) and its data gradient */
+int srgan_h_gemm(const void* a, const void* b, const float* bias, const void* ref, float slope, int epi, void* out, int32_t M,
+                 int32_t N, int32_t K, int32_t out_cols, int32_t bias_entries, int dtype, void* stream);
+/* gw element (m, k) at gw[map(m, row_plane) * ldw_m + map(k, col_plane) * ldw_k] += sum_n S[n][m] * X[n][k] */
+int srgan_h_linear_wgrad(const void* s, const void* x, float* gw, int32_t N, int32_t M, int32_t K, int64_t M_real, int64_t K_real,
+                         int64_t ldw_m, int64_t ldw_k, int32_t row_plane, int32_t col_plane, int dtype, void* stream);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------
  * Between begin and end every contraction launch (conv / gemm passes) is bracketed by a pair of HIP events on

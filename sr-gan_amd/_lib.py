@@ -109,6 +109,19 @@ SIGNATURES = {
     'srgan_adam_step_counted': ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp], ctypes.c_int),
     'srgan_pack_bf16': ([vp, vp, i64, vp], ctypes.c_int),
     'srgan_unpack_bf16': ([vp, vp, i64, vp], ctypes.c_int),
+    'srgan_h_pack': ([vp, vp, vp, f32, i32, i32, i64, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_unpack': ([vp, vp, i32, i32, i64, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_add': ([vp, vp, vp, i64, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_channel_sums': ([vp, vp, i32, i32, i64, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_maxpool2': ([vp, vp, vp, i64, i32, i32, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_maxpool2_bwd': ([vp, vp, vp, i64, i32, i32, ctypes.c_int, f32, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_conv_weight_slots': ([i32, i32, i32, i32], ctypes.c_int64),
+    'srgan_h_pack_conv_weights': ([vp, vp, i32, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_conv3x3': ([vp, vp, vp, vp, f32, ctypes.c_int, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_conv3x3_wgrad': ([vp, vp, vp, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_pack_matrix': ([vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_gemm': ([vp, vp, vp, vp, f32, ctypes.c_int, vp, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_linear_wgrad': ([vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i32, i32, ctypes.c_int, vp], ctypes.c_int),
     'srgan_comm_available': ([], ctypes.c_int),
     'srgan_comm_unique_id': ([vp], ctypes.c_int),
     'srgan_comm_init': ([ctypes.POINTER(vp), i32, i32, vp], ctypes.c_int),

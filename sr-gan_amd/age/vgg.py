@@ -44,10 +44,39 @@ class VGG(nn.Module):
             self._initialize_weights()
 
     def forward(self, x):
+        if F.STORAGE_DTYPE and x.meta is None:
+            return self._forward_blocked(x, F.STORAGE_DTYPE)
         h = self.feature_layers(x)
         h = self.classifier(F.flatten2d(h))
         self.features = h
         return self.final_layer(h)
+
+    def _forward_blocked(self, x, code):
+        """The same graph on the 16-bit data path (``blocked16``): bf16 / fp16 activations in the blocked layout, every
+        ``conv -> ReLU`` / ``Linear -> ReLU`` pair one kernel, fp32 only at the two ends (the images; ``features`` and the
+        prediction)."""
+        from .. import blocked16 as B
+        h = B.pack(x, code)
+        layers = list(self.feature_layers)
+        index = 0
+        while index < len(layers):
+            layer = layers[index]
+            if isinstance(layer, torch_nn.Conv2d):
+                fused = index + 1 < len(layers) and isinstance(layers[index + 1], nn.ReLU)
+                h = B.conv3x3(h, layer, slope=0.0 if fused else None)
+                index += 2 if fused else 1
+            elif isinstance(layer, nn.MaxPool2d):
+                if (layer.kernel_size, layer.stride, layer.padding) != (2, 2, 0):
+                    raise NotImplementedError('16-bit path: 2x2 / stride 2 max-pooling')
+                h = B.max_pool2(h)
+                index += 1
+            else:
+                raise NotImplementedError(f'16-bit path: {type(layer).__name__} inside the VGG feature stack')
+        h = B.flatten(h)
+        first, _, second, _ = self.classifier
+        h = B.linear(B.linear(h, first, slope=0.0), second, slope=0.0)
+        self.features = B.unpack(h)
+        return B.unpack(B.linear(h, self.final_layer))
 
     def _initialize_weights(self):
         for m in self.modules():

@@ -1,0 +1,340 @@
+"""The 16-bit data path on the tape (BASELINE.json configs[1] "bf16", configs[4] "fp16"; the reference is fp32-only).
+
+Activations, their gradients and a shadow of every layer's weights are bf16 / fp16 tensors in the BLOCKED layout of
+``csrc/blocked16.h`` -- ``[N][C / 8][H][W][8]``: the 8 channels of a group at a pixel are one 16-byte MFMA operand slot --
+while the master weights, the weight / bias gradients (accumulated straight into the fp32 arena), Adam and the losses stay
+fp32.  A ``Var`` of this kind carries ``meta`` (a ``Blocked``); ``pack`` / ``unpack`` are the only crossings.
+
+Fused activations and the "pre-masked gradient" convention.  A layer is ``y = act(conv(x) + b)`` in ONE kernel (the
+reference's ``conv -> ReLU`` / ``leaky_relu(conv)`` pairs, age/vgg.py:78-82, age/models.py:48-50,70-73) and only ``y`` is
+stored.  Its ``meta.mask_ref`` is ``y`` itself: the activation's derivative is 1 where ``y > 0`` and ``slope`` elsewhere.
+The gradient handed to the producer of a tensor with a ``mask_ref`` is ALREADY multiplied by that derivative: every
+operation that consumes such a tensor applies the mask in the epilogue of the kernel that produces its input gradient (the
+data-gradient convolution, the pool backward, the fp32 -> 16-bit conversion), so the un-masked gradient never exists in HBM
+and nothing like ``unary_kernel`` / ``binary_kernel`` runs on this path.  Sums of gradients commute with the mask, so
+several consumers simply add up.
+
+Second order (the gradient penalty, reference srgan.py:360-375).  With relu / leaky_relu and max-pool the networks are
+piecewise linear, so every backward operation is again "a linear map, then a mask": ``conv(s, W^T) * mask(ref)``.  Its own
+backward is the same kind of call with the roles swapped (the LINEARISED forward: ``conv(s, W) * mask(ref')``) plus a
+weight gradient from (tangent, first-backward gradient), so the recorded backward and its double backward reuse the
+forward kernels; masks and arg-max positions are constants."""
+import torch
+
+from . import _lib
+from . import functional as F
+from .tape import Var, accumulates_into
+
+TORCH_DTYPE = {1: torch.bfloat16, 2: torch.float16}
+CODES = {'bf16': 1, 'f16': 2, 'fp16': 2}
+
+
+class Blocked:
+    """Logical shape and conventions of a 16-bit blocked tensor: ``c`` channels (``(c + 7) // 8`` groups) on an h x w plane;
+    ``plane`` > 1 marks a FLATTENED tensor (h = w = 1) whose ``c`` entries are the slots of a [c0 / 8][plane][8] tensor."""
+    __slots__ = ('n', 'c', 'h', 'w', 'code', 'mask_ref', 'slope', 'plane', 'real')
+
+    def __init__(self, n, c, h, w, code, mask_ref=None, slope=0.0, plane=1, real=None):
+        self.n, self.c, self.h, self.w, self.code = n, c, h, w, code
+        self.mask_ref, self.slope, self.plane = mask_ref, slope, plane
+        self.real = c if real is None else real          # features that exist (flattened tensors: channels x plane)
+
+    @property
+    def groups(self):
+        return (self.c + 7) // 8
+
+    def like(self, **changes):
+        values = {name: getattr(self, name) for name in self.__slots__}
+        values.update(changes)
+        return Blocked(**values)
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.library(), name)(*args), name)
+
+
+def _new(n, c, h, w, code, device):
+    shape = (n, (c + 7) // 8, h, w, 8)
+    if F.POISON:
+        return torch.full(shape, float('nan'), dtype=TORCH_DTYPE[code], device=device)
+    return torch.empty(shape, dtype=TORCH_DTYPE[code], device=device)
+
+
+def _ptr(tensor):
+    return None if tensor is None else tensor.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------ conversions
+def pack(x, code, mask_ref=None, slope=0.0):
+    """fp32 [N, C, H, W] (or [N, F]) -> blocked 16-bit; with ``mask_ref`` the values are multiplied by the derivative of the
+    activation that produced ``mask_ref`` (this is then the PRE-masked gradient of that activated tensor)."""
+    shape = x.shape
+    n, c = shape[0], shape[1]
+    h, w = (shape[2], shape[3]) if len(shape) == 4 else (1, 1)
+    if len(shape) not in (2, 4):
+        raise ValueError(f'blocked16.pack takes [N, C, H, W] or [N, F], not {shape}')
+    F._check_device(x.data)
+    data = _new(n, c, h, w, code, x.data.device)
+    _call('srgan_h_pack', x.data.data_ptr(), data.data_ptr(), _ptr(mask_ref), float(slope), n, c, h * w, code, F._stream())
+    out = F._out(data, (x,), lambda s, needs: (unpack(s, shape),), 'h_pack')
+    out.meta = Blocked(n, c, h, w, code, mask_ref, slope)
+    return out
+
+
+def unpack(x, shape=None):
+    """blocked 16-bit -> fp32 [N, C, H, W] ([N, C] for 1 x 1 planes unless ``shape`` says otherwise)."""
+    meta = x.meta
+    if meta.plane != 1:
+        raise ValueError('a flattened blocked tensor has no NCHW form: unpack before flatten')
+    if shape is None:
+        shape = (meta.n, meta.c) if meta.h == meta.w == 1 else (meta.n, meta.c, meta.h, meta.w)
+    data = F._empty(shape, x.data)
+    _call('srgan_h_unpack', x.data.data_ptr(), data.data_ptr(), meta.n, meta.c, meta.h * meta.w, meta.code, F._stream())
+    return F._out(data, (x,), lambda g, needs: (pack(g, meta.code, meta.mask_ref, meta.slope),), 'h_unpack')
+
+
+def flatten(x):
+    """[N, C, H, W] -> [N, C/8 * H * W * 8] as a VIEW (the blocked order: a linear layer behind it permutes its weight
+    shadow's columns instead, ``Shadow``)."""
+    meta = x.meta
+    if meta.h == meta.w == 1:
+        return x
+    plane, length = meta.h * meta.w, meta.groups * 8 * meta.h * meta.w
+
+    def flat(tensor):
+        return None if tensor is None else tensor.view(meta.n, length // 8, 1, 1, 8)
+    flat_meta = Blocked(meta.n, length, 1, 1, meta.code, flat(meta.mask_ref), meta.slope, plane, meta.c * plane)
+
+    def backward(s, needs):
+        data = s.data.view(meta.n, meta.groups, meta.h, meta.w, 8)
+        back = F._out(data, (s,), lambda t, n2: (_reflatten(t, flat_meta),), 'h_unflatten')
+        back.meta = meta
+        return (back,)
+    out = F._out(flat(x.data), (x,), backward, 'h_flatten')
+    out.meta = flat_meta
+    return out
+
+
+def _reflatten(t, flat_meta):
+    out = F._out(t.data.view(flat_meta.n, flat_meta.c // 8, 1, 1, 8), (t,), None, 'h_flatten')
+    out.meta = flat_meta
+    if out.node is not None:
+        raise NotImplementedError('third-order use of blocked16.flatten')
+    return out
+
+
+def add(a, b):
+    if a.meta is None or b.meta is None or a.data.shape != b.data.shape or a.meta.code != b.meta.code:
+        raise ValueError('blocked16.add: both operands must be 16-bit blocked tensors of one shape')
+    data = torch.empty_like(a.data)
+    _call('srgan_h_add', a.data.data_ptr(), b.data.data_ptr(), data.data_ptr(), data.numel() // 8, a.meta.code, F._stream())
+    out = F._out(data, (a, b), lambda g, needs: (g, g), 'h_add')
+    out.meta = a.meta
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+def max_pool2(x):
+    """max_pool2d(x, 2, 2) (reference age/vgg.py:76).  Backward: the pooled gradient placed at the arg-max and multiplied
+    by the derivative of the activation that produced ``x`` in one pass; the arg-max is recomputed (first maximum)."""
+    meta = x.meta
+    if meta.h % 2 or meta.w % 2:
+        raise ValueError('blocked16.max_pool2 needs even planes')
+    if meta.mask_ref is not None and meta.mask_ref.data_ptr() != x.data.data_ptr():
+        raise ValueError('blocked16.max_pool2 pools activated tensors (mask = the tensor itself) or plain ones')
+    data = _new(meta.n, meta.c, meta.h // 2, meta.w // 2, meta.code, x.data.device)
+    _call('srgan_h_maxpool2', x.data.data_ptr(), None, data.data_ptr(), meta.n * meta.groups, meta.h, meta.w, 0, meta.code,
+          F._stream())
+    out = F._out(data, (x,), lambda g, needs: (_pool_backward(x.data, meta, g),), 'h_max_pool2')
+    out.meta = Blocked(meta.n, meta.c, meta.h // 2, meta.w // 2, meta.code)
+    return out
+
+
+def _pool_backward(x_data, meta, g):
+    data = torch.empty_like(x_data)
+    _call('srgan_h_maxpool2_bwd', x_data.data_ptr(), g.data.data_ptr(), data.data_ptr(), meta.n * meta.groups, meta.h, meta.w,
+          1 if meta.mask_ref is not None else 0, float(meta.slope), meta.code, F._stream())
+    out = F._out(data, (g,), lambda s, needs: (_pool_gather(x_data, meta, s),), 'h_max_pool2_backward')
+    out.meta = meta
+    return out
+
+
+def _pool_gather(x_data, meta, s):
+    """``s`` (shape of x, pre-masked) at the arg-max of x: the pool's action on a tangent."""
+    data = _new(meta.n, meta.c, meta.h // 2, meta.w // 2, meta.code, x_data.device)
+    _call('srgan_h_maxpool2', x_data.data_ptr(), s.data.data_ptr(), data.data_ptr(), meta.n * meta.groups, meta.h, meta.w, 2,
+          meta.code, F._stream())
+    out = F._out(data, (s,), lambda t, needs: (_pool_backward(x_data, meta, t),), 'h_max_pool2_gather')
+    out.meta = Blocked(meta.n, meta.c, meta.h // 2, meta.w // 2, meta.code)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ weight shadows
+class Shadow:
+    """The 16-bit operand forms of one layer's fp32 master weights: ``forward`` (rows = outputs) and ``transposed`` (the
+    data gradient's operand), re-rounded whenever the masters changed -- by ``refresh(arena)`` right behind the optimizer
+    update (same stream as the update), or lazily when the version key below moved (checkpoint load, tests)."""
+
+    def __init__(self, module, kind, code, in_blocked=0, plane=1):
+        self.module, self.kind, self.code, self.in_blocked, self.plane = module, kind, code, in_blocked, plane
+        self.forward = self.transposed = None
+        self.key = None
+        arena = getattr(module.weight, '_srgan_arena', None)
+        if arena is not None:
+            arena.shadows.append(self)
+
+    def _version(self):
+        weight = self.module.weight
+        arena = getattr(weight, '_srgan_arena', None)
+        return (weight.data_ptr(), weight._version, None if arena is None else (arena.version, arena.data._version))
+
+    def fresh(self):
+        if self.key != self._version():
+            self.repack()
+        return self
+
+    def repack(self):
+        weight = self.module.weight
+        lib, stream, device = _lib.library(), F._stream(), weight.device
+        if self.kind == 'conv3x3':
+            k, c, r, s = weight.shape
+            for name, transposed, rows, reduced in (('forward', 0, k, c), ('transposed', 1, c, k)):
+                slots = lib.srgan_h_conv_weight_slots(rows, reduced, r, s)
+                if getattr(self, name) is None:
+                    setattr(self, name, torch.empty(slots * 4, dtype=torch.int32, device=device))
+                _call('srgan_h_pack_conv_weights', weight.data_ptr(), getattr(self, name).data_ptr(), k, c, r, s, transposed,
+                      self.code, stream)
+        elif self.kind == 'linear':
+            outputs, inputs = weight.shape[0], weight.numel() // weight.shape[0]
+            blocked = self.in_blocked or (inputs + 7) // 8 * 8
+            outputs_padded = (outputs + 7) // 8 * 8
+            if self.forward is None:
+                self.forward = torch.empty(outputs * blocked // 2, dtype=torch.int32, device=device)
+                self.transposed = torch.empty(blocked * outputs_padded // 2, dtype=torch.int32, device=device)
+            # forward operand A[o][f'] = W[o][map(f')]; transposed operand A[f'][o] = W[o][map(f')]
+            _call('srgan_h_pack_matrix', weight.data_ptr(), self.forward.data_ptr(), outputs, blocked, outputs, inputs, inputs, 1,
+                  1, self.plane, self.code, stream)
+            _call('srgan_h_pack_matrix', weight.data_ptr(), self.transposed.data_ptr(), blocked, outputs_padded, inputs, outputs, 1,
+                  inputs, self.plane, 1, self.code, stream)
+        else:
+            raise ValueError(self.kind)
+        self.key = self._version()
+
+
+def shadow_of(module, kind, code, in_blocked=0, plane=1):
+    table = module.__dict__.setdefault('_srgan_shadows', {})
+    key = (kind, code, in_blocked, plane)
+    found = table.get(key)
+    if found is None:
+        found = table[key] = Shadow(module, kind, code, in_blocked, plane)
+    return found.fresh()
+
+
+def refresh(arena):
+    """Re-round every shadow of the networks' weights in ``arena`` (called right behind the optimizer update, on its stream:
+    whatever orders a later reader behind the update orders it behind the shadows too)."""
+    for shadow in getattr(arena, 'shadows', ()):
+        shadow.repack()
+
+
+# ------------------------------------------------------------------------------------------------ fused layers
+def _parameter(p):
+    from .nn import parameter_var
+    return None if p is None else parameter_var(p)
+
+
+def conv3x3(x, module, slope=None):
+    """``act(conv2d(x, w, b, stride 1, padding 1))`` for a 3x3 ``nn.Conv2d``: slope None = no activation, 0.0 = ReLU (reference
+    age/vgg.py:78-82), other = leaky_relu."""
+    if tuple(module.kernel_size) != (3, 3) or tuple(module.stride) != (1, 1) or tuple(module.padding) != (1, 1):
+        raise ValueError('blocked16.conv3x3: 3x3 / stride 1 / padding 1 convolutions')
+    shadow = shadow_of(module, 'conv3x3', x.meta.code)
+    epi, slope_value = (1, 1.0 if slope is None else float(slope))
+    return _layer(x, module, shadow, False, epi, slope_value, None, True)
+
+
+def linear(x, module, slope=None):
+    """``act(linear(x, w, b))`` on a [N, F] blocked matrix (reference age/vgg.py:33-41,48-53); ``x`` may be the flattened view
+    of a [N, C, H, W] tensor: the shadow's columns follow the blocked order."""
+    meta = x.meta
+    if meta.h != 1 or meta.w != 1:
+        raise ValueError('blocked16.linear takes [N, F] (flatten first)')
+    shadow = shadow_of(module, 'linear', meta.code, in_blocked=meta.groups * 8, plane=meta.plane)
+    return _layer(x, module, shadow, False, 1, 1.0 if slope is None else float(slope), None, True)
+
+
+def _layer(x, module, shadow, transposed, epi, slope, ref, use_bias):
+    """One contraction launch ``epi(op(x, W) [+ b])`` recorded on the tape.  transposed: the data-gradient direction (x has
+    the layer's OUTPUT features).  epi 1: bias + leaky(slope); epi 2: times mask(ref, slope); epi 0: plain."""
+    meta, code = x.meta, x.meta.code
+    weight = _parameter(module.weight)
+    bias = _parameter(module.bias) if (use_bias and module.bias is not None) else None
+    stream = F._stream()
+    if shadow.kind == 'conv3x3':
+        k, c = module.weight.shape[0], module.weight.shape[1]
+        c_in, c_out = (k, c) if transposed else (c, k)
+        if meta.c != c_in:
+            raise ValueError(f'blocked16 conv: input has {meta.c} channels, the layer expects {c_in}')
+        data = _new(meta.n, c_out, meta.h, meta.w, code, x.data.device)
+        operand = shadow.transposed if transposed else shadow.forward
+        _call('srgan_h_conv3x3', x.data.data_ptr(), operand.data_ptr(), _ptr(None if bias is None else bias.data), _ptr(ref),
+              float(slope), epi, data.data_ptr(), meta.n, c_in, c_out, c_out, meta.h, meta.w, code, stream)
+        out_meta = Blocked(meta.n, c_out, meta.h, meta.w, code)
+    else:
+        outputs, inputs = module.weight.shape[0], module.weight.numel() // module.weight.shape[0]
+        blocked = shadow.in_blocked or (inputs + 7) // 8 * 8
+        if transposed:
+            if meta.c != outputs:
+                raise ValueError(f'blocked16 linear (data gradient): input has {meta.c} features, expected {outputs}')
+            data = _new(meta.n, blocked, 1, 1, code, x.data.device)
+            _call('srgan_h_gemm', shadow.transposed.data_ptr(), x.data.data_ptr(), None, _ptr(ref), float(slope), epi,
+                  data.data_ptr(), blocked, meta.n, outputs, blocked, 0, code, stream)
+            out_meta = Blocked(meta.n, blocked, 1, 1, code, plane=shadow.plane, real=inputs)
+        else:
+            if meta.c != blocked:
+                raise ValueError(f'blocked16 linear: input has {meta.c} (blocked) features, the shadow was built for {blocked}')
+            data = _new(meta.n, outputs, 1, 1, code, x.data.device)
+            _call('srgan_h_gemm', shadow.forward.data_ptr(), x.data.data_ptr(), _ptr(None if bias is None else bias.data), _ptr(ref),
+                  float(slope), epi, data.data_ptr(), outputs, meta.n, blocked, outputs, outputs, code, stream)
+            out_meta = Blocked(meta.n, outputs, 1, 1, code)
+    if epi == 1 and slope != 1.0:
+        out_meta.mask_ref, out_meta.slope = data, slope            # an activated tensor is its own mask
+    elif epi == 2:
+        out_meta.mask_ref, out_meta.slope = ref, slope              # a pre-masked gradient: cotangents arrive masked alike
+
+    def backward(s, needs):
+        gx = None
+        if needs[0]:
+            if meta.mask_ref is not None:
+                gx = _layer(s, module, shadow, not transposed, 2, meta.slope, meta.mask_ref, False)
+            else:
+                gx = _layer(s, module, shadow, not transposed, 0, 1.0, None, False)
+        if needs[1]:
+            if not accumulates_into(weight):
+                raise NotImplementedError('the 16-bit path computes weight gradients in plain backward sweeps only '
+                                          '(straight into the fp32 gradient arena)')
+            x_side, y_side = (s, x) if transposed else (x, s)
+            _weight_gradient(shadow, module, x_side, y_side, weight.grad_buffer)
+        if needs[2]:
+            if not accumulates_into(bias):
+                raise NotImplementedError('the 16-bit path computes bias gradients in plain backward sweeps only')
+            sm = s.meta
+            _call('srgan_h_channel_sums', s.data.data_ptr(), bias.grad_buffer.data_ptr(), sm.n, sm.c, sm.h * sm.w, sm.code,
+                  F._stream())
+        return gx, None, None
+    out = F._out(data, (x, weight, bias), backward, 'h_' + shadow.kind + ('_t' if transposed else ''))
+    out.meta = out_meta
+    return out
+
+
+def _weight_gradient(shadow, module, x_side, y_side, into):
+    """into (fp32, the arena's gradient view of the layer's weight) += d loss / d W from the layer's input-side tensor and
+    the (pre-masked) gradient at its output side."""
+    xm, ym = x_side.meta, y_side.meta
+    if shadow.kind == 'conv3x3':
+        _call('srgan_h_conv3x3_wgrad', x_side.data.data_ptr(), y_side.data.data_ptr(), into.data_ptr(), xm.n, xm.c, ym.c, xm.h,
+              xm.w, xm.code, F._stream())
+    else:
+        outputs, inputs = module.weight.shape[0], module.weight.numel() // module.weight.shape[0]
+        _call('srgan_h_linear_wgrad', y_side.data.data_ptr(), x_side.data.data_ptr(), into.data_ptr(), xm.n, outputs, xm.c,
+              outputs, inputs, inputs, 1, 1, shadow.plane, xm.code, F._stream())

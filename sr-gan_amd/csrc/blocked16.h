@@ -1,0 +1,95 @@
+// blocked16.h -- the 16-bit data path (BASELINE.json configs[1] "bf16" and configs[4] "fp16"): what the kernels of
+// blocked16*.hip share.
+//
+// Layout in HBM ("blocked"): a tensor of logical shape [N, C, H, W] is stored as [N][ceil(C / 8)][H][W][8] elements of
+// bf16 (dtype 1) or fp16 (dtype 2): the 8 channels of a group at one pixel are ONE 16-byte slot.  That slot is exactly the
+// k = 8 operand fragment of v_mfma_f32_32x32x16_{bf16,f16} when the reduction runs over channels (forward convolution, data
+// gradient, linear layers): a workgroup copies slots from HBM to LDS and a lane's fragment is one ds_read_b128 -- no
+// conversion, no gather (the fp32-storage mixed kernels of conv3x3.hip spend eight 4-byte loads and eight conversions per
+// slot).  When the reduction runs over PIXELS (weight gradients) the same LDS image is read with ds_read_b64_tr_b16, the
+// hardware's 16-bit transpose read: 16 lanes fetch a 4-pixel x 16-channel block and every lane receives four consecutive
+// pixels of its own channel.  Channels beyond C inside the last group are stored as zeros (the packed weights are zero
+// there too, so they never contribute).  A [N, F] matrix is the H = W = 1 case: plain row-major.
+#pragma once
+#include <type_traits>
+#include "common.h"
+
+namespace srgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 h_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 h_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h_f16x2 __attribute__((ext_vector_type(2)));
+typedef short h_s4 __attribute__((ext_vector_type(4)));
+
+struct alignas(16) Slot { uint32_t v[4]; };      // 8 x 16-bit: channels 8g .. 8g + 7 of one pixel
+
+// two floats -> one packed pair (a in the low half), round to nearest even
+template <int PREC>
+__device__ __forceinline__ uint32_t h_pack2(float a, float b) {
+  if constexpr (PREC == 1) {
+    h_bf16x2 h; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, h);
+  } else {
+    h_f16x2 h; h[0] = (_Float16)a; h[1] = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, h);
+  }
+}
+template <int PREC>
+__device__ __forceinline__ float h_lo(uint32_t u) {
+  if constexpr (PREC == 1) return __uint_as_float(u << 16);
+  else return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xFFFFu));
+}
+template <int PREC>
+__device__ __forceinline__ float h_hi(uint32_t u) {
+  if constexpr (PREC == 1) return __uint_as_float(u & 0xFFFF0000u);
+  else return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+}
+// [value > 0] of a 16-bit float given its bits (bf16 and fp16 alike: sign clear, not zero; NaN counts as positive)
+__device__ __forceinline__ bool h_positive(uint32_t bits16) { return (int16_t)(uint16_t)bits16 > 0; }
+
+template <int PREC>
+__device__ __forceinline__ void h_unpack8(const Slot& s, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = h_lo<PREC>(s.v[i]); f[2 * i + 1] = h_hi<PREC>(s.v[i]); }
+}
+template <int PREC>
+__device__ __forceinline__ Slot h_pack8(const float (&f)[8]) {
+  Slot s;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s.v[i] = h_pack2<PREC>(f[2 * i], f[2 * i + 1]);
+  return s;
+}
+// The derivative of relu (slope 0) / leaky_relu / identity (slope 1) from the sign pattern of the ACTIVATED value:
+// act(z) > 0 <=> z > 0 for slope >= 0, so the 16-bit output itself is the mask (reference: torch's threshold / leaky_relu
+// backward use x > 0).
+__device__ __forceinline__ float h_mask(uint32_t bits16, float slope) { return h_positive(bits16) ? 1.f : slope; }
+
+// ds_read_b64_tr_b16: within every group of 16 lanes, lane t (0..15) supplies the address of 4 consecutive 16-bit elements
+// and RECEIVES element (t & 3) of the chunks supplied by lanes 4j + (t >> 2), j = 0..3 (guide: "lane l, elem j reads
+// lds[(l & 15) + j * 16 + (l >> 4) * 64]" for chunks laid out lane-linearly).  Pointed at blocked slots -- lane s = 4j + u
+// supplies pixel p0 + j, channels 4u .. 4u + 3 of a 16-channel block (u >> 1 picks the group, u & 1 the half of the slot) --
+// lane t receives pixels p0 .. p0 + 3 of channel t: four consecutive k of a pixel-reduction operand.
+__device__ __forceinline__ uint2 h_tr_read(uint32_t lds_byte_address) {
+  const h_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h_s4*)(uintptr_t)lds_byte_address);
+  return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ uint32_t h_lds_address(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int PREC, typename Frag = typename std::conditional<PREC == 1, h_bf16x8, h_f16x8>::type>
+__device__ __forceinline__ f32x16 h_mfma(const Slot& a, const Slot& b, f32x16 c) {
+  if constexpr (PREC == 1)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h_bf16x8, a), __builtin_bit_cast(h_bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h_f16x8, a), __builtin_bit_cast(h_f16x8, b), c, 0, 0, 0);
+}
+
+// Declared in gather_gemm_kernels.hip: the bench's live event bracket around a contraction launch, with explicit bytes.
+int profile_bracket_begin(hipStream_t stream);
+int profile_bracket_end_bytes(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split,
+                              double bytes, int precision);
+
+}  // namespace srgan

@@ -1,0 +1,844 @@
+// blocked16.hip -- the 16-bit data path: layout conversions, streaming kernels, the 3x3 convolution family.
+//
+// Reference graphs served: VGG-16 (age/vgg.py:28-53,70-84: conv3x3 + bias -> ReLU, max-pool 2x2, two Linear + ReLU)
+// with activations, gradients and a shadow copy of the weights stored as bf16 / fp16 in the blocked layout of blocked16.h;
+// master weights, weight gradients, Adam and every loss stay fp32.  The activation is FUSED: a convolution's epilogue adds
+// the bias and applies relu / leaky_relu before the 16-bit store, and every kernel that produces a gradient with respect
+// to an activated tensor multiplies by the activation's derivative on the way out (`mask by reference`: the sign pattern
+// of the activated tensor itself), so neither the pre-activation tensor nor the un-masked gradient ever exists in HBM.
+//
+//   hconv3x3_kernel      out = epi(conv3x3_s1_p1(in, w) [+ bias])      forward, data gradient (flipped packed weights) and
+//                                                                      the linearised forward of the penalty's double backward
+//   hwgrad3x3_kernel     gw += gy (x) x over pixels, all nine taps     ds_read_b64_tr_b16 operands, partial blocks +
+//                                                                      an ordered finish (bit-reproducible)
+//   pool / pack / unpack / add / channel sums                          HBM-bound streaming kernels on 16-byte slots
+#include <type_traits>
+#include "blocked16.h"
+#include "split_finish.h"
+#include <stdlib.h>
+
+namespace srgan {
+
+// ---------------------------------------------------------------------------------------------------- streaming kernels
+// fp32 NCHW -> blocked.  One thread per slot (n, group, pixel): eight loads, each coalesced across the lanes along the
+// plane.  Optional mask by reference (the gradient w.r.t. an activated tensor arrives here in fp32 from the loss side).
+template <int PREC>
+__global__ __launch_bounds__(256) void h_pack_kernel(const float* __restrict__ x, Slot* __restrict__ out,
+                                                     const Slot* __restrict__ ref, float slope, int64_t slots, int32_t C,
+                                                     int32_t CG, int32_t HW) {
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
+    const int pix = (int)(s % HW);
+    const int64_t ng = s / HW;
+    const int g = (int)(ng % CG);
+    const int64_t n = ng / CG;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * g + j;
+      v[j] = c < C ? x[(n * C + c) * HW + pix] : 0.f;
+    }
+    if (ref) {
+      const Slot r = ref[s];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= h_mask((r.v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, slope);
+    }
+    out[s] = h_pack8<PREC>(v);
+  }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void h_unpack_kernel(const Slot* __restrict__ x, float* __restrict__ out, int64_t slots,
+                                                       int32_t C, int32_t CG, int32_t HW) {
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
+    const int pix = (int)(s % HW);
+    const int64_t ng = s / HW;
+    const int g = (int)(ng % CG);
+    const int64_t n = ng / CG;
+    float v[8];
+    h_unpack8<PREC>(x[s], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * g + j;
+      if (c < C) out[(n * C + c) * HW + pix] = v[j];
+    }
+  }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void h_add_kernel(const Slot* __restrict__ a, const Slot* __restrict__ b,
+                                                    Slot* __restrict__ out, int64_t slots) {
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
+    float x[8], y[8];
+    h_unpack8<PREC>(a[s], x);
+    h_unpack8<PREC>(b[s], y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] += y[j];
+    out[s] = h_pack8<PREC>(x);
+  }
+}
+
+// Channel sums (a bias gradient): part[(g * parts + part) * 8 + j] = sum over this block's share of (n, pixel) of channel
+// 8g + j; h_channel_sums_finish_kernel adds the parts of a channel in part order into the fp32 gradient (bit-reproducible).
+template <int PREC>
+__global__ __launch_bounds__(256) void h_channel_sums_kernel(const Slot* __restrict__ x, float* __restrict__ part, int32_t N,
+                                                             int32_t CG, int32_t HW, int32_t parts) {
+  __shared__ float scratch[4 * 8];
+  const int g = (int)blockIdx.x, part_id = (int)blockIdx.y;
+  const int64_t total = (int64_t)N * HW;
+  float sum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+  for (int64_t i = (int64_t)part_id * 256 + threadIdx.x; i < total; i += (int64_t)parts * 256) {
+    const int64_t n = i / HW;
+    const int pix = (int)(i - n * HW);
+    float v[8];
+    h_unpack8<PREC>(x[(n * CG + g) * HW + pix], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] += v[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float w = wave_sum(sum[j]);
+    if (lane == 0) scratch[wave * 8 + j] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int j = threadIdx.x;
+    part[((int64_t)g * parts + part_id) * 8 + j] = (scratch[j] + scratch[8 + j]) + (scratch[16 + j] + scratch[24 + j]);
+  }
+}
+
+__global__ __launch_bounds__(256) void h_channel_sums_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                    int32_t C, int32_t parts) {
+  const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (c >= C) return;
+  const float* mine = part + (int64_t)(c >> 3) * parts * 8 + (c & 7);
+  float total = 0.f;
+  for (int s = 0; s < parts; ++s) total += mine[s * 8];
+  out[c] += total;
+}
+
+// 2x2 / stride 2 max-pool (reference age/vgg.py:76).  The arg-max is not stored: every kernel that needs it finds the FIRST
+// window position (scan order (0,0), (0,1), (1,0), (1,1): torch's tie rule) that holds the maximum.
+template <int PREC>
+__device__ __forceinline__ void h_pool_window(const Slot* __restrict__ x, int64_t base, int32_t W, float (&m)[8], int (&at)[8]) {
+  float v[4][8];
+  h_unpack8<PREC>(x[base], v[0]);
+  h_unpack8<PREC>(x[base + 1], v[1]);
+  h_unpack8<PREC>(x[base + W], v[2]);
+  h_unpack8<PREC>(x[base + W + 1], v[3]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    m[j] = v[0][j]; at[j] = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (v[q][j] > m[j]) { m[j] = v[q][j]; at[j] = q; }
+  }
+}
+
+// mode 0: out = pool(x)             [pooled shape]
+// mode 2: out = gather of `g` (input shape) at the arg-max of x      [pooled shape]   (the tangent of the double backward)
+template <int PREC, int MODE>
+__global__ __launch_bounds__(256) void h_maxpool_kernel(const Slot* __restrict__ x, const Slot* __restrict__ g,
+                                                        Slot* __restrict__ out, int64_t planes, int32_t H, int32_t W) {
+  const int OH = H / 2, OW = W / 2;
+  const int64_t total = planes * OH * OW;
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < total; s += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(s % OW);
+    const int64_t rest = s / OW;
+    const int oy = (int)(rest % OH);
+    const int64_t plane = rest / OH;
+    const int64_t base = (plane * H + 2 * oy) * W + 2 * ox;
+    float m[8]; int at[8];
+    h_pool_window<PREC>(x, base, W, m, at);
+    if (MODE == 0) {
+      out[s] = h_pack8<PREC>(m);
+    } else {
+      float v[4][8], r[8];
+      h_unpack8<PREC>(g[base], v[0]);
+      h_unpack8<PREC>(g[base + 1], v[1]);
+      h_unpack8<PREC>(g[base + W], v[2]);
+      h_unpack8<PREC>(g[base + W + 1], v[3]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = at[j] == 0 ? v[0][j] : (at[j] == 1 ? v[1][j] : (at[j] == 2 ? v[2][j] : v[3][j]));
+      out[s] = h_pack8<PREC>(r);
+    }
+  }
+}
+
+// Backward: gx (input shape) = the pooled gradient placed at the arg-max, times the derivative of the activation that
+// produced x (mask by x itself when `masked`): the gradient w.r.t. the PRE-activation tensor in one pass.
+template <int PREC>
+__global__ __launch_bounds__(256) void h_maxpool_bwd_kernel(const Slot* __restrict__ x, const Slot* __restrict__ gp,
+                                                            Slot* __restrict__ gx, int64_t planes, int32_t H, int32_t W,
+                                                            int masked, float slope) {
+  const int OH = H / 2, OW = W / 2;
+  const int64_t total = planes * OH * OW;
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < total; s += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(s % OW);
+    const int64_t rest = s / OW;
+    const int oy = (int)(rest % OH);
+    const int64_t plane = rest / OH;
+    const int64_t base = (plane * H + 2 * oy) * W + 2 * ox;
+    float m[8]; int at[8];
+    h_pool_window<PREC>(x, base, W, m, at);
+    float g[8];
+    h_unpack8<PREC>(gp[s], g);
+    if (masked) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] *= m[j] > 0.f ? 1.f : slope;
+    }
+    float r[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[q][j] = at[j] == q ? g[j] : 0.f;
+    gx[base] = h_pack8<PREC>(r[0]);
+    gx[base + 1] = h_pack8<PREC>(r[1]);
+    gx[base + W] = h_pack8<PREC>(r[2]);
+    gx[base + W + 1] = h_pack8<PREC>(r[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- packed weights
+// A convolution's weights in operand slots, rounded once per optimizer step (the "16-bit shadow" of the fp32 masters):
+//   packed[((chunk * T + tap) * 2 + group) * CO + o] = the 8 channels chunk * 16 + group * 8 ... + 7 of tap `tap` of output
+//   channel o, element (o, c, kh, kw) at w[base + o * so + c * si + kh * skh + kw * skw]   (zero beyond CI)
+// T = R * S taps.  The data gradient's shadow is the same call with the channel roles swapped and mirrored taps (base at the
+// last tap, negative tap strides).
+template <int PREC>
+__global__ __launch_bounds__(256) void h_pack_conv_weights_kernel(const float* __restrict__ w, Slot* __restrict__ packed,
+                                                                  int64_t slots, int32_t CO, int32_t CI, int32_t R, int32_t S,
+                                                                  int32_t base, int32_t so, int32_t si, int32_t skh, int32_t skw) {
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= slots) return;
+  const int T = R * S;
+  const int o = (int)(slot % CO);
+  const int64_t rest = slot / CO;
+  const int g = (int)(rest & 1);
+  const int64_t ct = rest >> 1;
+  const int tap = (int)(ct % T), chunk = (int)(ct / T);
+  const int kh = tap / S, kw = tap - kh * S;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = chunk * 16 + g * 8 + j;
+    v[j] = c < CI ? w[base + o * so + c * si + kh * skh + kw * skw] : 0.f;
+  }
+  packed[slot] = h_pack8<PREC>(v);
+}
+
+// ---------------------------------------------------------------------------------------------------- 3x3 convolution
+struct HConv3Params {
+  const Slot* in; const Slot* wp; Slot* out; const float* bias; const Slot* ref;
+  float slope;
+  int32_t epi;                 // 0 plain, 1 bias (optional) + leaky(slope), 2 multiply by mask(ref, slope)
+  int32_t N, CGI, CGO, CO, C_real, H, W;      // CO = rows of the packed weights (>= 8 * CGO is not required: rows beyond are zero)
+  int32_t chunks, chunks_per_split;
+  int32_t tiles_x, tiles_y, tiles_m;
+  float* split_ws; unsigned int* split_tickets;
+  int32_t xcd_remap;
+};
+
+__device__ unsigned int g_hconv3_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_TILES];
+
+// One workgroup (4 waves) = BM output channels x P = 128 * NI pixels.  The pixel tile is IMG x ROWS x TW with
+// IMG * ROWS * TW = P: a ROWS x 32 band of one image on wide planes, whole small images side by side on the 16 / 8 / 4
+// pixel planes of VGG's later stages (a one-image tile would leave most MFMA columns outside the image there).  Per
+// 16-channel chunk the halo patch [2 groups][IMG][(ROWS + 2) x (TW + 2)] and the weight slice [9 taps][2 groups][BM] are
+// staged in LDS as operand slots (register-staged: the next chunk's 16-byte loads are in flight during the current
+// chunk's 9 * MI * NI MFMAs) and every fragment is one ds_read_b128.
+template <int BM, int NI, int TW, int ROWS, int PREC>
+__global__ __launch_bounds__(256, 2) void hconv3x3_kernel(const HConv3Params p) {
+  constexpr int P = 128 * NI, IMG = P / (ROWS * TW), PW = TW + 2, PH = ROWS + 2, PLANE = PH * PW;
+  static_assert(IMG * ROWS * TW == P && IMG >= 1, "the pixel tile is IMG x ROWS x TW");
+  constexpr int MI = BM / 32;
+  constexpr int PATCH_G = IMG * PLANE, PATCH_Q = 2 * PATCH_G, WT_Q = 18 * BM, STAGE_Q = PATCH_Q + WT_Q;
+  constexpr int NP = (PATCH_Q + 255) / 256, NW = (WT_Q + 255) / 256;
+  __shared__ Slot lds[2 * STAGE_Q];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  int block = blockIdx.x;
+  if (p.xcd_remap) block = (block & 7) * ((int)gridDim.x >> 3) + (block >> 3);
+  const int logical_block = block;
+  const int tm = block % p.tiles_m; block /= p.tiles_m;
+  const int tx = block % p.tiles_x; block /= p.tiles_x;
+  const int ty = block % p.tiles_y;
+  const int n0 = (block / p.tiles_y) * IMG;
+  const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
+  const int cbeg = (int)blockIdx.y * p.chunks_per_split;
+  const int cend = min(p.chunks, cbeg + p.chunks_per_split);
+  const int HW = p.H * p.W;
+
+  int poff[NP], pgrp[NP], woff[NW];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) {
+    const int flat = e * 256 + tid;
+    const int g = flat / PATCH_G, rest = flat - g * PATCH_G;
+    const int img = rest / PLANE, pix = rest - img * PLANE;
+    const int py = pix / PW, px = pix - py * PW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool ok = flat < PATCH_Q && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && n0 + img < p.N;
+    poff[e] = ok ? img * p.CGI * HW + y * p.W + x : -1;
+    pgrp[e] = g;
+  }
+#pragma unroll
+  for (int e = 0; e < NW; ++e) {
+    const int flat = e * 256 + tid;
+    const int o = flat % BM, tg = flat / BM;
+    const bool ok = flat < WT_Q && (m0 + o) < p.CO;
+    woff[e] = ok ? tg * p.CO + m0 + o : -1;
+  }
+  const Slot* in_n = p.in + (int64_t)n0 * p.CGI * HW;
+
+  Slot rp[NP], rw[NW];
+  auto fetch = [&](int c) {                                 // raw loads only: validity is applied at stage time
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int g = 2 * c + pgrp[e];
+      const bool ok = poff[e] >= 0 && g < p.CGI;
+      rp[e] = in_n[ok ? g * HW + poff[e] : 0];
+    }
+#pragma unroll
+    for (int e = 0; e < NW; ++e) rw[e] = p.wp[(int64_t)c * (18 * p.CO) + (woff[e] >= 0 ? woff[e] : 0)];
+  };
+  auto stage = [&](int c, Slot* stage_base) {
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int flat = e * 256 + tid;
+      Slot v = rp[e];
+      if (!(poff[e] >= 0 && 2 * c + pgrp[e] < p.CGI)) v = Slot{{0u, 0u, 0u, 0u}};
+      if (flat < PATCH_Q) stage_base[flat] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int flat = e * 256 + tid;
+      Slot v = rw[e];
+      if (woff[e] < 0) v = Slot{{0u, 0u, 0u, 0u}};
+      if (flat < WT_Q) stage_base[PATCH_Q + flat] = v;
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  int b_lane[NI];                                           // this lane's pixel of column block ni in the patch (window origin)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int q = (wave * NI + ni) * 32 + l31;
+    b_lane[ni] = lhi * PATCH_G + (q / (ROWS * TW)) * PLANE + ((q / TW) % ROWS) * PW + q % TW;
+  }
+  const int a_lane = PATCH_Q + lhi * BM + l31;              // + tap * 2 * BM + mi * 32
+
+  if (cbeg < cend) {
+    fetch(cbeg);
+    stage(cbeg, lds);
+    __syncthreads();
+    int cur = 0;
+    for (int c = cbeg; c < cend; ++c) {
+      const bool more = c + 1 < cend;
+      if (more) fetch(c + 1);
+      const Slot* st = lds + cur * STAGE_Q;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        Slot a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = st[a_lane + tap * 2 * BM + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = st[b_lane[ni] + kh * PW + kw];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = h_mfma<PREC>(a[mi], b[ni], acc[mi][ni]);
+      }
+      if (more) stage(c + 1, lds + (cur ^ 1) * STAGE_Q);     // the other stage: everyone left it at the previous barrier
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  if (gridDim.y > 1) {       // K split, ordered finish: the tile's last workgroup goes on with the sum of all slices, in slice order
+    constexpr int COUNT = MI * NI * 16;
+    if (!split_finish_ordered<COUNT, 256>(p.split_ws + (int64_t)logical_block * gridDim.y * (COUNT * 256), (int)blockIdx.y,
+                                          (int)gridDim.y, p.split_tickets + logical_block,
+                                          [&](int i) { return acc[i / (NI * 16)][(i / 16) % NI][i % 16]; },
+                                          [&](int i, float v) { acc[i / (NI * 16)][(i / 16) % NI][i % 16] = v; }))
+      return;
+  }
+
+  // Epilogue.  C/D fragment: column = pixel (lane & 31), rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): registers 4q .. 4q + 3
+  // are four CONSECUTIVE output channels = 8 bytes of the pixel's slot of group (m0 + 32 mi) / 8 + q; the 32 lanes of a half
+  // cover 32 consecutive slots (with the other half: 512 contiguous bytes per store instruction).
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int q = (wave * NI + ni) * 32 + l31;
+    const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
+    if (n >= p.N || y >= p.H || x >= p.W) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int group = (m0 + mi * 32) / 8 + qd;
+        if (group >= p.CGO) continue;
+        const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
+        const int64_t slot = ((int64_t)n * p.CGO + group) * HW + y * p.W + x;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * qd + j];
+        if (p.epi == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (p.bias != nullptr && o + j < p.C_real) v[j] += p.bias[o + j];
+            v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+          }
+        } else if (p.epi == 2) {
+          const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
+          v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
+          v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
+        }
+        uint2 packed;
+        packed.x = h_pack2<PREC>(v[0], v[1]);
+        packed.y = h_pack2<PREC>(v[2], v[3]);
+        *(reinterpret_cast<uint2*>(p.out + slot) + lhi) = packed;
+      }
+    }
+  }
+}
+
+struct HConv3Plan { int bm, ni, tw, rows, tiles_x, tiles_y, tiles_m, tiles_n, split, chunks_per; int64_t blocks; };
+
+static bool hconv3_plan(int32_t N, int32_t CGI, int32_t CO_rows, int32_t H, int32_t W, HConv3Plan& plan) {
+  // tile width and the image rows of a 128-pixel (NI = 1) / 256-pixel (NI = 2) tile
+  int tw, rows_for_ni[3] = {0, 0, 0};
+  bool ni2_ok = true;
+  if (W > 16) { tw = 32; rows_for_ni[1] = 4; rows_for_ni[2] = 8; }
+  else if (W == 8 && H == 8) { tw = 8; rows_for_ni[1] = 8; rows_for_ni[2] = 8; }                 // whole images side by side
+  else if (W == 4 && H == 4) { tw = 4; rows_for_ni[1] = 4; rows_for_ni[2] = 4; ni2_ok = false; } // (32 KB of LDS per stage at NI = 2)
+  else { tw = 16; rows_for_ni[1] = 8; rows_for_ni[2] = 16; }
+  plan.tw = tw;
+  plan.bm = CO_rows > 32 ? 64 : 32;
+  plan.tiles_m = (CO_rows + plan.bm - 1) / plan.bm;
+  auto count = [&](int ni) {
+    const int rows = rows_for_ni[ni];
+    const int img = 128 * ni / (rows * tw);
+    const int64_t tx = (W + tw - 1) / tw, ty = img > 1 ? 1 : (H + rows - 1) / rows, tn = (N + img - 1) / img;
+    return tx * ty * tn * plan.tiles_m;
+  };
+  int ni = 2;
+  if (!ni2_ok || count(2) < 512) ni = 1;
+  plan.ni = ni;
+  plan.rows = rows_for_ni[ni];
+  const int img = 128 * ni / (plan.rows * tw);
+  plan.tiles_x = (W + tw - 1) / tw;
+  plan.tiles_y = img > 1 ? 1 : (H + plan.rows - 1) / plan.rows;
+  plan.tiles_n = (N + img - 1) / img;
+  plan.blocks = count(ni);
+  if (plan.blocks >= ((int64_t)1 << 31)) return false;
+  const int chunks = (CGI + 1) / 2;
+  int split = 1;
+  if (plan.blocks < 384 && chunks >= 4 && plan.blocks <= SPLIT_TICKET_TILES) {
+    split = (int)((512 + plan.blocks - 1) / plan.blocks);
+    if (split > chunks / 2) split = chunks / 2;
+    if (split > 16) split = 16;
+  }
+  plan.chunks_per = (chunks + split - 1) / split;
+  plan.split = (chunks + plan.chunks_per - 1) / plan.chunks_per;
+  return true;
+}
+
+template <int BM, int NI, int PREC>
+static void hconv3_launch_tiles(const HConv3Params& p, int tw, dim3 grid, hipStream_t stream) {
+  if (tw == 32) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 32, 4 * NI, PREC>), grid, dim3(256), 0, stream, p);
+  else if (tw == 16) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 16, 8 * NI, PREC>), grid, dim3(256), 0, stream, p);
+  else if (tw == 8) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 8, 8, PREC>), grid, dim3(256), 0, stream, p);
+  else if constexpr (NI == 1) hipLaunchKernelGGL((hconv3x3_kernel<BM, 1, 4, 4, PREC>), grid, dim3(256), 0, stream, p);
+}
+
+template <int PREC>
+static void hconv3_launch(const HConv3Params& p, const HConv3Plan& plan, dim3 grid, hipStream_t stream) {
+  if (plan.bm == 64) {
+    if (plan.ni == 2) hconv3_launch_tiles<64, 2, PREC>(p, plan.tw, grid, stream);
+    else hconv3_launch_tiles<64, 1, PREC>(p, plan.tw, grid, stream);
+  } else {
+    if (plan.ni == 2) hconv3_launch_tiles<32, 2, PREC>(p, plan.tw, grid, stream);
+    else hconv3_launch_tiles<32, 1, PREC>(p, plan.tw, grid, stream);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- 3x3 weight gradient
+//   gw[co, ci, kh, kw] += sum_{n, y, x} gy[n, co, y, x] * x[n, ci, y + kh - 1, x + kw - 1]        (fp32, [CO][CI][3][3])
+// M = co, N = ci, K = pixels: both operands are reduced over the pixel index, which the blocked layout does NOT keep
+// contiguous per channel -- the fragments come from LDS through ds_read_b64_tr_b16 (blocked16.h).  A workgroup (4 waves) owns
+// a 64 x 64 (co x ci) block of gw for ALL nine taps: wave (mi, ni) keeps nine 32 x 32 accumulators (144 registers) while the
+// workgroup walks its share of the 64-pixel tiles; per tile the gy slots [8 groups][64 pixels] and the x halo patch
+// [8 groups][IMG][(ROWS + 2) x (TW + 2)] are staged once (register-staged, one LDS stage) and all nine taps read them: per
+// 16-pixel step one A fragment and nine shifted B fragments, two transpose reads each.  The walkers of a block leave their
+// accumulators in the caller's workspace in thread order; hwgrad3x3_finish_kernel adds them in walker order into gw.
+struct HWgrad3Params {
+  const Slot* x; const Slot* gy; float* partial;
+  int32_t N, CGX, CGY, H, W;
+  int32_t tiles_ci, tiles_x, tiles_y, tiles_n, pixel_tiles, walkers;
+};
+
+constexpr int HWGRAD_P = 64;      // pixels per staged tile (128 needs 44+ staging registers next to the 144 accumulators: spills)
+constexpr int h_pad_stride(int slots) { return ((slots + 15) / 16) * 16 + 4; }     // = 4 slots (mod 16): the two groups of a
+                                                                                  // transpose read land 64 bytes apart
+template <int TW, int ROWS, int PREC>
+__global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p) {
+  constexpr int P = HWGRAD_P, IMG = P / (ROWS * TW), PW = TW + 2, PH = ROWS + 2, PLANE = PH * PW;
+  static_assert(IMG * ROWS * TW == P && IMG >= 1, "the pixel tile is IMG x ROWS x TW");
+  constexpr int GS = h_pad_stride(P), XS = h_pad_stride(IMG * PLANE);       // group strides of the two LDS images (slots)
+  constexpr int GQ = 8 * P, XQ = 8 * IMG * PLANE;                           // slots staged per tile
+  constexpr int NG = GQ / 256, NX = (XQ + 255) / 256;
+  __shared__ Slot lds[8 * GS + 8 * XS];
+  Slot* gs = lds;
+  Slot* xs = lds + 8 * GS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = wave >> 1, ni = wave & 1;
+  const int tci = (int)blockIdx.x % p.tiles_ci, tco = (int)blockIdx.x / p.tiles_ci;
+  const int walker = (int)blockIdx.y;
+  const int HW = p.H * p.W;
+
+  // staging ownership: gy slot e * 256 + tid -> (group, tile pixel); x slot -> (group, image, patch position); the index
+  // arithmetic (compile-time divisors) is redone where it is used instead of being kept in registers
+  Slot rg[NG], rx[NX];
+  uint32_t okg = 0, okx = 0;
+  auto fetch = [&](int tile) {
+    const int tx = tile % p.tiles_x;
+    const int rest_t = tile / p.tiles_x;
+    const int ty = rest_t % p.tiles_y;
+    const int n0 = (rest_t / p.tiles_y) * IMG;
+    const int y0 = ty * ROWS, x0 = tx * TW;
+    okg = okx = 0;
+#pragma unroll
+    for (int e = 0; e < NG; ++e) {
+      const int flat = e * 256 + tid;
+      const int grp = flat / P, q = flat % P;
+      const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
+      const int group = tco * 8 + grp;
+      const bool ok = n < p.N && y < p.H && x < p.W && group < p.CGY;
+      okg |= (ok ? 1u : 0u) << e;
+      rg[e] = p.gy[ok ? ((int64_t)n * p.CGY + group) * HW + y * p.W + x : 0];
+    }
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int flat = e * 256 + tid;
+      const int grp = flat / (IMG * PLANE), rest = flat - grp * (IMG * PLANE);
+      const int img = rest / PLANE, pix = rest % PLANE;
+      const int n = n0 + img, y = y0 - 1 + pix / PW, x = x0 - 1 + pix % PW;
+      const int group = tci * 8 + grp;
+      const bool ok = flat < XQ && n < p.N && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && group < p.CGX;
+      okx |= (ok ? 1u : 0u) << e;
+      rx[e] = p.x[ok ? ((int64_t)n * p.CGX + group) * HW + y * p.W + x : 0];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // Fragment addressing (blocked16.h, h_tr_read): 16-lane group G = lane >> 4: row block rb = G & 1 (channels 16 rb .. of the
+  // wave's 32), k half = G >> 1 (pixels 8 khalf .. of the 16-pixel step); within the group lane s = 4 j + u supplies pixel j
+  // of its quad, channels 4 u .. 4 u + 3.
+  const int G = lane >> 4, rb = G & 1, khalf = G >> 1, s = lane & 15, j = s >> 2, u = s & 3;
+  constexpr int HALF = TW >= 16 ? 8 : (TW == 8 ? PW : 2 * PW);     // patch offset of pixel 8 of a 16-pixel step
+  constexpr int QUAD = TW >= 8 ? 4 : PW;                           // ... of the second quad of a half
+  const uint32_t a_base = h_lds_address(gs) + (uint32_t)(((4 * mi + 2 * rb + (u >> 1)) * GS + 8 * khalf + j) * 16 + (u & 1) * 8);
+  const uint32_t b_base = h_lds_address(xs) + (uint32_t)(((4 * ni + 2 * rb + (u >> 1)) * XS + khalf * HALF + j) * 16 + (u & 1) * 8);
+
+  int tile = walker;
+  if (tile < p.pixel_tiles) fetch(tile);
+  for (; tile < p.pixel_tiles; tile += p.walkers) {
+    __syncthreads();                        // the previous tile's reads are done
+#pragma unroll
+    for (int e = 0; e < NG; ++e) {
+      const int flat = e * 256 + tid;
+      Slot v = rg[e];
+      if (!((okg >> e) & 1u)) v = Slot{{0u, 0u, 0u, 0u}};
+      gs[(flat / P) * GS + flat % P] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int flat = e * 256 + tid;
+      const int grp = flat / (IMG * PLANE), rest = flat - grp * (IMG * PLANE);
+      Slot v = rx[e];
+      if (!((okx >> e) & 1u)) v = Slot{{0u, 0u, 0u, 0u}};
+      if (flat < XQ) xs[grp * XS + rest] = v;
+    }
+    __syncthreads();
+    const int next = tile + p.walkers;
+    if (next < p.pixel_tiles) fetch(next);
+#pragma unroll 2
+    for (int t = 0; t < P / 16; ++t) {       // (not fully unrolled: the scheduler otherwise hoists the transpose reads of many steps and spills)
+      const int pix = 16 * t;                                                        // first pixel of the step (tile order)
+      const int origin = ((pix / (ROWS * TW)) * PH + (pix / TW) % ROWS) * PW + pix % TW;   // its window origin in the patch
+      Slot a;
+      const uint2 a0 = h_tr_read(a_base + pix * 16), a1 = h_tr_read(a_base + (pix + 4) * 16);
+      a.v[0] = a0.x; a.v[1] = a0.y; a.v[2] = a1.x; a.v[3] = a1.y;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int shift = origin + (tap / 3) * PW + tap % 3;
+        Slot b;
+        const uint2 b0 = h_tr_read(b_base + shift * 16), b1 = h_tr_read(b_base + (shift + QUAD) * 16);
+        b.v[0] = b0.x; b.v[1] = b0.y; b.v[2] = b1.x; b.v[3] = b1.y;
+        acc[tap] = h_mfma<PREC>(a, b, acc[tap]);
+      }
+    }
+  }
+
+  float* mine = p.partial + ((int64_t)blockIdx.x * p.walkers + walker) * (9 * 16 * 256) + tid;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[(t * 16 + r) * 256] = acc[t][r];
+}
+
+// gw[co][ci][tap] += sum over the walkers (in walker order) of the block's partial accumulators.  One thread per element of gw
+// (coalesced writes); the read index undoes the accumulator layout: wave = (co' / 32) * 2 + ci' / 32, C/D row co' % 32 =
+// (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column ci' % 32 = lane & 31.
+__global__ __launch_bounds__(256) void hwgrad3x3_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw,
+                                                               int32_t CO, int32_t CI, int32_t tiles_ci, int32_t walkers) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)CO * CI * 9) return;
+  const int tap = (int)(idx % 9);
+  const int64_t oc = idx / 9;
+  const int ci = (int)(oc % CI), co = (int)(oc / CI);
+  const int tco = co >> 6, tci = ci >> 6, col = ci & 63, row = co & 63;
+  const int wave = (row >> 5) * 2 + (col >> 5), r32 = row & 31, c32 = col & 31;
+  const int lhi = (r32 >> 2) & 1, r = (r32 & 3) + 4 * (r32 >> 3);
+  const int thread = wave * 64 + lhi * 32 + c32;
+  const float* mine = partial + (int64_t)(tco * tiles_ci + tci) * walkers * (9 * 16 * 256) + (tap * 16 + r) * 256 + thread;
+  float total = 0.f;
+  for (int w = 0; w < walkers; ++w) total += mine[(int64_t)w * (9 * 16 * 256)];
+  gw[idx] += total;
+}
+
+float* partial_workspace(size_t bytes, hipStream_t stream);
+
+static int check_dtype(int dtype) {
+  SRGAN_REQUIRE(dtype == 1 || dtype == 2, SRGAN_EINVAL, "blocked 16-bit tensors are bf16 (1) or fp16 (2)");
+  return SRGAN_OK;
+}
+
+}  // namespace srgan
+
+using namespace srgan;
+
+extern "C" {
+
+int srgan_h_pack(const float* x, void* out, const void* mask_ref, float slope, int32_t N, int32_t C, int64_t HW, int dtype,
+                 hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(x && out && N >= 0 && C > 0 && HW > 0 && HW < ((int64_t)1 << 31), SRGAN_EINVAL, "srgan_h_pack arguments");
+  const int CG = (C + 7) / 8;
+  const int64_t slots = (int64_t)N * CG * HW;
+  if (slots == 0) return SRGAN_OK;
+  const dim3 grid(stream_grid(slots, 256));
+  if (dtype == 1) hipLaunchKernelGGL(h_pack_kernel<1>, grid, dim3(256), 0, stream, x, (Slot*)out, (const Slot*)mask_ref, slope, slots, C, CG, (int32_t)HW);
+  else hipLaunchKernelGGL(h_pack_kernel<2>, grid, dim3(256), 0, stream, x, (Slot*)out, (const Slot*)mask_ref, slope, slots, C, CG, (int32_t)HW);
+  return launch_status();
+}
+
+int srgan_h_unpack(const void* x, float* out, int32_t N, int32_t C, int64_t HW, int dtype, hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(x && out && N >= 0 && C > 0 && HW > 0 && HW < ((int64_t)1 << 31), SRGAN_EINVAL, "srgan_h_unpack arguments");
+  const int CG = (C + 7) / 8;
+  const int64_t slots = (int64_t)N * CG * HW;
+  if (slots == 0) return SRGAN_OK;
+  const dim3 grid(stream_grid(slots, 256));
+  if (dtype == 1) hipLaunchKernelGGL(h_unpack_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, out, slots, C, CG, (int32_t)HW);
+  else hipLaunchKernelGGL(h_unpack_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)x, out, slots, C, CG, (int32_t)HW);
+  return launch_status();
+}
+
+int srgan_h_add(const void* a, const void* b, void* out, int64_t slots, int dtype, hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(a && b && out && slots >= 0, SRGAN_EINVAL, "srgan_h_add arguments");
+  if (slots == 0) return SRGAN_OK;
+  const dim3 grid(stream_grid(slots, 256));
+  if (dtype == 1) hipLaunchKernelGGL(h_add_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)a, (const Slot*)b, (Slot*)out, slots);
+  else hipLaunchKernelGGL(h_add_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)a, (const Slot*)b, (Slot*)out, slots);
+  return launch_status();
+}
+
+// out[c] += sum over n and pixels of x[n, c, pixel]   (c < C; fp32; the bias gradient of a fused convolution / linear layer)
+int srgan_h_channel_sums(const void* x, float* out, int32_t N, int32_t C, int64_t HW, int dtype, hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(x && out && N > 0 && C > 0 && HW > 0 && HW < ((int64_t)1 << 31), SRGAN_EINVAL, "srgan_h_channel_sums arguments");
+  const int CG = (C + 7) / 8;
+  const int64_t per_group = (int64_t)N * HW;
+  int parts = (int)((per_group + 4095) / 4096);
+  if (parts > 256) parts = 256;
+  if (parts < 1) parts = 1;
+  while (parts > 1 && (int64_t)parts * CG > 4096) parts >>= 1;
+  float* part = partial_workspace((size_t)CG * parts * 8 * sizeof(float), stream);
+  SRGAN_REQUIRE(part, SRGAN_EINVAL, "srgan_h_channel_sums: register a workspace for this stream first (srgan_set_workspace)");
+  const dim3 grid((unsigned)CG, (unsigned)parts);
+  if (dtype == 1) hipLaunchKernelGGL(h_channel_sums_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
+  else hipLaunchKernelGGL(h_channel_sums_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
+  hipLaunchKernelGGL(h_channel_sums_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, out, C, parts);
+  return launch_status();
+}
+
+// mode 0: out = maxpool2x2(x); mode 2: out = `g` gathered at the arg-max of x (both [planes][H/2][W/2] slots, planes = N * groups)
+int srgan_h_maxpool2(const void* x, const void* g, void* out, int64_t planes, int32_t H, int32_t W, int mode, int dtype,
+                     hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(x && out && planes >= 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && (mode == 0 || (mode == 2 && g)),
+                SRGAN_EINVAL, "srgan_h_maxpool2 arguments (even planes; mode 0 or 2)");
+  const int64_t total = planes * (H / 2) * (W / 2);
+  if (total == 0) return SRGAN_OK;
+  const dim3 grid(stream_grid(total, 256));
+  if (dtype == 1) {
+    if (mode == 0) hipLaunchKernelGGL((h_maxpool_kernel<1, 0>), grid, dim3(256), 0, stream, (const Slot*)x, (const Slot*)g, (Slot*)out, planes, H, W);
+    else hipLaunchKernelGGL((h_maxpool_kernel<1, 2>), grid, dim3(256), 0, stream, (const Slot*)x, (const Slot*)g, (Slot*)out, planes, H, W);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((h_maxpool_kernel<2, 0>), grid, dim3(256), 0, stream, (const Slot*)x, (const Slot*)g, (Slot*)out, planes, H, W);
+    else hipLaunchKernelGGL((h_maxpool_kernel<2, 2>), grid, dim3(256), 0, stream, (const Slot*)x, (const Slot*)g, (Slot*)out, planes, H, W);
+  }
+  return launch_status();
+}
+
+// gx (shape of x) = gp placed at the arg-max of x, times mask(x, slope) when `masked`
+int srgan_h_maxpool2_bwd(const void* x, const void* gp, void* gx, int64_t planes, int32_t H, int32_t W, int masked, float slope,
+                         int dtype, hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(x && gp && gx && planes >= 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SRGAN_EINVAL,
+                "srgan_h_maxpool2_bwd arguments");
+  const int64_t total = planes * (H / 2) * (W / 2);
+  if (total == 0) return SRGAN_OK;
+  const dim3 grid(stream_grid(total, 256));
+  if (dtype == 1) hipLaunchKernelGGL(h_maxpool_bwd_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, (const Slot*)gp, (Slot*)gx, planes, H, W, masked, slope);
+  else hipLaunchKernelGGL(h_maxpool_bwd_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)x, (const Slot*)gp, (Slot*)gx, planes, H, W, masked, slope);
+  return launch_status();
+}
+
+// Slots of a packed convolution weight tensor of CO rows, CI reduced channels and R x S taps.
+int64_t srgan_h_conv_weight_slots(int32_t CO, int32_t CI, int32_t R, int32_t S) {
+  return (int64_t)((CI + 15) / 16) * R * S * 2 * CO;
+}
+
+// transposed = 0: the forward operand of conv2d weights w[K][C][R][S] (rows = K, reduced = C).
+// transposed = 1: the data-gradient operand (rows = C, reduced = K, taps mirrored).
+int srgan_h_pack_conv_weights(const float* w, void* packed, int32_t K, int32_t C, int32_t R, int32_t S, int transposed, int dtype,
+                              hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(w && packed && K > 0 && C > 0 && R > 0 && S > 0, SRGAN_EINVAL, "srgan_h_pack_conv_weights arguments");
+  const int rows = transposed ? C : K, reduced = transposed ? K : C;
+  const int64_t slots = srgan_h_conv_weight_slots(rows, reduced, R, S);
+  const int so = transposed ? R * S : C * R * S, si = transposed ? C * R * S : R * S;
+  const int base = transposed ? R * S - 1 : 0, skh = transposed ? -S : S, skw = transposed ? -1 : 1;
+  const dim3 grid((unsigned)((slots + 255) / 256));
+  if (dtype == 1) hipLaunchKernelGGL(h_pack_conv_weights_kernel<1>, grid, dim3(256), 0, stream, w, (Slot*)packed, slots, rows, reduced, R, S, base, so, si, skh, skw);
+  else hipLaunchKernelGGL(h_pack_conv_weights_kernel<2>, grid, dim3(256), 0, stream, w, (Slot*)packed, slots, rows, reduced, R, S, base, so, si, skh, skw);
+  return launch_status();
+}
+
+// out[N, C_out, H, W] = epi(conv3x3 / stride 1 / pad 1 of x[N, C_in, H, W] with packed weights of `rows` rows [+ bias]).
+// epi 0: plain; 1: + bias (may be NULL), then leaky_relu(slope) (slope 0 = relu, 1 = identity); 2: times mask(ref, slope), ref
+// of the output's shape.  C_out = the channels the output tensor stores (rows of the packed weights may be fewer or more).
+int srgan_h_conv3x3(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi, void* out,
+                    int32_t N, int32_t C_in, int32_t C_out, int32_t rows, int32_t H, int32_t W, int dtype, hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(x && packed && out && N > 0 && C_in > 0 && C_out > 0 && rows > 0 && H > 0 && W > 0 && epi >= 0 && epi <= 2 &&
+                (epi != 2 || ref), SRGAN_EINVAL, "srgan_h_conv3x3 arguments");
+  HConv3Params p;
+  p.in = (const Slot*)x; p.wp = (const Slot*)packed; p.out = (Slot*)out; p.bias = bias; p.ref = (const Slot*)ref;
+  p.slope = slope; p.epi = epi;
+  p.N = N; p.CGI = (C_in + 7) / 8; p.CGO = (C_out + 7) / 8; p.CO = rows; p.C_real = C_out; p.H = H; p.W = W;
+  p.chunks = (p.CGI + 1) / 2;
+  SRGAN_REQUIRE((int64_t)N * (p.CGI > p.CGO ? p.CGI : p.CGO) * H * W < ((int64_t)1 << 31), SRGAN_ERANGE, "srgan_h_conv3x3 tensor size");
+  HConv3Plan plan;
+  const int rows_needed = p.CGO * 8 < rows ? p.CGO * 8 : rows;       // output rows that are stored
+  SRGAN_REQUIRE(hconv3_plan(N, p.CGI, rows_needed, H, W, plan), SRGAN_EUNSUPPORTED, "srgan_h_conv3x3 plane size");
+  p.tiles_x = plan.tiles_x; p.tiles_y = plan.tiles_y; p.tiles_m = plan.tiles_m;
+  p.chunks_per_split = plan.chunks_per;
+  p.split_ws = nullptr; p.split_tickets = nullptr;
+  int split = plan.split;
+  if (split > 1) {
+    int ticket_set = -1;
+    const int64_t accumulators = (int64_t)(plan.bm / 32) * plan.ni * 16 * 256;
+    float* ws = split_workspace(plan.blocks, split, accumulators, 0, stream, &ticket_set);
+    unsigned int* tickets = ws ? device_tickets(g_hconv3_split_tickets) : nullptr;
+    if (ws && tickets) {
+      p.split_ws = ws;
+      p.split_tickets = tickets + (size_t)ticket_set * SPLIT_TICKET_TILES;
+    } else {
+      split = 1;
+      p.chunks_per_split = p.chunks;
+    }
+  }
+  p.xcd_remap = (plan.blocks % 8 == 0 && plan.blocks >= 64) ? 1 : 0;
+  const dim3 grid((unsigned)plan.blocks, (unsigned)split, 1);
+  const int slot = profile_bracket_begin(stream);
+  if (dtype == 1) hconv3_launch<1>(p, plan, grid, stream);
+  else hconv3_launch<2>(p, plan, grid, stream);
+  const int status = launch_status();
+  const double pixels = (double)N * H * W;
+  profile_bracket_end_bytes(slot, stream, rows_needed, (int64_t)pixels, (int64_t)p.CGI * 8 * 9, 14, plan.bm, plan.ni * 128, split,
+                            2.0 * (pixels * p.CGI * 8 + pixels * p.CGO * 8 * (epi == 2 ? 2 : 1) + (double)rows * p.CGI * 8 * 9), dtype);
+  return status;
+}
+
+// gw[C_out][C_in][3][3] (fp32) += the weight gradient of a 3x3 / s1 / p1 convolution from x[N, C_in, H, W] and gy[N, C_out, H, W]
+int srgan_h_conv3x3_wgrad(const void* x, const void* gy, float* gw, int32_t N, int32_t C_in, int32_t C_out, int32_t H, int32_t W,
+                          int dtype, hipStream_t stream) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(x && gy && gw && N > 0 && C_in > 0 && C_out > 0 && H > 0 && W > 0, SRGAN_EINVAL, "srgan_h_conv3x3_wgrad arguments");
+  HWgrad3Params p;
+  p.x = (const Slot*)x; p.gy = (const Slot*)gy;
+  p.N = N; p.CGX = (C_in + 7) / 8; p.CGY = (C_out + 7) / 8; p.H = H; p.W = W;
+  int tw, rows;
+  if (W > 16) { tw = 32; rows = 2; }
+  else if (W == 8 && H == 8) { tw = 8; rows = 8; }
+  else if (W == 4 && H == 4) { tw = 4; rows = 4; }
+  else { tw = 16; rows = 4; }
+  const int img = HWGRAD_P / (rows * tw);
+  p.tiles_x = (W + tw - 1) / tw;
+  p.tiles_y = img > 1 ? 1 : (H + rows - 1) / rows;
+  p.tiles_n = (N + img - 1) / img;
+  p.pixel_tiles = p.tiles_x * p.tiles_y * p.tiles_n;
+  p.tiles_ci = (C_in + 63) / 64;
+  const int tiles_co = (C_out + 63) / 64;
+  const int blocks = p.tiles_ci * tiles_co;
+  int walkers = (1024 + blocks - 1) / blocks;
+  if (walkers > p.pixel_tiles) walkers = p.pixel_tiles;
+  if (walkers < 1) walkers = 1;
+  const size_t floats_per_walker = (size_t)blocks * 9 * 16 * 256;
+  while (walkers > 1 && floats_per_walker * walkers * sizeof(float) > ((size_t)192 << 20)) walkers = (walkers + 1) / 2;
+  p.walkers = walkers;
+  p.partial = partial_workspace((size_t)blocks * walkers * 9 * 16 * 256 * sizeof(float), stream);
+  SRGAN_REQUIRE(p.partial, SRGAN_EINVAL, "srgan_h_conv3x3_wgrad: register a workspace for this stream first (srgan_set_workspace)");
+  const dim3 grid((unsigned)blocks, (unsigned)walkers);
+  const int slot = profile_bracket_begin(stream);
+#define HWGRAD_LAUNCH(TWv, ROWSv)                                                                                       \
+  do {                                                                                                                  \
+    if (dtype == 1) hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 1>), grid, dim3(256), 0, stream, p);             \
+    else hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 2>), grid, dim3(256), 0, stream, p);                        \
+  } while (0)
+  if (tw == 32) HWGRAD_LAUNCH(32, 2);
+  else if (tw == 16) HWGRAD_LAUNCH(16, 4);
+  else if (tw == 8) HWGRAD_LAUNCH(8, 8);
+  else HWGRAD_LAUNCH(4, 4);
+#undef HWGRAD_LAUNCH
+  const int64_t elements = (int64_t)C_out * C_in * 9;
+  hipLaunchKernelGGL(hwgrad3x3_finish_kernel, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0, stream, p.partial, gw,
+                     C_out, C_in, p.tiles_ci, walkers);
+  const int status = launch_status();
+  const double pixels = (double)N * H * W;
+  profile_bracket_end_bytes(slot, stream, C_out, (int64_t)C_in * 9, (int64_t)pixels, 15, 64, 64, walkers,
+                            2.0 * pixels * (p.CGX + p.CGY) * 8 + 8.0 * (double)elements, dtype);
+  return status;
+}
+
+}  // extern "C"

@@ -818,6 +818,27 @@ int profile_bracket_end(int slot, hipStream_t stream, int64_t M, int64_t N, int6
   return SRGAN_OK;
 }
 
+// The same bracket end for a launch that states its own algorithmic bytes (the 16-bit kernels of blocked16*.hip: kinds 14
+// hconv3x3, 15 hwgrad3x3, 16 hgemm, 17 hlinear_wgrad, 18 hconv4x4s2, 19 hwgrad4x4s2).
+int profile_bracket_end_bytes(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split,
+                              double bytes, int precision) {
+  if (slot < 0) return SRGAN_OK;
+  hipEvent_t stop;
+  {
+    std::lock_guard<std::mutex> lock(g_profile.mutex);
+    if ((size_t)slot >= g_profile.slots) return SRGAN_OK;
+    stop = g_profile.events[2 * slot + 1];
+    const double f = 2.0 * (double)M * (double)N * (double)K;
+    g_profile.records[slot] = ProfileRecord{(int32_t)M, (int32_t)N, (int32_t)K, kind, bm, bn, split, 0, 0, bytes, precision};
+    g_profile.flops += f;
+    g_profile.mfma_flops += f;
+    g_profile.bytes += bytes;
+    g_profile.launches += 1;
+  }
+  SRGAN_HIP(hipEventRecord(stop, stream));
+  return SRGAN_OK;
+}
+
 bool conv3x3_enabled();
 int conv3x3_run(const float* in, int64_t in_bs, const float* w, int32_t w_base, int32_t w_so, int32_t w_si, int32_t w_skh,
                 int32_t w_skw, const float* bias, float* out, int64_t out_bs, int32_t N, int32_t CI, int32_t CO, int32_t H,
@@ -1447,12 +1468,13 @@ int srgan_capabilities(srgan_capabilities_t* out, int32_t out_bytes) {
   SRGAN_REQUIRE(out != nullptr && out_bytes >= (int32_t)sizeof(srgan_capabilities_t), SRGAN_EINVAL,
                 "srgan_capabilities: output struct");
   memset(out, 0, sizeof(*out));
-  out->abi_version = 100;
+  out->abi_version = 110;
   out->struct_bytes = (int32_t)sizeof(*out);
   snprintf(out->arch, sizeof(out->arch), "gfx950");
   out->dtypes = 0x1u /* fp32 */ | 0x2u /* bf16 MFMA operands */ | 0x4u /* fp16 MFMA operands */;
   out->features = 0x1u /* fused batch-norm + relu prologues / epilogues */ | 0x2u /* split-K through a workspace */ |
-                  0x4u /* live event profile of the contraction launches */;
+                  0x4u /* live event profile of the contraction launches */ |
+                  0x8u /* 16-bit blocked data path (srgan_h_*) */;
   out->workspace_bytes = (int64_t)WORKSPACE_BYTES;
   out->max_tensor_elements = ((int64_t)1 << 31) - 1;
   return SRGAN_OK;

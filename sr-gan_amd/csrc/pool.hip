@@ -571,6 +571,6 @@ int srgan_avgpool2d_bwd(const float* g, float* gx, int32_t planes, int32_t H, in
   return launch_status();
 }
 
-int srgan_version(void) { return 100; }
+int srgan_version(void) { return 110; }
 
 }  // extern "C"

@@ -26,6 +26,28 @@ COMPUTE_DTYPES = {'f32': 0, 'fp32': 0, 'bf16': 1, 'f16': 2, 'fp16': 2}
 COMPUTE_DTYPE = 0
 
 
+# Storage type of the activations / gradients of the networks that have a 16-bit data path (``blocked16``): 0 = fp32
+# tensors (the operands are rounded per fragment when COMPUTE_DTYPE asks for it), 1 / 2 = bf16 / fp16 tensors in the
+# blocked layout with fused activations.  Read when a network's forward runs.
+STORAGE_DTYPE = 0
+
+
+class storage_dtype:
+    """``with F.storage_dtype('bf16'): ...`` -- networks with a 16-bit data path run it inside."""
+
+    def __init__(self, name):
+        self.code = (COMPUTE_DTYPES[name] if isinstance(name, str) else int(name)) if name else 0
+
+    def __enter__(self):
+        global STORAGE_DTYPE
+        self.previous, STORAGE_DTYPE = STORAGE_DTYPE, self.code
+        return self
+
+    def __exit__(self, *exc):
+        global STORAGE_DTYPE
+        STORAGE_DTYPE = self.previous
+
+
 class compute_dtype:
     """``with F.compute_dtype('bf16'): ...`` -- contractions launched inside use bf16 (or 'f16') MFMA operands with fp32
     accumulation; 'f32' restores the exact path (e.g. around the gradient-penalty chain of an fp16 step)."""
@@ -141,6 +163,9 @@ def _unary(op, x, backward, name, p0=0.0, p1=0.0):
 
 
 def add(a, b):
+    if a.meta is not None or b.meta is not None:          # 16-bit blocked tensors (gradients summed by the tape's sweep)
+        from . import blocked16
+        return blocked16.add(a, b)
     return _out(_binary_raw(B_ADD, a.data, b.data), (a, b), lambda g, needs: (g, g), 'add')
 
 

@@ -119,6 +119,8 @@ class ParameterArena:
         self.data = torch.zeros(total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.parameters = parameters
+        self.version = 0          # bumped by every optimizer update (raw-pointer writes torch's version counters do not see)
+        self.shadows = []         # blocked16.Shadow objects: 16-bit operand forms of these weights, refreshed behind an update
         with torch.no_grad():
             for p, offset, size in zip(parameters, self.offsets, self.sizes):
                 view = self.data[offset:offset + size].view(p.shape)
@@ -126,6 +128,7 @@ class ParameterArena:
                 p.data = view
                 p.grad = self.grad[offset:offset + size].view(p.shape)
                 p._srgan_var = None
+                p._srgan_arena = self
         for buffer_owner in module.modules():      # move buffers (batch-norm statistics) as well
             for name, buffer in list(buffer_owner._buffers.items()):
                 if buffer is not None:

@@ -577,7 +577,12 @@ class Experiment(ABC):
         name = getattr(self.settings, 'compute_dtype', 'f32')
         if phase == 'penalty':
             name = getattr(self.settings, 'gradient_penalty_dtype', 'f32')
-        return F.compute_dtype(name)
+        # settings.storage_dtype ('bf16' / 'f16' / None): the networks with a 16-bit data path (blocked16) keep activations
+        # and gradients in that type while the phase computes in it; a phase in another type (an fp32 penalty chain) does not
+        storage = getattr(self.settings, 'storage_dtype', None)
+        if storage and F.COMPUTE_DTYPES[storage] == F.COMPUTE_DTYPES[name]:
+            return _Contexts(F.compute_dtype(name), F.storage_dtype(storage))
+        return _Contexts(F.compute_dtype(name), F.storage_dtype(None))
 
     def scaled_backward(self, root, **arguments):
         """``backward(root)`` with the root gradient set to ``settings.loss_scale`` (static loss scaling for the fp16 mode:
@@ -995,6 +1000,22 @@ class Experiment(ABC):
 
     def inference(self, input_):
         raise NotImplementedError
+
+
+class _Contexts:
+    """Several context managers entered / left together."""
+
+    def __init__(self, *managers):
+        self.managers = managers
+
+    def __enter__(self):
+        for manager in self.managers:
+            manager.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        for manager in reversed(self.managers):
+            manager.__exit__(*exc)
 
 
 def disable_batch_norm_updates(module):

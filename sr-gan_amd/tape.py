@@ -51,11 +51,11 @@ class Node:
 
 
 class Var:
-    """A device tensor (contiguous fp32) with an optional producer node.
+    """A device tensor (contiguous fp32; or 16-bit in the blocked layout, see ``blocked16``) with an optional producer node.
 
     Leaves created from parameters carry ``grad_buffer``: a view of the network's flat gradient arena into
     which ``backward`` accumulates."""
-    __slots__ = ('data', 'node', 'requires_grad', 'grad_buffer', 'grad', '__weakref__')
+    __slots__ = ('data', 'node', 'requires_grad', 'grad_buffer', 'grad', 'meta', '__weakref__')
 
     def __init__(self, data, requires_grad=False, node=None):
         self.data = data
@@ -63,6 +63,7 @@ class Var:
         self.node = node
         self.grad_buffer = None
         self.grad = None
+        self.meta = None          # blocked16.Blocked for a 16-bit tensor in the blocked layout (None: plain fp32)
 
     @property
     def shape(self):

@@ -40,7 +40,7 @@ def test_every_declared_entry_point_is_exported_and_bound(lib):
 def test_capabilities_and_build_identity(lib):
     from srgan_amd import _build
     caps = lib.capabilities()
-    assert caps.abi_version == lib.library().srgan_version() == 100
+    assert caps.abi_version == lib.library().srgan_version() == 110
     assert caps.struct_bytes == ctypes.sizeof(lib.Capabilities) and caps.arch == b'gfx950'
     assert caps.dtypes == 0x7 and caps.features & 0x7 == 0x7
     assert caps.workspace_bytes == lib.library().srgan_workspace_bytes() == 256 << 20      # (round 5: the partial tiles of every K split)

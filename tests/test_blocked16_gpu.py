@@ -1,0 +1,269 @@
+"""The 16-bit data path (``blocked16``: bf16 / fp16 tensors in the blocked layout, fused activations) on the GPU.
+
+Every kernel of ``csrc/blocked16*.hip`` is held against the fp32 kernels of the parity path (which the other GPU test files
+pin against the reference-generated goldens) on operands that bf16 / fp16 represent EXACTLY (small integers): the fp32
+result, rounded once to the 16-bit type, must then be reproduced bit for bit -- this pins the blocked layout, the packed
+weight shadows, the transpose-read fragments of the weight gradients, the epilogues (bias + activation, mask by reference) and
+the tie rule of the pool independently of rounding.  Then whole VGG passes (first and second order) against the fp32-storage
+path with the rounding-sized tolerances stated in the tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODES = ['bf16', 'f16']
+TORCH = {'bf16': torch.bfloat16, 'f16': torch.float16}
+
+
+@pytest.fixture(scope='module')
+def F():
+    import srgan_amd  # noqa: F401
+    from srgan_amd import functional
+    assert torch.cuda.is_available()
+    return functional
+
+
+@pytest.fixture(scope='module')
+def B():
+    import srgan_amd  # noqa: F401
+    from srgan_amd import blocked16
+    return blocked16
+
+
+def integers(shape, low, high, seed):
+    generator = torch.Generator().manual_seed(seed)
+    return torch.randint(low, high + 1, shape, generator=generator).float().cuda()
+
+
+def rounded(t, mode):
+    return t.to(TORCH[mode]).float()
+
+
+def blocked(F, B, t, mode):
+    return B.pack(F.leaf(t), B.CODES[mode])
+
+
+def nchw(B, var):
+    meta = var.meta
+    return B.unpack(var, (meta.n, meta.c, meta.h, meta.w)).data
+
+
+# planes: 64-wide and ragged 40-wide (32-column tiles), 16 x 16, 8 x 8, 4 x 4 (whole images side by side), 14 x 14 and 7 x 7
+# (guards of the 16-wide tile); channel tails on both sides; few / many images
+CONVS = [(2, 64, 64, 64, 64), (3, 24, 12, 40, 40), (2, 3, 64, 64, 64), (5, 128, 16, 16, 72), (19, 40, 4, 4, 72), (9, 32, 8, 8, 200),
+         (32, 256, 4, 4, 128), (3, 48, 14, 14, 16), (2, 16, 7, 7, 8), (4, 64, 32, 32, 128), (130, 16, 8, 8, 64), (2, 64, 20, 16, 3)]
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('case', CONVS)
+def test_conv3x3_forward_data_gradient_and_weight_gradient_are_exact_on_integers(F, B, mode, case):
+    n, c, h, w, k = case
+    layer = torch.nn.Conv2d(c, k, 3, padding=1).cuda()
+    with torch.no_grad():
+        layer.weight.copy_(integers((k, c, 3, 3), -1, 1, 1))
+        layer.bias.copy_(integers((k,), -3, 3, 2))
+    x = integers((n, c, h, w), -2, 2, 3)
+    from srgan_amd.tape import no_grad
+    with no_grad():
+        xb = blocked(F, B, x, mode)
+        # forward: relu(conv + bias), fp32 result rounded once
+        got = nchw(B, B.conv3x3(xb, layer, slope=0.0))
+        want = F.relu(F.conv2d(F.leaf(x), F.leaf(layer.weight.data), F.leaf(layer.bias.data), 1, 1)).data
+        assert torch.equal(got, rounded(want, mode))
+        # leaky and plain epilogues
+        got = nchw(B, B.conv3x3(xb, layer, slope=0.25))
+        plain = F.conv2d(F.leaf(x), F.leaf(layer.weight.data), F.leaf(layer.bias.data), 1, 1).data
+        assert torch.equal(got, rounded(torch.where(plain > 0, plain, plain * 0.25), mode))
+        assert torch.equal(nchw(B, B.conv3x3(xb, layer)), rounded(plain, mode))
+        # data gradient with the mask epilogue: convT(s) * (ref > 0 ? 1 : slope), ref = an activated tensor of x's shape
+        s = integers((n, k, h, w), -2, 2, 4)
+        ref = integers((n, c, h, w), -1, 1, 5)
+        sb, refb = blocked(F, B, s, mode), blocked(F, B, ref, mode)
+        shadow = B.shadow_of(layer, 'conv3x3', B.CODES[mode])
+        got = nchw(B, B._layer(sb, layer, shadow, True, 2, 0.5, refb.data, False))
+        plain = F.conv2d_backward_data(F.leaf(s), F.leaf(layer.weight.data), (n, c, h, w), (1, 1), (1, 1)).data
+        assert torch.equal(got, rounded(plain * torch.where(ref > 0, 1.0, 0.5), mode))
+        assert torch.equal(nchw(B, B._layer(sb, layer, shadow, True, 0, 1.0, None, False)), rounded(plain, mode))
+        # weight gradient (fp32, accumulated into): exact integers
+        into = torch.full((k, c, 3, 3), 7.0, device='cuda')
+        B._weight_gradient(shadow, layer, xb, sb, into)
+        want = F.conv2d_backward_weight(F.leaf(x), F.leaf(s), (k, c, 3, 3), (1, 1), (1, 1)).data + 7.0
+        assert torch.equal(into, want)
+        # bias gradient
+        sums = torch.full((k,), 1.0, device='cuda')
+        from srgan_amd import _lib
+        _lib.check(_lib.library().srgan_h_channel_sums(sb.data.data_ptr(), sums.data_ptr(), n, k, h * w, B.CODES[mode], F._stream()),
+                   'srgan_h_channel_sums')
+        assert torch.equal(sums, s.sum(dim=(0, 2, 3)) + 1.0)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_pack_unpack_add_and_masks(F, B, mode):
+    x = integers((3, 13, 6, 10), -200, 200, 1) / 8.0
+    ref = integers((3, 13, 6, 10), -1, 1, 2)
+    from srgan_amd.tape import no_grad
+    with no_grad():
+        xb, refb = blocked(F, B, x, mode), blocked(F, B, ref, mode)
+        assert xb.data.shape == (3, 2, 6, 10, 8) and xb.data.dtype == TORCH[mode]
+        assert torch.equal(nchw(B, xb), x)
+        assert torch.all(xb.data[:, 1, :, :, 5:] == 0)                     # channels 13..15 of the last group are zeros
+        masked = B.pack(F.leaf(x), B.CODES[mode], refb.data, 0.125)
+        assert torch.equal(nchw(B, masked), x * torch.where(ref > 0, 1.0, 0.125))
+        assert torch.equal(nchw(B, B.add(xb, refb)), rounded(x + ref, mode))
+        matrix = integers((5, 20), -9, 9, 3)
+        mb = blocked(F, B, matrix, mode)
+        assert mb.data.shape == (5, 3, 1, 1, 8) and torch.equal(B.unpack(mb).data, matrix)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('shape', [(3, 24, 8, 12), (2, 5, 2, 2), (4, 64, 16, 16)])
+def test_max_pool_forward_backward_and_gather_follow_torchs_first_maximum(F, B, mode, shape):
+    n, c, h, w = shape
+    x = torch.relu(integers(shape, -2, 2, 1))              # many ties (zeros and equal positives), as behind a ReLU in bf16
+    g = integers((n, c, h // 2, w // 2), -3, 3, 2)
+    tangent = integers(shape, -3, 3, 3)
+    reference = torch.nn.functional.max_pool2d(x.cpu().requires_grad_(True), 2, 2, return_indices=True)
+    pooled_cpu, indices = reference
+    from srgan_amd.tape import no_grad
+    with no_grad():
+        xb = blocked(F, B, x, mode)
+        xb.meta.mask_ref, xb.meta.slope = xb.data, 0.0           # an activated (ReLU) tensor
+        pooled = B.max_pool2(xb)
+        assert torch.equal(nchw(B, pooled), pooled_cpu.detach().cuda())
+        gb = blocked(F, B, g, mode)
+        gx = nchw(B, B._pool_backward(xb.data, xb.meta, gb))
+        want = torch.zeros(n, c, h * w)
+        want.scatter_(2, indices.view(n, c, -1), g.cpu().view(n, c, -1))
+        want = want.view(shape).cuda() * (x > 0)                 # ... times the ReLU's derivative
+        assert torch.equal(gx, want)
+        gathered = nchw(B, B._pool_gather(xb.data, xb.meta, blocked(F, B, tangent, mode)))
+        want = tangent.cpu().view(n, c, -1).gather(2, indices.view(n, c, -1)).view(n, c, h // 2, w // 2).cuda()
+        assert torch.equal(gathered, want)
+
+
+LINEARS = [(7, 40, 2, 2, 24), (130, 64, 1, 1, 200), (33, 16, 4, 12, 1), (384, 512, 2, 2, 4096 // 16)]
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('case', LINEARS)
+def test_linear_layers_behind_a_flattened_plane_are_exact_on_integers(F, B, mode, case):
+    n, c, h, w, outputs = case
+    inputs = c * h * w
+    layer = torch.nn.Linear(inputs, outputs).cuda()
+    with torch.no_grad():
+        layer.weight.copy_(integers((outputs, inputs), -1, 1, 1))
+        layer.bias.copy_(integers((outputs,), -3, 3, 2))
+    x = integers((n, c, h, w), -1, 1, 3)
+    s = integers((n, outputs), -2, 2, 4)
+    from srgan_amd.tape import no_grad
+    with no_grad():
+        flat = B.flatten(blocked(F, B, x, mode))
+        want = torch.nn.functional.linear(x.view(n, -1), layer.weight.data, layer.bias.data)
+        assert torch.equal(B.unpack(B.linear(flat, layer, slope=0.0)).data, rounded(torch.relu(want), mode))
+        assert torch.equal(B.unpack(B.linear(flat, layer)).data, rounded(want, mode))
+        # data gradient (blocked order, viewed back to the plane) and weight gradient (in the layer's own layout)
+        sb = blocked(F, B, s, mode)
+        shadow = B.shadow_of(layer, 'linear', B.CODES[mode], in_blocked=flat.meta.c, plane=flat.meta.plane)
+        gx = B._layer(sb, layer, shadow, True, 0, 1.0, None, False)
+        back = gx.data.view(n, (c + 7) // 8, h, w, 8)
+        unblocked = back.permute(0, 1, 4, 2, 3).reshape(n, -1, h, w)[:, :c].float()
+        assert torch.equal(unblocked, rounded((s @ layer.weight.data).view(n, c, h, w), mode))
+        into = torch.full_like(layer.weight.data, 3.0)
+        B._weight_gradient(shadow, layer, flat, sb, into)
+        assert torch.equal(into, s.t() @ x.view(n, -1) + 3.0)
+
+
+def _vgg(size, scale):
+    import srgan_amd  # noqa: F401
+    from srgan_amd.age import vgg
+    from srgan_amd import nn
+    torch.manual_seed(3)
+    model = vgg.vgg16(num_classes=1, image_size=size)
+    with torch.no_grad():
+        for module in model.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.Linear)):
+                module.weight.mul_(scale)
+                if module.bias is not None:
+                    module.bias.normal_(0, 0.05)
+    nn.flatten_parameters(model, torch.device('cuda'))
+    return model
+
+
+def _penalty_step(F, model, x, storage):
+    """Feature loss + gradient penalty of the interpolates through one VGG: first-order and double backward (reference
+    srgan.py:360-375) -> (loss, penalty, gradient norms, the arena's gradient)."""
+    from srgan_amd.tape import backward
+    arena = model._srgan_arena
+    arena.zero_grad()
+    with F.compute_dtype('bf16'), F.storage_dtype('bf16' if storage else None):
+        scores = model(F.leaf(x))
+        loss = F.add(F.mean_all(F.square(scores)), F.mean_all(F.abs_(model.features)))
+        backward(loss)
+        interpolates = F.leaf(x * 0.5, requires_grad=True)
+        model(interpolates)
+        norms = F.row_norm(F.flatten2d(model.features))
+        gradients, = backward(norms, grad=F.full_like(norms, 1.0), inputs=[interpolates], create_graph=True)
+        gradient_norm = F.row_norm(F.flatten2d(gradients))
+        penalty = F.mean_all(F.square(F.relu(F.add_scalar(gradient_norm, -1.0))))
+        backward(penalty)
+    torch.cuda.synchronize()
+    return loss.item(), penalty.item(), gradient_norm.data.clone(), arena.grad.clone()
+
+
+@pytest.mark.parametrize('size', [32, 64])
+def test_vgg_first_and_second_order_match_the_fp32_storage_path(F, size):
+    """The whole 16-bit graph (13 fused convolutions, 5 pools, 3 linear layers; the recorded backward w.r.t. the images and
+    its double backward) against the same bf16-operand arithmetic on fp32 tensors: the two differ by the rounding of the
+    STORED activations / gradients only (2^-9 relative each), stated bounds below."""
+    model = _vgg(size, 1.6)
+    generator = torch.Generator().manual_seed(5)
+    x = (torch.rand(6, 3, size, size, generator=generator) * 2 - 1).cuda()
+    loss_a, penalty_a, norms_a, grad_a = _penalty_step(F, model, x, storage=False)
+    loss_b, penalty_b, norms_b, grad_b = _penalty_step(F, model, x, storage=True)
+    assert penalty_a > 1e-3, 'the penalty must be active for the double backward to be tested'
+    assert abs(loss_a - loss_b) <= 2e-2 * abs(loss_a)
+    assert torch.allclose(norms_a, norms_b, rtol=3e-2)
+    assert abs(penalty_a - penalty_b) <= 6e-2 * abs(penalty_a)
+    scale = grad_a.abs().max().item()
+    assert scale > 0 and (grad_a - grad_b).abs().max().item() <= 4e-2 * scale
+    # per layer: the cosine between the two gradients of every weight tensor
+    arena = model._srgan_arena
+    for parameter, offset, count in zip(arena.parameters, arena.offsets, arena.sizes):
+        a, b = grad_a[offset:offset + count], grad_b[offset:offset + count]
+        if a.norm() > 0:
+            cosine = torch.dot(a, b) / (a.norm() * b.norm())
+            assert cosine > 0.98, (tuple(parameter.shape), cosine.item())
+
+
+def test_the_16_bit_path_is_bit_reproducible(F):
+    model = _vgg(32, 1.6)
+    generator = torch.Generator().manual_seed(6)
+    x = (torch.rand(5, 3, 32, 32, generator=generator) * 2 - 1).cuda()
+    first = _penalty_step(F, model, x, storage=True)
+    second = _penalty_step(F, model, x, storage=True)
+    assert first[0] == second[0] and first[1] == second[1]
+    assert torch.equal(first[2], second[2]) and torch.equal(first[3], second[3])
+
+
+def test_shadows_follow_the_optimizer(F, B):
+    from srgan_amd import optim
+    model = _vgg(32, 1.0)
+    arena = model._srgan_arena
+    optimizer = optim.Adam(arena, lr=1e-2)
+    x = (torch.rand(4, 3, 32, 32) * 2 - 1).cuda()
+    from srgan_amd.tape import backward, no_grad
+    with F.compute_dtype('bf16'), F.storage_dtype('bf16'):
+        before = model(F.leaf(x))
+        arena.zero_grad()
+        backward(F.mean_all(F.square(before)))
+        optimizer.step()                                         # raw-pointer update: the shadows are re-rounded behind it
+        with no_grad():
+            after = model(F.leaf(x))
+    with F.compute_dtype('bf16'), no_grad():
+        want = model(F.leaf(x))                                  # fp32 tensors, bf16 operands: reads the masters
+    assert not torch.equal(before.data, after.data)
+    assert torch.allclose(after.data, want.data, rtol=3e-2, atol=3e-2 * want.data.abs().max().item())

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f'{name} is declared in srgan_hip.h but not exported'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.library().srgan_version() == 100
+    assert _lib.library().srgan_version() == 110
 
 
 def test_product_fails_loudly_without_gpu_tensors():
