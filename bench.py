@@ -54,10 +54,12 @@ LOW_PRECISION_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 (MI355X_MICROARCH.m
 WORKLOADS = {
     'crowd': None,
     'age-vgg-bf16': dict(application='age', architecture='vgg', image_size=64, batch_per_gpu=128, gp_scale=1.3, dtype='bf16',
-                         settings=dict(compute_dtype='bf16', gradient_penalty_dtype='bf16', matching_loss_multiplier=1e2,
-                                       contrasting_loss_multiplier=1e1, gradient_penalty_multiplier=1e2),
-                         name='age SRGAN, VGG-16 D/DNN + DCGAN G on 64x64 faces (BASELINE.json configs[1]), bf16 MFMA operands (gradient-penalty '
-                              'chain included)'),
+                         settings=dict(compute_dtype='bf16', gradient_penalty_dtype='bf16', storage_dtype='bf16',
+                                       matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
+                                       gradient_penalty_multiplier=1e2),
+                         name='age SRGAN, VGG-16 D/DNN + DCGAN G on 64x64 faces (BASELINE.json configs[1]), bf16: activations, gradients '
+                              'and weight shadows of D / DNN stored as bf16 in the blocked layout with fused activations (gradient-penalty '
+                              'chain included), fp32 master weights / Adam / losses; the DCGAN generator on fp32 tensors with bf16 MFMA operands'),
     'driving-fp16': dict(application='driving', image_size=(64, 192), batch_per_gpu=128, gp_scale=3.0, dtype='f16',
                          settings=dict(compute_dtype='f16', gradient_penalty_dtype='f32', loss_scale=256.0,
                                        matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
@@ -118,6 +120,10 @@ def parse():
     parser.add_argument('--exchange-form', default=None, choices=['all_reduce', 'reduce_scatter'],
                         help='data parallel: all-reduce (default) or reduce-scatter + all-gather buckets')
     parser.add_argument('--master-port', type=int, default=None, help='self-launch only: rendezvous port on 127.0.0.1')
+    parser.add_argument('--no-secondary', action='store_true',
+                        help='crowd headline on one GPU: do not append the two mixed-precision configurations (age-vgg-bf16, '
+                             'driving-fp16) as `secondary` entries (each is this script run as a child process)')
+    parser.add_argument('--secondary-steps', type=int, default=30, help='timed steps of each secondary configuration')
     return parser.parse_args()
 
 
@@ -149,6 +155,8 @@ def build_experiment(args, dp):
     if workload is not None:
         for key, value in workload['settings'].items():
             setattr(settings, key, value)
+        if os.environ.get('SRGAN_NO_STORAGE16'):            # A / B: fp32 tensors, operands rounded per fragment (rounds 2-5)
+            settings.storage_dtype = None
     if args.grad_wire:
         settings.gradient_wire_dtype = args.grad_wire
     if args.exchange_form:
@@ -200,6 +208,14 @@ def gp_scale(args):
     return workload['gp_scale'] if workload is not None else GP_SCALE.get(args.image_size, 1.27)
 
 
+def restore_weights(arena, saved):
+    """arena.data <- saved, and the 16-bit shadows of those weights (blocked16) behind it on the same stream."""
+    arena.data.copy_(saved)
+    if arena.shadows:
+        from srgan_amd import blocked16
+        blocked16.refresh(arena)
+
+
 def one_step(experiment, labeled, unlabeled, step, eager=False):
     batch = next(labeled)
     x, labels = (batch[0], (batch[1], batch[2])) if len(batch) == 3 else batch
@@ -243,12 +259,13 @@ def schedule_check(experiment, labeled, unlabeled, step):
 
     def run(timed_schedule):
         for (m, o), (data, exp_avg, exp_avg_sq, count) in zip(zip(modules, optimizers), saved):
-            m._srgan_arena.data.copy_(data)
+            restore_weights(m._srgan_arena, data)
             o.exp_avg.copy_(exp_avg)
             o.exp_avg_sq.copy_(exp_avg_sq)
             o.step_count = count
             if o.device_state is not None:
                 o.device_state[0] = count
+        torch.cuda.synchronize()
         experiment.injected_draws = {k: v.clone() for k, v in draws.items()}
         one_step(experiment, itertools.repeat(batch), itertools.repeat(unlabeled_batch), step, eager=not timed_schedule)
         experiment.join_dnn_stream()
@@ -278,7 +295,7 @@ def schedule_check(experiment, labeled, unlabeled, step):
     timed_floor = difference(timed_again, timed_losses)
     weight_difference = max(float((a - b).abs().max()) for a, b in zip(timed_weights, single_weights))
     for (m, o), (data, exp_avg, exp_avg_sq, count) in zip(zip(modules, optimizers), saved):     # back to the timed state
-        m._srgan_arena.data.copy_(data)
+        restore_weights(m._srgan_arena, data)
         o.exp_avg.copy_(exp_avg)
         o.exp_avg_sq.copy_(exp_avg_sq)
         o.step_count = count
@@ -426,6 +443,30 @@ def cpu_baseline(image_size, batch=1, timed=3, limit_seconds=600):
     except (subprocess.TimeoutExpired, ValueError, IndexError) as error:
         return {'value': None, 'unit': 'images/s', 'cores': usable_cores(), 'kind': 'port', 'cpu': cpu_model(),
                 'sample': f'not measured: {type(error).__name__} (limit {limit_seconds} s)'}
+
+
+def secondary_line(workload, steps, warmup=5, limit_seconds=600):
+    """One of the other BASELINE.json configurations measured by THIS script in a child process (its own timed region, schedule
+    check and single-stream roofline step), reduced to the figures the headline line carries as `secondary`."""
+    import subprocess
+    command = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--steps', str(steps), '--warmup', str(warmup),
+               '--no-cpu-baseline', '--no-secondary']
+    try:
+        completed = subprocess.run(command, capture_output=True, text=True, timeout=limit_seconds)
+        line = json.loads(completed.stdout.strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, ValueError, IndexError) as error:
+        return {'value': None, 'unit': 'images/s', 'error': f'{type(error).__name__}', 'command': ' '.join(command[1:])}
+    roofline = line.get('roofline') or {}
+    check = line['config'].get('schedule_check')
+    return {'metric': line['metric'], 'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'],
+            'steps': line['steps'], 'warmup': line['warmup'], 'dtype': line['dtype'], 'n_gpus': line['n_gpus'],
+            'workload': line['config']['workload'], 'global_batch': line['config']['global_batch'],
+            'gradient_penalty_last': line['config'].get('gradient_penalty_last'),
+            'schedule_check_within_limit': check.get('within_limit') if isinstance(check, dict) else None,
+            'roofline': {key: roofline.get(key) for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                                            'launches', 'kernel_ms_per_step', 'executed_gflop_per_step',
+                                                            'algorithmic_bytes_per_launch', 'fp32_part')},
+            'command': 'python bench.py ' + ' '.join(command[2:])}
 
 
 def committed_cpu_baseline(image_size, batch, cpu):
@@ -579,7 +620,7 @@ def main():
     # after 13 iterations, 4e4 after 25) and a long --steps would end in non-finite losses.  Every RESTORE_PERIOD steps the
     # three networks' weights go back to their post-warm-up values (device-to-device copies INSIDE the timed region: 0.76 GB
     # per 16 steps at 512 x 512, < 0.02 ms per step); every step still runs its full forward / backward / Adam arithmetic.
-    snapshot = [(module._srgan_arena.data, module._srgan_arena.data.clone())
+    snapshot = [(module._srgan_arena, module._srgan_arena.data.clone())
                 for module in (experiment.D, experiment.DNN, experiment.G)]
     torch.cuda.synchronize()
     start = time.perf_counter()
@@ -588,7 +629,7 @@ def main():
         if step % RESTORE_PERIOD == RESTORE_PERIOD - 1 and step + 1 < args.steps:
             experiment.join_dnn_stream()
             for live, saved in snapshot:
-                live.copy_(saved)
+                restore_weights(live, saved)
     fence()
     elapsed = time.perf_counter() - start
     # What the HOST needs to enqueue one iteration (eager: the Python tape and ~4000 launches; replay: input copies + one graph
@@ -599,7 +640,7 @@ def main():
     host_seconds = time.perf_counter() - enqueue_start
     fence()
     for live, saved in snapshot:
-        live.copy_(saved)
+        restore_weights(live, saved)
     del snapshot
     per_rank_ms = None
     if dp is not None:
@@ -727,8 +768,9 @@ def main():
             roofline = result['roofline']
             roofline.update({
                 'achieved': low, 'peak': LOW_PRECISION_MFMA_PEAK_TFLOPS, 'frac': low / LOW_PRECISION_MFMA_PEAK_TFLOPS,
-                'kernel': 'srgan::gg_mfma_kernel<..., PREC> (v_mfma_f32_32x32x16_bf16 / _f16): every contraction launched in the '
-                          'low-precision mode',
+                'kernel': 'every contraction launched with bf16 / fp16 operands (v_mfma_f32_32x32x16_bf16 / _f16): the 16-bit data '
+                          'path srgan::hconv3x3_kernel / hwgrad3x3_kernel / hgemm_kernel / hlinear_wgrad_kernel (blocked16*.hip) and the '
+                          'fp32-storage kernels gg_mfma_kernel<..., PREC> / conv3x3_mixed_kernel where a network has no 16-bit path',
                 'low_precision_kernel_ms_per_step': low_ms.value, 'low_precision_gflop_per_step': low_flops.value / 1e9,
                 'fp32_part': {'kernel_ms_per_step': rest_ms, 'gflop_per_step': rest_flops / 1e9,
                               'achieved': rest_flops / (rest_ms * 1e-3) / 1e12 if rest_ms > 0 else 0.0,
@@ -740,6 +782,12 @@ def main():
         result['cpu_baseline'] = cpu_baseline(args.image_size, batch=args.cpu_baseline_batch, timed=args.cpu_baseline_timed)
         result['cpu_baseline']['like_for_like'] = committed_cpu_baseline(args.image_size, args.batch_per_gpu,
                                                                          result['cpu_baseline'].get('cpu'))
+    if rank == 0 and world == 1 and dp is None and args.workload == 'crowd' and not args.no_secondary:
+        # the two BASELINE.json configurations that name a precision (configs[1] bf16, configs[4] fp16): same script, child
+        # processes, after this process has finished its own GPU work
+        torch.cuda.synchronize()
+        result['secondary'] = {'age_vgg_bf16': secondary_line('age-vgg-bf16', args.secondary_steps),
+                               'driving_fp16': secondary_line('driving-fp16', args.secondary_steps)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dp is not None:

@@ -8,7 +8,9 @@ import sys
 
 KINDS = {0: 'gg_direct_kernel', 1: 'gg_mfma_kernel', 2: 'conv3x3_lds_kernel', 3: 'pointwise_kernel', 4: 'conv3x3_wgrad_kernel',
          5: 'gg_rows_kernel', 6: 'pointwise_wgrad_kernel', 8: 'pointwise_ksplit_kernel', 9: 'gg_dot_kernel',
-         10: 'stem7x7_fwd_kernel', 11: 'stem7x7_wgrad_kernel', 12: 'stem7x7_bwd_data_kernel', 13: 'pointwise_ring_kernel'}
+         10: 'stem7x7_fwd_kernel', 11: 'stem7x7_wgrad_kernel', 12: 'stem7x7_bwd_data_kernel', 13: 'pointwise_ring_kernel',
+         14: 'hconv3x3_kernel', 15: 'hwgrad3x3_kernel', 16: 'hgemm_kernel', 17: 'hlinear_wgrad_kernel', 18: 'hconv4x4s2_kernel',
+         19: 'hwgrad4x4s2_kernel'}
 PEAK = 157.3
 
 rows = []
@@ -40,4 +42,4 @@ cumulative = 0.0
 for ms, M, N, K, kind, bm, bn, split, akf, bkf, count, flops, nbytes in rows[:top]:
     cumulative += ms
     print(f'{ms:7.2f} {100 * ms / total_ms:5.1f} {100 * cumulative / total_ms:5.1f} {count:6d} {M:6d} {N:8d} {K:7d} '
-          f'{KINDS.get(kind, kind):24s} {bm:4d} {bn:4d} {split:4d} {akf:3d} {bkf:3d} {flops / ms / 1e9:6.1f} {1e3 * ms / count:9.1f}')
+          f'{str(KINDS.get(kind, kind)):24s} {bm:4d} {bn:4d} {split:4d} {akf:3d} {bkf:3d} {flops / ms / 1e9:6.1f} {1e3 * ms / count:9.1f}')

@@ -190,7 +190,11 @@ class Shadow:
 
     def fresh(self):
         if self.key != self._version():
+            # the lazy path (first use, checkpoint load, a test that edited the weights): other streams may launch readers of
+            # this shadow right away -- they are only ordered behind whatever wrote the masters, not behind this repack
             self.repack()
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
         return self
 
     def repack(self):

@@ -556,6 +556,8 @@ __global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p
   const uint32_t a_base = h_lds_address(gs) + (uint32_t)(((4 * mi + 2 * rb + (u >> 1)) * GS + 8 * khalf + j) * 16 + (u & 1) * 8);
   const uint32_t b_base = h_lds_address(xs) + (uint32_t)(((4 * ni + 2 * rb + (u >> 1)) * XS + khalf * HALF + j) * 16 + (u & 1) * 8);
 
+  // a wave whose 32 x 32 block lies entirely beyond the channels that exist (3 input channels: conv1_1) only helps staging
+  const bool active = (tco * 64 + mi * 32) < p.CGY * 8 && (tci * 64 + ni * 32) < p.CGX * 8;
   int tile = walker;
   if (tile < p.pixel_tiles) fetch(tile);
   for (; tile < p.pixel_tiles; tile += p.walkers) {
@@ -578,6 +580,7 @@ __global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p
     __syncthreads();
     const int next = tile + p.walkers;
     if (next < p.pixel_tiles) fetch(next);
+    if (active)
 #pragma unroll 2
     for (int t = 0; t < P / 16; ++t) {       // (not fully unrolled: the scheduler otherwise hoists the transpose reads of many steps and spills)
       const int pix = 16 * t;                                                        // first pixel of the step (tile order)
@@ -603,24 +606,39 @@ __global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p
     for (int r = 0; r < 16; ++r) mine[(t * 16 + r) * 256] = acc[t][r];
 }
 
-// gw[co][ci][tap] += sum over the walkers (in walker order) of the block's partial accumulators.  One thread per element of gw
-// (coalesced writes); the read index undoes the accumulator layout: wave = (co' / 32) * 2 + ci' / 32, C/D row co' % 32 =
-// (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column ci' % 32 = lane & 31.
+// gw[co][ci][tap] += sum over the walkers of the block's partial accumulators, in a FIXED order: a workgroup owns 64
+// consecutive elements of gw (coalesced writes), its four waves add the walkers w = wave, wave + 4, ... of every element (eight
+// independent loads in flight per thread) and the four sums meet as (0 + 1) + (2 + 3).  The read index undoes the accumulator
+// layout: wave = (co' / 32) * 2 + ci' / 32, C/D row co' % 32 = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column ci' % 32 = lane & 31.
 __global__ __launch_bounds__(256) void hwgrad3x3_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                                int32_t CO, int32_t CI, int32_t tiles_ci, int32_t walkers) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)CO * CI * 9) return;
-  const int tap = (int)(idx % 9);
-  const int64_t oc = idx / 9;
-  const int ci = (int)(oc % CI), co = (int)(oc / CI);
-  const int tco = co >> 6, tci = ci >> 6, col = ci & 63, row = co & 63;
-  const int wave = (row >> 5) * 2 + (col >> 5), r32 = row & 31, c32 = col & 31;
-  const int lhi = (r32 >> 2) & 1, r = (r32 & 3) + 4 * (r32 >> 3);
-  const int thread = wave * 64 + lhi * 32 + c32;
-  const float* mine = partial + (int64_t)(tco * tiles_ci + tci) * walkers * (9 * 16 * 256) + (tap * 16 + r) * 256 + thread;
+  __shared__ float sums[4][64];
+  const int lane = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
+  const bool valid = idx < (int64_t)CO * CI * 9;
   float total = 0.f;
-  for (int w = 0; w < walkers; ++w) total += mine[(int64_t)w * (9 * 16 * 256)];
-  gw[idx] += total;
+  if (valid) {
+    const int tap = (int)(idx % 9);
+    const int64_t oc = idx / 9;
+    const int ci = (int)(oc % CI), co = (int)(oc / CI);
+    const int tco = co >> 6, tci = ci >> 6, col = ci & 63, row = co & 63;
+    const int wave = (row >> 5) * 2 + (col >> 5), r32 = row & 31, c32 = col & 31;
+    const int lhi = (r32 >> 2) & 1, r = (r32 & 3) + 4 * (r32 >> 3);
+    const int thread = wave * 64 + lhi * 32 + c32;
+    const float* mine = partial + (int64_t)(tco * tiles_ci + tci) * walkers * (9 * 16 * 256) + (tap * 16 + r) * 256 + thread;
+    int w = part;
+    for (; w + 28 < walkers; w += 32) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = mine[(int64_t)(w + 4 * i) * (9 * 16 * 256)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) total += v[i];
+    }
+    for (; w < walkers; w += 4) total += mine[(int64_t)w * (9 * 16 * 256)];
+  }
+  sums[part][lane] = total;
+  __syncthreads();
+  if (part == 0 && valid) gw[idx] += (sums[0][lane] + sums[1][lane]) + (sums[2][lane] + sums[3][lane]);
 }
 
 float* partial_workspace(size_t bytes, hipStream_t stream);
@@ -811,11 +829,12 @@ int srgan_h_conv3x3_wgrad(const void* x, const void* gy, float* gw, int32_t N, i
   p.tiles_ci = (C_in + 63) / 64;
   const int tiles_co = (C_out + 63) / 64;
   const int blocks = p.tiles_ci * tiles_co;
-  int walkers = (1024 + blocks - 1) / blocks;
+  // Walkers per block: enough workgroups to occupy the chip, but every walker leaves 147 KB of partial accumulators that the
+  // finish reads back -- 1024 / blocks walkers made that traffic (and the finish's serial walker loop) the larger part of the
+  // launch on both ends of VGG (1 block x 1024 walkers; 64 blocks x 16 walkers: 151 MB each, profiles/r06b_*).
+  int walkers = (320 + blocks - 1) / blocks;
   if (walkers > p.pixel_tiles) walkers = p.pixel_tiles;
   if (walkers < 1) walkers = 1;
-  const size_t floats_per_walker = (size_t)blocks * 9 * 16 * 256;
-  while (walkers > 1 && floats_per_walker * walkers * sizeof(float) > ((size_t)192 << 20)) walkers = (walkers + 1) / 2;
   p.walkers = walkers;
   p.partial = partial_workspace((size_t)blocks * walkers * 9 * 16 * 256 * sizeof(float), stream);
   SRGAN_REQUIRE(p.partial, SRGAN_EINVAL, "srgan_h_conv3x3_wgrad: register a workspace for this stream first (srgan_set_workspace)");
@@ -832,7 +851,7 @@ int srgan_h_conv3x3_wgrad(const void* x, const void* gy, float* gw, int32_t N, i
   else HWGRAD_LAUNCH(4, 4);
 #undef HWGRAD_LAUNCH
   const int64_t elements = (int64_t)C_out * C_in * 9;
-  hipLaunchKernelGGL(hwgrad3x3_finish_kernel, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0, stream, p.partial, gw,
+  hipLaunchKernelGGL(hwgrad3x3_finish_kernel, dim3((unsigned)((elements + 63) / 64)), dim3(256), 0, stream, p.partial, gw,
                      C_out, C_in, p.tiles_ci, walkers);
   const int status = launch_status();
   const double pixels = (double)N * H * W;
