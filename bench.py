@@ -635,10 +635,12 @@ def main():
     # What the HOST needs to enqueue one iteration (eager: the Python tape and ~4000 launches; replay: input copies + one graph
     # launch): one more iteration issued into an idle device, timed until the last launch call returns -- no queue
     # back-pressure in the number, which is what matters when eight ranks share a 16-CPU quota.  Outside the timed region.
-    enqueue_start = time.perf_counter()
-    one_step(experiment, labeled, unlabeled, args.warmup + args.steps)
-    host_seconds = time.perf_counter() - enqueue_start
-    fence()
+    host_seconds = float('nan')
+    if not os.environ.get('SRGAN_BENCH_NO_HOST_STEP'):      # (the PMC passes count exactly the timed steps: scratch/pmc_summarise.py)
+        enqueue_start = time.perf_counter()
+        one_step(experiment, labeled, unlabeled, args.warmup + args.steps)
+        host_seconds = time.perf_counter() - enqueue_start
+        fence()
     for live, saved in snapshot:
         restore_weights(live, saved)
     del snapshot
@@ -700,7 +702,7 @@ def main():
                                        'together; sr-gan_amd/srgan.py:_exchanges_are_capturable)')
     result['config']['launch'] = (f'HIP graph replay ({captured.replays} replayed, {captured.eager_iterations} eager iterations)'
                                   if captured is not None else 'eager (Python tape enqueues every kernel)')
-    result['config']['host_ms_per_step'] = round(1e3 * host_seconds, 3)
+    result['config']['host_ms_per_step'] = round(1e3 * host_seconds, 3) if host_seconds == host_seconds else None
     result['config']['schedule_check'] = check if check is not None else 'not applicable: the timed region ran on one stream, eagerly'
     if dp is not None:
         import torch.distributed as dist

@@ -24,7 +24,9 @@ from srgan_amd import _build  # noqa: E402
 CONTRACTION = ('gg_mfma_kernel', 'gg_direct_kernel', 'gg_rows_kernel', 'gg_dot_kernel', 'conv3x3_lds_kernel', 'conv3x3_wgrad_kernel',
                'pointwise_ksplit_kernel', 'pointwise_kernel', 'pointwise_ring_kernel', 'pointwise_wgrad_kernel', 'pointwise_wgrad_grouped_kernel',
                'conv3x3_wgrad_grouped_kernel', 'conv3x3_mixed_kernel', 'stem7x7_fwd_kernel', 'stem7x7_wgrad_kernel',
-               'stem7x7_bwd_data_kernel', 'pointwise_wgrad_lds_kernel', 'pointwise_wgrad_lds_grouped_kernel')
+               'stem7x7_bwd_data_kernel', 'pointwise_wgrad_lds_kernel', 'pointwise_wgrad_lds_grouped_kernel',
+               'hconv3x3_kernel', 'hwgrad3x3_kernel', 'hgemm_kernel', 'hlinear_wgrad_kernel', 'hconv4x4s2_kernel', 'hwgrad4x4s2_kernel',
+               'conv3x3_mixed_small_kernel')
 
 
 def family(name):

@@ -16,6 +16,7 @@
 #include "blocked16.h"
 #include "split_finish.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace srgan {
 
@@ -239,9 +240,54 @@ struct HConv3Params {
   int32_t tiles_x, tiles_y, tiles_m;
   float* split_ws; unsigned int* split_tickets;
   int32_t xcd_remap;
+  int32_t debug;               // SRGAN_H_EXPERIMENT (timing experiments, wrong results): 1 = no staging after the prologue
 };
 
 __device__ unsigned int g_hconv3_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_TILES];
+
+// Epilogue of the 3x3 kernels.  C/D fragment: column = pixel (lane & 31), rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): registers
+// 4q .. 4q + 3 are four CONSECUTIVE output channels = 8 bytes of the pixel's slot of group (m0 + 32 mi) / 8 + q; the 32 lanes of
+// a half cover 32 consecutive slots (with the other half: 512 contiguous bytes per store instruction).
+template <int BM, int NI, int TW, int ROWS, int PREC>
+__device__ __forceinline__ void hconv3_epilogue(const HConv3Params& p, f32x16 (&acc)[BM / 32][NI], int n0, int y0, int x0, int m0,
+                                                int wave, int l31, int lhi) {
+  constexpr int MI = BM / 32;
+  const int HW = p.H * p.W;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int q = (wave * NI + ni) * 32 + l31;
+    const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
+    if (n >= p.N || y >= p.H || x >= p.W) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int group = (m0 + mi * 32) / 8 + qd;
+        if (group >= p.CGO) continue;
+        const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
+        const int64_t slot = ((int64_t)n * p.CGO + group) * HW + y * p.W + x;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * qd + j];
+        if (p.epi == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (p.bias != nullptr && o + j < p.C_real) v[j] += p.bias[o + j];
+            v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+          }
+        } else if (p.epi == 2) {
+          const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
+          v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
+          v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
+        }
+        uint2 packed;
+        packed.x = h_pack2<PREC>(v[0], v[1]);
+        packed.y = h_pack2<PREC>(v[2], v[3]);
+        *(reinterpret_cast<uint2*>(p.out + slot) + lhi) = packed;
+      }
+    }
+  }
+}
 
 // One workgroup (4 waves) = BM output channels x P = 128 * NI pixels.  The pixel tile is IMG x ROWS x TW with
 // IMG * ROWS * TW = P: a ROWS x 32 band of one image on wide planes, whole small images side by side on the 16 / 8 / 4
@@ -249,14 +295,16 @@ __device__ unsigned int g_hconv3_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_
 // 16-channel chunk the halo patch [2 groups][IMG][(ROWS + 2) x (TW + 2)] and the weight slice [9 taps][2 groups][BM] are
 // staged in LDS as operand slots (register-staged: the next chunk's 16-byte loads are in flight during the current
 // chunk's 9 * MI * NI MFMAs) and every fragment is one ds_read_b128.
-template <int BM, int NI, int TW, int ROWS, int PREC>
+// STAGES = 2: two LDS stages, one barrier per chunk; STAGES = 1 (the 512-pixel tiles, whose two stages would not fit two
+// workgroups per CU): one stage, the next chunk waits in registers, two barriers per (twice as long) chunk.
+template <int BM, int NI, int TW, int ROWS, int PREC, int STAGES = 2>
 __global__ __launch_bounds__(256, 2) void hconv3x3_kernel(const HConv3Params p) {
   constexpr int P = 128 * NI, IMG = P / (ROWS * TW), PW = TW + 2, PH = ROWS + 2, PLANE = PH * PW;
   static_assert(IMG * ROWS * TW == P && IMG >= 1, "the pixel tile is IMG x ROWS x TW");
   constexpr int MI = BM / 32;
   constexpr int PATCH_G = IMG * PLANE, PATCH_Q = 2 * PATCH_G, WT_Q = 18 * BM, STAGE_Q = PATCH_Q + WT_Q;
   constexpr int NP = (PATCH_Q + 255) / 256, NW = (WT_Q + 255) / 256;
-  __shared__ Slot lds[2 * STAGE_Q];
+  __shared__ Slot lds[STAGES * STAGE_Q];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   int block = blockIdx.x;
@@ -336,31 +384,43 @@ __global__ __launch_bounds__(256, 2) void hconv3x3_kernel(const HConv3Params p) 
   }
   const int a_lane = PATCH_Q + lhi * BM + l31;              // + tap * 2 * BM + mi * 32
 
+  auto multiply = [&](const Slot* st) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+      Slot a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = st[a_lane + tap * 2 * BM + mi * 32];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = st[b_lane[ni] + kh * PW + kw];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = h_mfma<PREC>(a[mi], b[ni], acc[mi][ni]);
+    }
+  };
   if (cbeg < cend) {
     fetch(cbeg);
-    stage(cbeg, lds);
-    __syncthreads();
-    int cur = 0;
-    for (int c = cbeg; c < cend; ++c) {
-      const bool more = c + 1 < cend;
-      if (more) fetch(c + 1);
-      const Slot* st = lds + cur * STAGE_Q;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int kh = tap / 3, kw = tap % 3;
-        Slot a[MI], b[NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = st[a_lane + tap * 2 * BM + mi * 32];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = st[b_lane[ni] + kh * PW + kw];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = h_mfma<PREC>(a[mi], b[ni], acc[mi][ni]);
-      }
-      if (more) stage(c + 1, lds + (cur ^ 1) * STAGE_Q);     // the other stage: everyone left it at the previous barrier
+    if constexpr (STAGES == 2) {
+      stage(cbeg, lds);
       __syncthreads();
-      cur ^= 1;
+      int cur = 0;
+      for (int c = cbeg; c < cend; ++c) {
+        const bool more = c + 1 < cend;
+        if (more) fetch(c + 1);
+        multiply(lds + cur * STAGE_Q);
+        if (more) stage(c + 1, lds + (cur ^ 1) * STAGE_Q);     // the other stage: everyone left it at the previous barrier
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+      for (int c = cbeg; c < cend; ++c) {
+        if (c > cbeg) __syncthreads();                          // the previous chunk's fragment reads are done
+        stage(c, lds);
+        __syncthreads();
+        if (c + 1 < cend) fetch(c + 1);
+        multiply(lds);
+      }
     }
   }
 
@@ -373,55 +433,144 @@ __global__ __launch_bounds__(256, 2) void hconv3x3_kernel(const HConv3Params p) 
       return;
   }
 
-  // Epilogue.  C/D fragment: column = pixel (lane & 31), rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): registers 4q .. 4q + 3
-  // are four CONSECUTIVE output channels = 8 bytes of the pixel's slot of group (m0 + 32 mi) / 8 + q; the 32 lanes of a half
-  // cover 32 consecutive slots (with the other half: 512 contiguous bytes per store instruction).
+  hconv3_epilogue<BM, NI, TW, ROWS, PREC>(p, acc, n0, y0, x0, m0, wave, l31, lhi);
+}
+
+// ---- the same convolution with LDS-DMA staging (global_load_lds_dwordx4: HBM / L2 -> LDS without passing the registers) -----
+// The register-staged kernel above has ONE chunk in flight per workgroup and pays a ds_write phase per chunk; the counters
+// (profiles/r06f) show its waves parked on memory 46 % of the time at 1.4x the algorithmic HBM bytes: latency, not bandwidth.
+// Here a chunk's patch and weight slots are fetched by DMA into a ring of RING stages, RING - 1 chunks ahead, with no staging
+// registers and no LDS-write instructions.  An LDS-DMA writes lane-linearly (wave-uniform LDS base + lane * 16) from PER-LANE
+// global addresses, and the stage image [patch slots, rounded up to whole 64-slot instructions][weight slots][padding to a
+// multiple of four instructions] is linear in the staging index, so instruction i of a chunk is "slots 64 i .. 64 i + 63" and
+// the halo gather lives entirely in the lanes' source addresses; slots that are padding (outside the image, beyond the
+// channels) read a 16-byte block of zeros in global memory.  Wave w issues instructions w, w + 4, ...: every wave exactly
+// L = TP / 4, so `s_waitcnt vmcnt(L * chunks left in flight)` is exact; one raw s_barrier per chunk (a __syncthreads() would
+// drain the DMA queue).  No K split (the small layers keep the register-staged kernel).
+__device__ Slot g_h_zero_slots[4];
+
+__device__ __forceinline__ void h_glds16(const void* lane_pointer, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_pointer), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void h_dma_wait_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+
+template <int BM, int NI, int TW, int ROWS, int PREC, int RING>
+__global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void hconv3x3_dma_kernel(const HConv3Params p, const Slot* zero) {
+  constexpr int P = 128 * NI, IMG = P / (ROWS * TW), PW = TW + 2, PH = ROWS + 2, PLANE = PH * PW;
+  static_assert(IMG * ROWS * TW == P && IMG >= 1, "the pixel tile is IMG x ROWS x TW");
+  constexpr int MI = BM / 32;
+  constexpr int PATCH_G = IMG * PLANE, PATCH_Q = 2 * PATCH_G, WT_Q = 18 * BM;
+  constexpr int PATCH_I = (PATCH_Q + 63) / 64, WT_I = WT_Q / 64, T = PATCH_I + WT_I, TP = (T + 3) / 4 * 4, L = TP / 4;
+  constexpr int WT_OFF = PATCH_I * 64, STAGE_Q = TP * 64;
+  static_assert(WT_Q % 64 == 0, "whole weight instructions");
+  extern __shared__ __attribute__((aligned(16))) Slot ring[];
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int block = blockIdx.x;
+  if (p.xcd_remap) block = (block & 7) * ((int)gridDim.x >> 3) + (block >> 3);
+  const int tm = block % p.tiles_m; block /= p.tiles_m;
+  const int tx = block % p.tiles_x; block /= p.tiles_x;
+  const int ty = block % p.tiles_y;
+  const int n0 = (block / p.tiles_y) * IMG;
+  const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
+  const int HW = p.H * p.W;
+  const uint32_t lds0 = h_lds_address(ring);
+
+  // this lane's source of instruction wave + 4 e: an offset (slots) from the input of image n0 (patch; + group * HW + the chunk's
+  // 2 * HW * c) or from the packed weights (+ 18 * CO * c); kind 0 patch group 0, 1 patch group 1, 2 weights, 3 zeros
+  int off[L], kind[L];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int q = (wave * NI + ni) * 32 + l31;
-    const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
-    if (n >= p.N || y >= p.H || x >= p.W) continue;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int group = (m0 + mi * 32) / 8 + qd;
-        if (group >= p.CGO) continue;
-        const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
-        const int64_t slot = ((int64_t)n * p.CGO + group) * HW + y * p.W + x;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * qd + j];
-        if (p.epi == 1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (p.bias != nullptr && o + j < p.C_real) v[j] += p.bias[o + j];
-            v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
-          }
-        } else if (p.epi == 2) {
-          const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
-          v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
-          v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
-        }
-        uint2 packed;
-        packed.x = h_pack2<PREC>(v[0], v[1]);
-        packed.y = h_pack2<PREC>(v[2], v[3]);
-        *(reinterpret_cast<uint2*>(p.out + slot) + lhi) = packed;
-      }
+  for (int e = 0; e < L; ++e) {
+    const int i = wave + 4 * e;
+    off[e] = 0; kind[e] = 3;
+    if (i < PATCH_I) {
+      const int flat = i * 64 + lane;
+      const int g = flat / PATCH_G, rest = flat - g * PATCH_G;
+      const int img = rest / PLANE, pix = rest - img * PLANE;
+      const int py = pix / PW, px = pix - py * PW;
+      const int y = y0 - 1 + py, x = x0 - 1 + px;
+      const bool ok = flat < PATCH_Q && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && n0 + img < p.N;
+      if (ok) { off[e] = (img * p.CGI + g) * HW + y * p.W + x; kind[e] = g; }
+    } else if (i < T) {
+      const int flat = (i - PATCH_I) * 64 + lane;
+      const int o = flat % BM, tg = flat / BM;
+      if (m0 + o < p.CO) { off[e] = tg * p.CO + m0 + o; kind[e] = 2; }
     }
   }
+  const Slot* in_n = p.in + (int64_t)n0 * p.CGI * HW;
+  auto issue = [&](int c, int stage) {
+#pragma unroll
+    for (int e = 0; e < L; ++e) {
+      const Slot* src = zero;
+      if (kind[e] == 2) src = p.wp + ((int64_t)c * (18 * p.CO) + off[e]);
+      else if (kind[e] < 2 && 2 * c + kind[e] < p.CGI) src = in_n + ((int64_t)c * (2 * HW) + off[e]);
+      h_glds16(src, lds0 + (uint32_t)((stage * STAGE_Q + (wave + 4 * e) * 64) * 16));
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  int b_lane[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int q = ((tid >> 6) * NI + ni) * 32 + l31;
+    b_lane[ni] = lhi * PATCH_G + (q / (ROWS * TW)) * PLANE + ((q / TW) % ROWS) * PW + q % TW;
+  }
+  const int a_lane = WT_OFF + lhi * BM + l31;
+
+  const int chunks = p.chunks;
+#pragma unroll
+  for (int d = 0; d < RING - 1; ++d)
+    if (d < chunks) issue(d, d);
+  if ((p.debug & 1) && RING - 1 < chunks) issue(RING - 1, RING - 1);       // (experiment: every stage holds finite data)
+  int stage = 0;
+  for (int c = 0; c < chunks; ++c) {
+    // chunk c has landed (this wave's part: vmcnt; everybody's: the barrier), and everybody is done reading the stage that
+    // chunk c + RING - 1 goes into (it held chunk c - 1)
+    if (RING == 3 && c + 1 < chunks) h_dma_wait_and_barrier<L>();
+    else h_dma_wait_and_barrier<0>();
+    if (c + RING - 1 < chunks && !(p.debug & 1)) issue(c + RING - 1, (stage + RING - 1) % RING);
+    const Slot* st = ring + stage * STAGE_Q;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+      Slot a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = st[a_lane + tap * 2 * BM + mi * 32];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = st[b_lane[ni] + kh * PW + kw];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = h_mfma<PREC>(a[mi], b[ni], acc[mi][ni]);
+    }
+    stage = stage + 1 == RING ? 0 : stage + 1;
+  }
+  hconv3_epilogue<BM, NI, TW, ROWS, PREC>(p, acc, n0, y0, x0, m0, tid >> 6, l31, lhi);
 }
 
 struct HConv3Plan { int bm, ni, tw, rows, tiles_x, tiles_y, tiles_m, tiles_n, split, chunks_per; int64_t blocks; };
 
 static bool hconv3_plan(int32_t N, int32_t CGI, int32_t CO_rows, int32_t H, int32_t W, HConv3Plan& plan) {
-  // tile width and the image rows of a 128-pixel (NI = 1) / 256-pixel (NI = 2) tile
-  int tw, rows_for_ni[3] = {0, 0, 0};
-  bool ni2_ok = true;
-  if (W > 16) { tw = 32; rows_for_ni[1] = 4; rows_for_ni[2] = 8; }
-  else if (W == 8 && H == 8) { tw = 8; rows_for_ni[1] = 8; rows_for_ni[2] = 8; }                 // whole images side by side
-  else if (W == 4 && H == 4) { tw = 4; rows_for_ni[1] = 4; rows_for_ni[2] = 4; ni2_ok = false; } // (32 KB of LDS per stage at NI = 2)
-  else { tw = 16; rows_for_ni[1] = 8; rows_for_ni[2] = 16; }
+  // tile width and the image rows of a 128 * NI pixel tile (NI = 1, 2, 4; 0 = that tile does not exist for the plane)
+  int tw, rows_for_ni[5] = {0, 0, 0, 0, 0};
+  if (W > 16) { tw = 32; rows_for_ni[1] = 4; rows_for_ni[2] = 8; rows_for_ni[4] = 16; }
+  else if (W == 8 && H == 8) { tw = 8; rows_for_ni[1] = rows_for_ni[2] = rows_for_ni[4] = 8; }   // whole images side by side
+  else if (W == 4 && H == 4) { tw = 4; rows_for_ni[1] = 4; }                                      // (32 KB of LDS per stage at NI = 2)
+  else { tw = 16; rows_for_ni[1] = 8; rows_for_ni[2] = 16; if (H == 16) rows_for_ni[4] = 16; }    // (NI = 4: two whole images)
+  static const bool no_wide = getenv("SRGAN_H_NO_WIDE_TILE") != nullptr;
+  if (no_wide) rows_for_ni[4] = 0;
   plan.tw = tw;
   plan.bm = CO_rows > 32 ? 64 : 32;
   plan.tiles_m = (CO_rows + plan.bm - 1) / plan.bm;
@@ -431,8 +580,15 @@ static bool hconv3_plan(int32_t N, int32_t CGI, int32_t CO_rows, int32_t H, int3
     const int64_t tx = (W + tw - 1) / tw, ty = img > 1 ? 1 : (H + rows - 1) / rows, tn = (N + img - 1) / img;
     return tx * ty * tn * plan.tiles_m;
   };
-  int ni = 2;
-  if (!ni2_ok || count(2) < 512) ni = 1;
+  // the largest pixel tile that still gives two workgroups per CU: the weight slice of a chunk (18 KB at 64 rows) is staged once
+  // per tile, and the L2 -> LDS stream, not the matrix pipe, bounds these kernels
+  int ni = 1;
+  if (rows_for_ni[4] && plan.bm == 64 && count(4) >= 512) ni = 4;
+  else if (rows_for_ni[2] && count(2) >= 512) ni = 2;
+  if (const char* forced = getenv("SRGAN_H_CONV_NI")) {          // tests: every tile shape on small tensors
+    const int want = atoi(forced);
+    if ((want == 1 || want == 2 || want == 4) && rows_for_ni[want] && (want != 4 || plan.bm == 64)) ni = want;
+  }
   plan.ni = ni;
   plan.rows = rows_for_ni[ni];
   const int img = 128 * ni / (plan.rows * tw);
@@ -455,21 +611,68 @@ static bool hconv3_plan(int32_t N, int32_t CGI, int32_t CO_rows, int32_t H, int3
 
 template <int BM, int NI, int PREC>
 static void hconv3_launch_tiles(const HConv3Params& p, int tw, dim3 grid, hipStream_t stream) {
-  if (tw == 32) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 32, 4 * NI, PREC>), grid, dim3(256), 0, stream, p);
-  else if (tw == 16) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 16, 8 * NI, PREC>), grid, dim3(256), 0, stream, p);
-  else if (tw == 8) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 8, 8, PREC>), grid, dim3(256), 0, stream, p);
-  else if constexpr (NI == 1) hipLaunchKernelGGL((hconv3x3_kernel<BM, 1, 4, 4, PREC>), grid, dim3(256), 0, stream, p);
+  if constexpr (NI == 4) {
+    if (tw == 32) hipLaunchKernelGGL((hconv3x3_kernel<BM, 4, 32, 16, PREC, 1>), grid, dim3(256), 0, stream, p);
+    else if (tw == 16) hipLaunchKernelGGL((hconv3x3_kernel<BM, 4, 16, 16, PREC, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((hconv3x3_kernel<BM, 4, 8, 8, PREC, 1>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (tw == 32) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 32, 4 * NI, PREC>), grid, dim3(256), 0, stream, p);
+    else if (tw == 16) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 16, 8 * NI, PREC>), grid, dim3(256), 0, stream, p);
+    else if (tw == 8) hipLaunchKernelGGL((hconv3x3_kernel<BM, NI, 8, 8, PREC>), grid, dim3(256), 0, stream, p);
+    else if constexpr (NI == 1) hipLaunchKernelGGL((hconv3x3_kernel<BM, 1, 4, 4, PREC>), grid, dim3(256), 0, stream, p);
+  }
 }
 
 template <int PREC>
 static void hconv3_launch(const HConv3Params& p, const HConv3Plan& plan, dim3 grid, hipStream_t stream) {
   if (plan.bm == 64) {
-    if (plan.ni == 2) hconv3_launch_tiles<64, 2, PREC>(p, plan.tw, grid, stream);
+    if (plan.ni == 4) hconv3_launch_tiles<64, 4, PREC>(p, plan.tw, grid, stream);
+    else if (plan.ni == 2) hconv3_launch_tiles<64, 2, PREC>(p, plan.tw, grid, stream);
     else hconv3_launch_tiles<64, 1, PREC>(p, plan.tw, grid, stream);
   } else {
     if (plan.ni == 2) hconv3_launch_tiles<32, 2, PREC>(p, plan.tw, grid, stream);
     else hconv3_launch_tiles<32, 1, PREC>(p, plan.tw, grid, stream);
   }
+}
+
+// ---- launchers of the LDS-DMA ring kernel (64-row tiles, unsplit K) -------------------------------------------------------
+template <int NI, int TW, int ROWS, int PREC, int RING>
+static int hconv3_dma_launch_one(const HConv3Params& p, dim3 grid, hipStream_t stream, const Slot* zero) {
+  constexpr int P = 128 * NI, IMG = P / (ROWS * TW), PLANE = (ROWS + 2) * (TW + 2);
+  constexpr int PATCH_I = (2 * IMG * PLANE + 63) / 64, T = PATCH_I + 18, TP = (T + 3) / 4 * 4;
+  constexpr int bytes = RING * TP * 64 * 16;
+  static_assert(bytes <= 160 * 1024, "the ring fits the CU's LDS");
+  auto kernel = hconv3x3_dma_kernel<64, NI, TW, ROWS, PREC, RING>;
+  // more than 64 KB of dynamic LDS needs the attribute, once per kernel and device (as pointwise_ring.hip)
+  static std::atomic<uint64_t> configured_devices{0};
+  int device = 0;
+  SRGAN_HIP(hipGetDevice(&device));
+  const uint64_t bit = (uint64_t)1 << (device & 63);
+  if (!(configured_devices.load(std::memory_order_acquire) & bit)) {
+    SRGAN_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    configured_devices.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(256), bytes, stream, p, zero);
+  return SRGAN_OK;
+}
+
+template <int PREC, int RING>
+static int hconv3_dma_launch(const HConv3Params& p, const HConv3Plan& plan, dim3 grid, hipStream_t stream, const Slot* zero) {
+  const int tw = plan.tw;
+  if (plan.ni == 4) {
+    if (tw == 32) return hconv3_dma_launch_one<4, 32, 16, PREC, RING>(p, grid, stream, zero);
+    if (tw == 16) return hconv3_dma_launch_one<4, 16, 16, PREC, RING>(p, grid, stream, zero);
+    return hconv3_dma_launch_one<4, 8, 8, PREC, RING>(p, grid, stream, zero);
+  }
+  if (plan.ni == 2) {
+    if (tw == 32) return hconv3_dma_launch_one<2, 32, 8, PREC, RING>(p, grid, stream, zero);
+    if (tw == 16) return hconv3_dma_launch_one<2, 16, 16, PREC, RING>(p, grid, stream, zero);
+    return hconv3_dma_launch_one<2, 8, 8, PREC, RING>(p, grid, stream, zero);
+  }
+  if (tw == 32) return hconv3_dma_launch_one<1, 32, 4, PREC, RING>(p, grid, stream, zero);
+  if (tw == 16) return hconv3_dma_launch_one<1, 16, 8, PREC, RING>(p, grid, stream, zero);
+  if (tw == 8) return hconv3_dma_launch_one<1, 8, 8, PREC, RING>(p, grid, stream, zero);
+  return hconv3_dma_launch_one<1, 4, 4, PREC, RING>(p, grid, stream, zero);
 }
 
 // ---------------------------------------------------------------------------------------------------- 3x3 weight gradient
@@ -490,16 +693,19 @@ struct HWgrad3Params {
 constexpr int HWGRAD_P = 64;      // pixels per staged tile (128 needs 44+ staging registers next to the 144 accumulators: spills)
 constexpr int h_pad_stride(int slots) { return ((slots + 15) / 16) * 16 + 4; }     // = 4 slots (mod 16): the two groups of a
                                                                                   // transpose read land 64 bytes apart
-template <int TW, int ROWS, int PREC>
-__global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p) {
+// MB = 32-row blocks of output channels per workgroup: 2 (64 x 64 block, 4 waves, two workgroups per CU) or 4 (128 x 64 block,
+// 8 waves = two per SIMD in one workgroup: the x patch, two thirds of the staged bytes, is then shared by twice the matrix work).
+template <int TW, int ROWS, int PREC, int MB>
+__global__ __launch_bounds__(128 * MB, 2) void hwgrad3x3_kernel(const HWgrad3Params p) {
+  constexpr int THREADS = 128 * MB;
   constexpr int P = HWGRAD_P, IMG = P / (ROWS * TW), PW = TW + 2, PH = ROWS + 2, PLANE = PH * PW;
   static_assert(IMG * ROWS * TW == P && IMG >= 1, "the pixel tile is IMG x ROWS x TW");
   constexpr int GS = h_pad_stride(P), XS = h_pad_stride(IMG * PLANE);       // group strides of the two LDS images (slots)
-  constexpr int GQ = 8 * P, XQ = 8 * IMG * PLANE;                           // slots staged per tile
-  constexpr int NG = GQ / 256, NX = (XQ + 255) / 256;
-  __shared__ Slot lds[8 * GS + 8 * XS];
+  constexpr int GQ = 4 * MB * P, XQ = 8 * IMG * PLANE;                      // slots staged per tile
+  constexpr int NG = GQ / THREADS, NX = (XQ + THREADS - 1) / THREADS;
+  __shared__ Slot lds[4 * MB * GS + 8 * XS];
   Slot* gs = lds;
-  Slot* xs = lds + 8 * GS;
+  Slot* xs = lds + 4 * MB * GS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave >> 1, ni = wave & 1;
@@ -507,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p
   const int walker = (int)blockIdx.y;
   const int HW = p.H * p.W;
 
-  // staging ownership: gy slot e * 256 + tid -> (group, tile pixel); x slot -> (group, image, patch position); the index
+  // staging ownership: gy slot e * THREADS + tid -> (group, tile pixel); x slot -> (group, image, patch position); the index
   // arithmetic (compile-time divisors) is redone where it is used instead of being kept in registers
   Slot rg[NG], rx[NX];
   uint32_t okg = 0, okx = 0;
@@ -520,17 +726,17 @@ __global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p
     okg = okx = 0;
 #pragma unroll
     for (int e = 0; e < NG; ++e) {
-      const int flat = e * 256 + tid;
+      const int flat = e * THREADS + tid;
       const int grp = flat / P, q = flat % P;
       const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
-      const int group = tco * 8 + grp;
+      const int group = tco * (4 * MB) + grp;
       const bool ok = n < p.N && y < p.H && x < p.W && group < p.CGY;
       okg |= (ok ? 1u : 0u) << e;
       rg[e] = p.gy[ok ? ((int64_t)n * p.CGY + group) * HW + y * p.W + x : 0];
     }
 #pragma unroll
     for (int e = 0; e < NX; ++e) {
-      const int flat = e * 256 + tid;
+      const int flat = e * THREADS + tid;
       const int grp = flat / (IMG * PLANE), rest = flat - grp * (IMG * PLANE);
       const int img = rest / PLANE, pix = rest % PLANE;
       const int n = n0 + img, y = y0 - 1 + pix / PW, x = x0 - 1 + pix % PW;
@@ -557,21 +763,21 @@ __global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p
   const uint32_t b_base = h_lds_address(xs) + (uint32_t)(((4 * ni + 2 * rb + (u >> 1)) * XS + khalf * HALF + j) * 16 + (u & 1) * 8);
 
   // a wave whose 32 x 32 block lies entirely beyond the channels that exist (3 input channels: conv1_1) only helps staging
-  const bool active = (tco * 64 + mi * 32) < p.CGY * 8 && (tci * 64 + ni * 32) < p.CGX * 8;
+  const bool active = (tco * (32 * MB) + mi * 32) < p.CGY * 8 && (tci * 64 + ni * 32) < p.CGX * 8;
   int tile = walker;
   if (tile < p.pixel_tiles) fetch(tile);
   for (; tile < p.pixel_tiles; tile += p.walkers) {
     __syncthreads();                        // the previous tile's reads are done
 #pragma unroll
     for (int e = 0; e < NG; ++e) {
-      const int flat = e * 256 + tid;
+      const int flat = e * THREADS + tid;
       Slot v = rg[e];
       if (!((okg >> e) & 1u)) v = Slot{{0u, 0u, 0u, 0u}};
       gs[(flat / P) * GS + flat % P] = v;
     }
 #pragma unroll
     for (int e = 0; e < NX; ++e) {
-      const int flat = e * 256 + tid;
+      const int flat = e * THREADS + tid;
       const int grp = flat / (IMG * PLANE), rest = flat - grp * (IMG * PLANE);
       Slot v = rx[e];
       if (!((okx >> e) & 1u)) v = Slot{{0u, 0u, 0u, 0u}};
@@ -599,46 +805,53 @@ __global__ __launch_bounds__(256, 2) void hwgrad3x3_kernel(const HWgrad3Params p
     }
   }
 
-  float* mine = p.partial + ((int64_t)blockIdx.x * p.walkers + walker) * (9 * 16 * 256) + tid;
+  float* mine = p.partial + ((int64_t)blockIdx.x * p.walkers + walker) * (9 * 16 * THREADS) + tid;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[(t * 16 + r) * 256] = acc[t][r];
+    for (int r = 0; r < 16; ++r) mine[(t * 16 + r) * THREADS] = acc[t][r];
 }
 
-// gw[co][ci][tap] += sum over the walkers of the block's partial accumulators, in a FIXED order: a workgroup owns 64
-// consecutive elements of gw (coalesced writes), its four waves add the walkers w = wave, wave + 4, ... of every element (eight
-// independent loads in flight per thread) and the four sums meet as (0 + 1) + (2 + 3).  The read index undoes the accumulator
-// layout: wave = (co' / 32) * 2 + ci' / 32, C/D row co' % 32 = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column ci' % 32 = lane & 31.
+// gw[co][ci][tap] += sum over the walkers of the block's partial accumulators, in a FIXED order.  One workgroup per (block,
+// output channel): the 64 input channels x 9 taps of that row are 576 consecutive floats of gw.  Lane l of every wave reads
+// input channel l of each tap -- two 128-byte runs of the partial block per (walker, tap), whole lines: the first version gave a
+// workgroup 64 consecutive gw elements = 7 of a line's 32 floats and fetched every line 4.5 times (18 GB per step, PMC
+// profiles/r06f) -- the four waves add the walkers w = wave, wave + 4, ... and the four sums meet as (0 + 1) + (2 + 3); the
+// row leaves through LDS in gw's own order.  The read index undoes the accumulator layout: wave = (co' / 32) * 2 + ci' / 32,
+// C/D row co' % 32 = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column ci' % 32 = lane & 31.
 __global__ __launch_bounds__(256) void hwgrad3x3_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw,
-                                                               int32_t CO, int32_t CI, int32_t tiles_ci, int32_t walkers) {
-  __shared__ float sums[4][64];
+                                                               int32_t CO, int32_t CI, int32_t tiles_ci, int32_t walkers,
+                                                               int32_t block_rows) {
+  __shared__ float sums[4][9][64];
   const int lane = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
-  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
-  const bool valid = idx < (int64_t)CO * CI * 9;
-  float total = 0.f;
-  if (valid) {
-    const int tap = (int)(idx % 9);
-    const int64_t oc = idx / 9;
-    const int ci = (int)(oc % CI), co = (int)(oc / CI);
-    const int tco = co >> 6, tci = ci >> 6, col = ci & 63, row = co & 63;
-    const int wave = (row >> 5) * 2 + (col >> 5), r32 = row & 31, c32 = col & 31;
-    const int lhi = (r32 >> 2) & 1, r = (r32 & 3) + 4 * (r32 >> 3);
-    const int thread = wave * 64 + lhi * 32 + c32;
-    const float* mine = partial + (int64_t)(tco * tiles_ci + tci) * walkers * (9 * 16 * 256) + (tap * 16 + r) * 256 + thread;
-    int w = part;
-    for (; w + 28 < walkers; w += 32) {
-      float v[8];
+  const int block = (int)blockIdx.x / block_rows, row = (int)blockIdx.x % block_rows;
+  const int tco = block / tiles_ci, tci = block % tiles_ci;
+  const int co = tco * block_rows + row;
+  if (co >= CO) return;
+  const int threads = 4 * block_rows;
+  const int64_t per_walker = (int64_t)9 * 16 * threads;              // accumulators of one workgroup
+  const int r32 = row & 31, lhi = (r32 >> 2) & 1, r = (r32 & 3) + 4 * (r32 >> 3);
+  const int thread = ((row >> 5) * 2 + (lane >> 5)) * 64 + lhi * 32 + (lane & 31);
+  const float* base = partial + (int64_t)block * walkers * per_walker + r * threads + thread;
+  float total[9];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = mine[(int64_t)(w + 4 * i) * (9 * 16 * 256)];
+  for (int t = 0; t < 9; ++t) total[t] = 0.f;
+  for (int w = part; w < walkers; w += 4) {
+    float v[9];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) total += v[i];
-    }
-    for (; w < walkers; w += 4) total += mine[(int64_t)w * (9 * 16 * 256)];
+    for (int t = 0; t < 9; ++t) v[t] = base[(int64_t)w * per_walker + t * 16 * threads];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) total[t] += v[t];
   }
-  sums[part][lane] = total;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) sums[part][t][lane] = total[t];
   __syncthreads();
-  if (part == 0 && valid) gw[idx] += (sums[0][lane] + sums[1][lane]) + (sums[2][lane] + sums[3][lane]);
+  for (int i = (int)threadIdx.x; i < 576; i += 256) {
+    const int ci_local = i / 9, tap = i - ci_local * 9;
+    const int ci = tci * 64 + ci_local;
+    if (ci < CI)
+      gw[((int64_t)co * CI + ci) * 9 + tap] += (sums[0][tap][ci_local] + sums[1][tap][ci_local]) + (sums[2][tap][ci_local] + sums[3][tap][ci_local]);
+  }
 }
 
 float* partial_workspace(size_t bytes, hipStream_t stream);
@@ -797,9 +1010,26 @@ int srgan_h_conv3x3(const void* x, const void* packed, const float* bias, const 
     }
   }
   p.xcd_remap = (plan.blocks % 8 == 0 && plan.blocks >= 64) ? 1 : 0;
+  static const int experiment = getenv("SRGAN_H_EXPERIMENT") ? atoi(getenv("SRGAN_H_EXPERIMENT")) : 0;
+  p.debug = experiment;
   const dim3 grid((unsigned)plan.blocks, (unsigned)split, 1);
+  // LDS-DMA ring for 64-row tiles with an unsplit K.  SRGAN_H_DMA_RING: 0 = off (register staging), 2 / 3 = that many stages;
+  // default two stages = two workgroups per CU.  Measured (profiles/r06h_*, scratch/h_conv_bench.py): three stages -- two chunks
+  // in flight but ONE workgroup per CU -- lose 25-40 %; two stages equal the register-staged kernel on the wide planes and gain
+  // 15-20 % on the 16 x 16 / 8 x 8 planes of the stacked pass.  With the staging switched off altogether the loop reaches
+  // 950-1160 TF/s: fragment reads and matrix work, not the operand stream, are the larger part of what is left.
+  static const int ring_env = getenv("SRGAN_H_DMA_RING") ? atoi(getenv("SRGAN_H_DMA_RING")) : -1;
+  const int ring = ring_env >= 0 ? ring_env : 2;
+  const Slot* zero = (ring == 2 || ring == 3) && split == 1 && plan.bm == 64
+                         ? reinterpret_cast<const Slot*>(device_tickets(g_h_zero_slots)) : nullptr;
   const int slot = profile_bracket_begin(stream);
-  if (dtype == 1) hconv3_launch<1>(p, plan, grid, stream);
+  if (zero) {
+    int launched;
+    if (ring == 3) launched = dtype == 1 ? hconv3_dma_launch<1, 3>(p, plan, grid, stream, zero) : hconv3_dma_launch<2, 3>(p, plan, grid, stream, zero);
+    else launched = dtype == 1 ? hconv3_dma_launch<1, 2>(p, plan, grid, stream, zero) : hconv3_dma_launch<2, 2>(p, plan, grid, stream, zero);
+    if (launched != SRGAN_OK) return launched;
+  }
+  else if (dtype == 1) hconv3_launch<1>(p, plan, grid, stream);
   else hconv3_launch<2>(p, plan, grid, stream);
   const int status = launch_status();
   const double pixels = (double)N * H * W;
@@ -827,23 +1057,32 @@ int srgan_h_conv3x3_wgrad(const void* x, const void* gy, float* gw, int32_t N, i
   p.tiles_n = (N + img - 1) / img;
   p.pixel_tiles = p.tiles_x * p.tiles_y * p.tiles_n;
   p.tiles_ci = (C_in + 63) / 64;
-  const int tiles_co = (C_out + 63) / 64;
+  static const bool no_tall = getenv("SRGAN_H_WGRAD_64") != nullptr;
+  const int mb = (C_out >= 128 && !no_tall) ? 4 : 2;                 // 128- or 64-row blocks of gw
+  const int tiles_co = (C_out + 32 * mb - 1) / (32 * mb);
   const int blocks = p.tiles_ci * tiles_co;
-  // Walkers per block: enough workgroups to occupy the chip, but every walker leaves 147 KB of partial accumulators that the
-  // finish reads back -- 1024 / blocks walkers made that traffic (and the finish's serial walker loop) the larger part of the
-  // launch on both ends of VGG (1 block x 1024 walkers; 64 blocks x 16 walkers: 151 MB each, profiles/r06b_*).
-  int walkers = (320 + blocks - 1) / blocks;
+  // Walkers per block: enough workgroups to occupy the chip, but every walker leaves its accumulators (147 / 295 KB) as a partial
+  // block that the finish reads back -- 1024 / blocks walkers made that traffic (and the finish's serial walker loop) the larger
+  // part of the launch on both ends of VGG (1 block x 1024 walkers; 64 blocks x 16 walkers: 151 MB each, profiles/r06b_*).
+  const int target = mb == 4 ? 256 : 320;
+  int walkers = (target + blocks - 1) / blocks;
   if (walkers > p.pixel_tiles) walkers = p.pixel_tiles;
   if (walkers < 1) walkers = 1;
   p.walkers = walkers;
-  p.partial = partial_workspace((size_t)blocks * walkers * 9 * 16 * 256 * sizeof(float), stream);
+  const int threads = 128 * mb;
+  p.partial = partial_workspace((size_t)blocks * walkers * 9 * 16 * threads * sizeof(float), stream);
   SRGAN_REQUIRE(p.partial, SRGAN_EINVAL, "srgan_h_conv3x3_wgrad: register a workspace for this stream first (srgan_set_workspace)");
   const dim3 grid((unsigned)blocks, (unsigned)walkers);
   const int slot = profile_bracket_begin(stream);
 #define HWGRAD_LAUNCH(TWv, ROWSv)                                                                                       \
   do {                                                                                                                  \
-    if (dtype == 1) hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 1>), grid, dim3(256), 0, stream, p);             \
-    else hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 2>), grid, dim3(256), 0, stream, p);                        \
+    if (mb == 4) {                                                                                                      \
+      if (dtype == 1) hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 1, 4>), grid, dim3(512), 0, stream, p);         \
+      else hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 2, 4>), grid, dim3(512), 0, stream, p);                    \
+    } else {                                                                                                            \
+      if (dtype == 1) hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 1, 2>), grid, dim3(256), 0, stream, p);         \
+      else hipLaunchKernelGGL((hwgrad3x3_kernel<TWv, ROWSv, 2, 2>), grid, dim3(256), 0, stream, p);                    \
+    }                                                                                                                   \
   } while (0)
   if (tw == 32) HWGRAD_LAUNCH(32, 2);
   else if (tw == 16) HWGRAD_LAUNCH(16, 4);
@@ -851,11 +1090,11 @@ int srgan_h_conv3x3_wgrad(const void* x, const void* gy, float* gw, int32_t N, i
   else HWGRAD_LAUNCH(4, 4);
 #undef HWGRAD_LAUNCH
   const int64_t elements = (int64_t)C_out * C_in * 9;
-  hipLaunchKernelGGL(hwgrad3x3_finish_kernel, dim3((unsigned)((elements + 63) / 64)), dim3(256), 0, stream, p.partial, gw,
-                     C_out, C_in, p.tiles_ci, walkers);
+  hipLaunchKernelGGL(hwgrad3x3_finish_kernel, dim3((unsigned)(blocks * 32 * mb)), dim3(256), 0, stream, p.partial, gw,
+                     C_out, C_in, p.tiles_ci, walkers, 32 * mb);
   const int status = launch_status();
   const double pixels = (double)N * H * W;
-  profile_bracket_end_bytes(slot, stream, C_out, (int64_t)C_in * 9, (int64_t)pixels, 15, 64, 64, walkers,
+  profile_bracket_end_bytes(slot, stream, C_out, (int64_t)C_in * 9, (int64_t)pixels, 15, 32 * mb, 64, walkers,
                             2.0 * pixels * (p.CGX + p.CGY) * 8 + 8.0 * (double)elements, dtype);
   return status;
 }

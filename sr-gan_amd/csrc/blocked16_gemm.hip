@@ -41,6 +41,39 @@ __global__ __launch_bounds__(256) void h_pack_matrix_kernel(const float* __restr
   out[slot] = h_pack8<PREC>(v);
 }
 
+// The same for row_stride == 1 (the TRANSPOSED shadow of a row-major matrix: consecutive output rows are consecutive source
+// addresses): a 64 x 64 tile goes through LDS, so both the fp32 reads (along r) and the 16-byte slot stores (along c) are
+// coalesced -- the one-thread-per-slot kernel read eight floats a row pitch apart and fetched every line seven times
+// (4.1 GB per step for VGG-16's two large linear layers, PMC profiles/r06f).
+template <int PREC>
+__global__ __launch_bounds__(256) void h_pack_matrix_transposed_kernel(const float* __restrict__ src, Slot* __restrict__ out,
+                                                                       int64_t rows, int32_t row_slots, int64_t rows_real,
+                                                                       int64_t cols_real, int64_t cs, int32_t row_plane,
+                                                                       int32_t col_plane, int32_t tiles_r) {
+  __shared__ float tile[64][65];
+  const int tid = (int)threadIdx.x;
+  const int64_t r0 = (int64_t)((int)blockIdx.x % tiles_r) * 64, c0 = (int64_t)((int)blockIdx.x / tiles_r) * 64;
+  const int r_load = tid & 63;
+  const int64_t rr = h_plane_index(r0 + r_load, row_plane);
+  const bool row_ok = r0 + r_load < rows && rr < rows_real;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c_local = (tid >> 6) + 4 * i;
+    const int64_t cc = h_plane_index(c0 + c_local, col_plane);
+    tile[c_local][r_load] = (row_ok && c0 + c_local < (int64_t)row_slots * 8 && cc < cols_real) ? src[cc * cs + rr] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot_local = tid & 7, r_local = (tid >> 3) + 32 * i;
+    if (r0 + r_local >= rows || c0 / 8 + slot_local >= row_slots) continue;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[slot_local * 8 + j][r_local];
+    out[(r0 + r_local) * row_slots + c0 / 8 + slot_local] = h_pack8<PREC>(v);
+  }
+}
+
 struct HGemmParams {
   const Slot* a; const Slot* b; Slot* out; const float* bias; const Slot* ref;
   float slope; int32_t epi;
@@ -299,6 +332,13 @@ int srgan_h_pack_matrix(const float* src, void* out, int64_t rows, int64_t cols,
   SRGAN_REQUIRE(src && out && rows > 0 && cols > 0, SRGAN_EINVAL, "srgan_h_pack_matrix arguments");
   const int64_t row_slots = (cols + 7) / 8, slots = rows * row_slots;
   SRGAN_REQUIRE(row_slots < ((int64_t)1 << 31), SRGAN_ERANGE, "srgan_h_pack_matrix row length");
+  if (row_stride == 1 && col_stride != 1) {
+    const int tiles_r = (int)((rows + 63) / 64), tiles_c = (int)((row_slots * 8 + 63) / 64);
+    const dim3 tgrid((unsigned)(tiles_r * tiles_c));
+    if (dtype == 1) hipLaunchKernelGGL(h_pack_matrix_transposed_kernel<1>, tgrid, dim3(256), 0, stream, src, (Slot*)out, rows, (int32_t)row_slots, rows_real, cols_real, col_stride, row_plane, col_plane, tiles_r);
+    else hipLaunchKernelGGL(h_pack_matrix_transposed_kernel<2>, tgrid, dim3(256), 0, stream, src, (Slot*)out, rows, (int32_t)row_slots, rows_real, cols_real, col_stride, row_plane, col_plane, tiles_r);
+    return launch_status();
+  }
   const dim3 grid((unsigned)((slots + 255) / 256));
   if (dtype == 1) hipLaunchKernelGGL(h_pack_matrix_kernel<1>, grid, dim3(256), 0, stream, src, (Slot*)out, slots, (int32_t)row_slots, rows_real, cols_real, row_stride, col_stride, row_plane, col_plane);
   else hipLaunchKernelGGL(h_pack_matrix_kernel<2>, grid, dim3(256), 0, stream, src, (Slot*)out, slots, (int32_t)row_slots, rows_real, cols_real, row_stride, col_stride, row_plane, col_plane);

@@ -55,7 +55,32 @@ def nchw(B, var):
 # planes: 64-wide and ragged 40-wide (32-column tiles), 16 x 16, 8 x 8, 4 x 4 (whole images side by side), 14 x 14 and 7 x 7
 # (guards of the 16-wide tile); channel tails on both sides; few / many images
 CONVS = [(2, 64, 64, 64, 64), (3, 24, 12, 40, 40), (2, 3, 64, 64, 64), (5, 128, 16, 16, 72), (19, 40, 4, 4, 72), (9, 32, 8, 8, 200),
-         (32, 256, 4, 4, 128), (3, 48, 14, 14, 16), (2, 16, 7, 7, 8), (4, 64, 32, 32, 128), (130, 16, 8, 8, 64), (2, 64, 20, 16, 3)]
+         (32, 256, 4, 4, 128), (3, 48, 14, 14, 16), (2, 16, 7, 7, 8), (4, 64, 32, 32, 128), (130, 16, 8, 8, 64), (2, 64, 20, 16, 3),
+         (3, 40, 16, 16, 136)]
+
+
+@pytest.mark.parametrize('tile', ['1', '2', '4'])
+@pytest.mark.parametrize('case', [(2, 64, 64, 64, 64), (5, 128, 16, 16, 72), (9, 32, 8, 8, 200), (3, 24, 12, 40, 40), (19, 40, 4, 4, 72),
+                                  (3, 72, 20, 16, 136), (2, 8, 33, 70, 64)])
+def test_conv3x3_is_exact_with_every_pixel_tile(F, B, monkeypatch, tile, case):
+    """The 128- / 256- / 512-pixel tiles of the 3x3 kernels (the plan picks by workgroup count; forced here).  The staging
+    variant -- LDS-DMA ring of 2 / 3 stages or registers -- is read once per process (SRGAN_H_DMA_RING): the default policy
+    runs here (a ring of 2; registers where K is split or the tile has 32 rows),
+    `test_conv3x3_staging_variants_agree` runs the others in child processes."""
+    monkeypatch.setenv('SRGAN_H_CONV_NI', tile)
+    test_conv3x3_forward_data_gradient_and_weight_gradient_are_exact_on_integers(F, B, 'bf16', case)
+
+
+@pytest.mark.parametrize('ring', ['0', '2', '3'])
+def test_conv3x3_staging_variants_agree(ring):
+    """The exactness tests again with the staging variant forced for every launch (a child process each: the switch is read
+    once)."""
+    import subprocess
+    environment = dict(os.environ, SRGAN_H_DMA_RING=ring)
+    completed = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
+                                'every_pixel_tile or exact_on_integers'], env=environment, capture_output=True, text=True,
+                               cwd=ROOT, timeout=900)
+    assert completed.returncode == 0, completed.stdout[-3000:] + completed.stderr[-2000:]
 
 
 @pytest.mark.parametrize('mode', MODES)
@@ -267,3 +292,23 @@ def test_shadows_follow_the_optimizer(F, B):
         want = model(F.leaf(x))                                  # fp32 tensors, bf16 operands: reads the masters
     assert not torch.equal(before.data, after.data)
     assert torch.allclose(after.data, want.data, rtol=3e-2, atol=3e-2 * want.data.abs().max().item())
+
+
+@pytest.mark.parametrize('batch', [8, 128])
+def test_age_vgg_step_on_bf16_storage_against_the_fp32_oracle(monkeypatch, batch):
+    """BASELINE.json configs[1] on the 16-bit data path (bf16 activations / gradients / weight shadows in the blocked layout,
+    the gradient-penalty chain included) against the fp32 CPU oracle: five losses within 5e-2 and the post-Adam weights, at a
+    small batch and at the configuration's own batch of 128."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_mixed_precision_gpu import _step_against_fp32_oracle
+    import srgan_amd.age.srgan as age
+    from oracle import models as OM
+    monkeypatch.setattr(age, 'model_architecture', 'vgg')
+
+    def configure(experiment):
+        experiment.image_size = 64
+    _step_against_fp32_oracle(age.AgeExperiment, configure,
+                              lambda: (OM.DCGANGenerator(image_size=64), OM.VGG16(1, 64), OM.VGG16(1, 64)),
+                              size=64, batch=batch, d_scale=1.3,
+                              settings_overrides=dict(compute_dtype='bf16', gradient_penalty_dtype='bf16', storage_dtype='bf16'),
+                              tolerance=5e-2)
