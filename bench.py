@@ -61,14 +61,15 @@ WORKLOADS = {
                               'and weight shadows of D / DNN stored as bf16 in the blocked layout with fused activations (gradient-penalty '
                               'chain included), fp32 master weights / Adam / losses; the DCGAN generator on fp32 tensors with bf16 MFMA operands'),
     'driving-fp16': dict(application='driving', image_size=(64, 192), batch_per_gpu=128, gp_scale=3.0, dtype='f16',
-                         settings=dict(compute_dtype='f16', gradient_penalty_dtype='f32', loss_scale=256.0,
+                         settings=dict(compute_dtype='f16', gradient_penalty_dtype='f32', storage_dtype='f16', loss_scale=256.0,
                                        matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
                                        gradient_penalty_multiplier=1e2,
                                        # comm-sensitive under data parallelism: half the bytes per link,
                                        # S/N to every peer over all seven xGMI links instead of S around one ring
                                        gradient_wire_dtype='bf16', gradient_exchange_form='reduce_scatter'),
-                         name='driving SRGAN, DCGAN D/DNN/G on 64x192 frames (BASELINE.json configs[4]), fp16 MFMA operands with '
-                              'the gradient-penalty chain in fp32, static loss scale 256'),
+                         name='driving SRGAN, DCGAN D/DNN/G on 64x192 frames (BASELINE.json configs[4]), fp16: activations, gradients and '
+                              'weight shadows of the three networks stored as fp16 in the blocked layout with fused leaky_relu; the '
+                              'gradient-penalty chain in fp32 on fp32 tensors; fp32 master weights / Adam / losses; static loss scale 256'),
 }
 
 
@@ -152,6 +153,8 @@ def build_experiment(args, dp):
     settings.overlap_gradient_penalty = streams and not os.environ.get('SRGAN_NO_PENALTY_STREAM')
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
     settings.step_graph = bool(args.step_graph)
+    if args.step_graph and dp is not None:
+        settings.step_graph_collectives = 'abi'     # the opt-in: exchanges through the C ABI's own communicator, capturable
     if workload is not None:
         for key, value in workload['settings'].items():
             setattr(settings, key, value)
@@ -794,6 +797,7 @@ def main():
         print(json.dumps(result), flush=True)
     if dp is not None:
         dp.barrier()
+        experiment.close()                        # the C ABI's communicator, before the process group goes
         torch.distributed.destroy_process_group()
     return 0
 

@@ -442,6 +442,21 @@ int srgan_h_gemm(const void* a, const void* b, const float* bias, const void* re
 int srgan_h_linear_wgrad(const void* s, const void* x, float* gw, int32_t N, int32_t M, int32_t K, int64_t M_real, int64_t K_real,
                          int64_t ldw_m, int64_t ldw_k, int32_t row_plane, int32_t col_plane, int dtype, void* stream);
 
+/* 4x4 / stride 2 / pad 1 pair (the DCGAN stacks, reference age/models.py:37-51,61-73).  A weight tensor [A][B][4][4] in torch's
+ * layout -- conv2d weights [K][C][4][4]: A = K, B = C; conv_transpose2d weights [Cin][Cout][4][4]: A = Cin, B = Cout -- always
+ * has A = the channels of the tensor on the SMALL (H/2 x W/2) plane.  direction 0 "down" (big -> small plane, rows = A): conv2d's
+ * forward, conv_transpose2d's data gradient; direction 1 "up" (small -> big plane, rows = B, the four output parity classes):
+ * conv_transpose2d's forward, conv2d's data gradient.  epi as srgan_h_conv3x3. */
+int64_t srgan_h_k4s2_weight_slots(int32_t A, int32_t B, int direction);
+int srgan_h_pack_k4s2_weights(const float* w, void* packed, int32_t A, int32_t B, int direction, int dtype, void* stream);
+int srgan_h_conv4x4s2(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi, void* out,
+                      int32_t N, int32_t C_in, int32_t rows, int32_t H, int32_t W, int dtype, void* stream);
+int srgan_h_conv_transpose4x4s2(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi,
+                                void* out, int32_t N, int32_t C_in, int32_t rows, int32_t h, int32_t w, int dtype, void* stream);
+/* gw (fp32 [A][B][4][4]) += weight gradient from `small` [N, A, H/2, W/2] and `big` [N, B, H, W] (small_is_rows must be 1) */
+int srgan_h_k4s2_wgrad(const void* big, const void* small, float* gw, int32_t N, int32_t C_big, int32_t C_small, int32_t H, int32_t W,
+                       int small_is_rows, int dtype, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------
  * Between begin and end every contraction launch (conv / gemm passes) is bracketed by a pair of HIP events on
  * its launch stream; end() synchronises and returns the summed kernel time, the summed logical 2*M*N*K, the

@@ -10,6 +10,11 @@ batch_norm = False            # the reference's module-level switch (age/models.
 LEAK = 0.05
 
 
+def _blocked_stack_ok(network):
+    """The 16-bit path has the reference configuration: no batch-norm inside the stages (age/models.py:13)."""
+    return all(len(stage) == 1 for name, stage in network.named_children())
+
+
 def _pair(value):
     return (value, value) if isinstance(value, int) else tuple(value)
 
@@ -46,10 +51,21 @@ class Generator(nn.Module):
         self.input_size = z_dim
 
     def forward(self, z):
+        if F.STORAGE_DTYPE and z.meta is None and _blocked_stack_ok(self):
+            return self._forward_blocked(z, F.STORAGE_DTYPE)
         out = self.fc(F.view(z, (z.shape[0], z.shape[1], 1, 1)))
         for stage in (self.layer1, self.layer2, self.layer3):
             out = F.leaky_relu(stage(out), LEAK)
         return F.tanh(self.layer4(out))
+
+    def _forward_blocked(self, z, code):
+        """The same graph on the 16-bit data path (``blocked16``): the code and every feature map bf16 / fp16 in the blocked
+        layout, ``leaky_relu(convT(x))`` one kernel per stage, fp32 again for the images (tanh on the 3-channel result)."""
+        from .. import blocked16 as B
+        h = B.seed_conv_transpose(B.pack(F.view(z, (z.shape[0], z.shape[1])), code), self.fc[0])
+        for stage in (self.layer1, self.layer2, self.layer3):
+            h = B.conv_transpose4x4s2(h, stage[0], slope=LEAK)
+        return F.tanh(B.unpack(B.conv_transpose4x4s2(h, self.layer4[0])))
 
 
 class Discriminator(nn.Module):
@@ -67,9 +83,22 @@ class Discriminator(nn.Module):
         self.features = None
 
     def forward(self, x):
+        if F.STORAGE_DTYPE and x.meta is None and _blocked_stack_ok(self):
+            return self._forward_blocked(x, F.STORAGE_DTYPE)
         out = x
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             out = F.leaky_relu(stage(out), LEAK)
         self.features = F.flatten2d(out)
         scores = self.layer5(out)
+        return F.view(scores, (-1,) if self.number_of_outputs == 1 else (-1, self.number_of_outputs))
+
+    def _forward_blocked(self, x, code):
+        """The same graph on the 16-bit data path (``blocked16``): every ``leaky_relu(conv(x))`` stage one kernel on bf16 / fp16
+        tensors in the blocked layout; ``features`` (reference order: the NCHW flattening) and the scores leave as fp32."""
+        from .. import blocked16 as B
+        h = B.pack(x, code)
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            h = B.conv4x4s2(h, stage[0], slope=LEAK)
+        self.features = F.flatten2d(B.unpack(h))
+        scores = B.unpack(B.linear(B.flatten(h), self.layer5[0]))
         return F.view(scores, (-1,) if self.number_of_outputs == 1 else (-1, self.number_of_outputs))

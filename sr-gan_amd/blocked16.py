@@ -177,16 +177,11 @@ class Shadow:
 
     def __init__(self, module, kind, code, in_blocked=0, plane=1):
         self.module, self.kind, self.code, self.in_blocked, self.plane = module, kind, code, in_blocked, plane
-        self.forward = self.transposed = None
+        self.forward = self.transposed = self.down = self.up = self.bias_rows = None
         self.key = None
         arena = getattr(module.weight, '_srgan_arena', None)
         if arena is not None:
             arena.shadows.append(self)
-
-    def _version(self):
-        weight = self.module.weight
-        arena = getattr(weight, '_srgan_arena', None)
-        return (weight.data_ptr(), weight._version, None if arena is None else (arena.version, arena.data._version))
 
     def fresh(self):
         if self.key != self._version():
@@ -200,29 +195,56 @@ class Shadow:
     def repack(self):
         weight = self.module.weight
         lib, stream, device = _lib.library(), F._stream(), weight.device
+
+        def buffer(name, slots):
+            if getattr(self, name, None) is None:
+                setattr(self, name, torch.empty(slots * 4, dtype=torch.int32, device=device))
+            return getattr(self, name).data_ptr()
         if self.kind == 'conv3x3':
             k, c, r, s = weight.shape
             for name, transposed, rows, reduced in (('forward', 0, k, c), ('transposed', 1, c, k)):
-                slots = lib.srgan_h_conv_weight_slots(rows, reduced, r, s)
-                if getattr(self, name) is None:
-                    setattr(self, name, torch.empty(slots * 4, dtype=torch.int32, device=device))
-                _call('srgan_h_pack_conv_weights', weight.data_ptr(), getattr(self, name).data_ptr(), k, c, r, s, transposed,
-                      self.code, stream)
+                _call('srgan_h_pack_conv_weights', weight.data_ptr(), buffer(name, lib.srgan_h_conv_weight_slots(rows, reduced, r, s)),
+                      k, c, r, s, transposed, self.code, stream)
         elif self.kind == 'linear':
             outputs, inputs = weight.shape[0], weight.numel() // weight.shape[0]
             blocked = self.in_blocked or (inputs + 7) // 8 * 8
             outputs_padded = (outputs + 7) // 8 * 8
-            if self.forward is None:
-                self.forward = torch.empty(outputs * blocked // 2, dtype=torch.int32, device=device)
-                self.transposed = torch.empty(blocked * outputs_padded // 2, dtype=torch.int32, device=device)
             # forward operand A[o][f'] = W[o][map(f')]; transposed operand A[f'][o] = W[o][map(f')]
-            _call('srgan_h_pack_matrix', weight.data_ptr(), self.forward.data_ptr(), outputs, blocked, outputs, inputs, inputs, 1,
-                  1, self.plane, self.code, stream)
-            _call('srgan_h_pack_matrix', weight.data_ptr(), self.transposed.data_ptr(), blocked, outputs_padded, inputs, outputs, 1,
-                  inputs, self.plane, 1, self.code, stream)
+            _call('srgan_h_pack_matrix', weight.data_ptr(), buffer('forward', outputs * blocked // 8), outputs, blocked, outputs, inputs,
+                  inputs, 1, 1, self.plane, self.code, stream)
+            _call('srgan_h_pack_matrix', weight.data_ptr(), buffer('transposed', blocked * outputs_padded // 8), blocked, outputs_padded,
+                  inputs, outputs, 1, inputs, self.plane, 1, self.code, stream)
+        elif self.kind == 'k4s2':
+            # [A][B][4][4], A = the channels on the small plane: conv2d weights [K][C], conv_transpose2d weights [Cin][Cout]
+            a, b = weight.shape[0], weight.shape[1]
+            for name, direction in (('down', 0), ('up', 1)):
+                _call('srgan_h_pack_k4s2_weights', weight.data_ptr(), buffer(name, lib.srgan_h_k4s2_weight_slots(a, b, direction)), a, b,
+                      direction, self.code, stream)
+        elif self.kind == 'linear_t':
+            # conv_transpose2d weights [Cin][Cout][R][S] applied to a 1 x 1 input: a linear map Cin -> (Cout, R x S); its outputs
+            # in the blocked order of a [Cout, R, S] tensor (plane = R * S)
+            c_in, c_out = weight.shape[0], weight.shape[1]
+            plane = weight.shape[2] * weight.shape[3]
+            blocked, c_in_padded = (c_out + 7) // 8 * 8 * plane, (c_in + 7) // 8 * 8
+            _call('srgan_h_pack_matrix', weight.data_ptr(), buffer('forward', blocked * c_in_padded // 8), blocked, c_in_padded,
+                  c_out * plane, c_in, 1, c_out * plane, plane, 1, self.code, stream)
+            _call('srgan_h_pack_matrix', weight.data_ptr(), buffer('transposed', c_in * blocked // 8), c_in, blocked, c_in,
+                  c_out * plane, c_out * plane, 1, 1, plane, self.code, stream)
+            if self.module.bias is not None:       # bias[co] of every output row (co, pixel), in the blocked order (a copy, no arithmetic)
+                groups = (c_out + 7) // 8
+                padded = torch.zeros(groups * 8, dtype=torch.float32, device=device)
+                padded[:c_out] = self.module.bias.data
+                self.bias_rows = padded.view(groups, 1, 8).expand(groups, plane, 8).reshape(-1).contiguous()
         else:
             raise ValueError(self.kind)
         self.key = self._version()
+
+    def _version(self):
+        weight = self.module.weight
+        arena = getattr(weight, '_srgan_arena', None)
+        bias = getattr(self.module, 'bias', None)
+        return (weight.data_ptr(), weight._version, None if bias is None else bias._version,
+                None if arena is None else (arena.version, arena.data._version))
 
 
 def shadow_of(module, kind, code, in_blocked=0, plane=1):
@@ -267,40 +289,107 @@ def linear(x, module, slope=None):
     return _layer(x, module, shadow, False, 1, 1.0 if slope is None else float(slope), None, True)
 
 
-def _layer(x, module, shadow, transposed, epi, slope, ref, use_bias):
-    """One contraction launch ``epi(op(x, W) [+ b])`` recorded on the tape.  transposed: the data-gradient direction (x has
-    the layer's OUTPUT features).  epi 1: bias + leaky(slope); epi 2: times mask(ref, slope); epi 0: plain."""
-    meta, code = x.meta, x.meta.code
-    weight = _parameter(module.weight)
-    bias = _parameter(module.bias) if (use_bias and module.bias is not None) else None
-    stream = F._stream()
+def conv4x4s2(x, module, slope=None):
+    """``act(conv2d(x, w, b, stride 2, padding 1))`` for a 4x4 ``nn.Conv2d`` (the DCGAN discriminator's stages, reference
+    age/models.py:61-73: ``leaky_relu(layer(x), 0.05)``)."""
+    if tuple(module.kernel_size) != (4, 4) or tuple(module.stride) != (2, 2) or tuple(module.padding) != (1, 1):
+        raise ValueError('blocked16.conv4x4s2: 4x4 / stride 2 / padding 1 convolutions')
+    return _layer(x, module, shadow_of(module, 'k4s2', x.meta.code), False, 1, 1.0 if slope is None else float(slope), None, True)
+
+
+def conv_transpose4x4s2(x, module, slope=None):
+    """``act(conv_transpose2d(x, w, b, stride 2, padding 1))`` for a 4x4 ``nn.ConvTranspose2d`` (the DCGAN generator's stages,
+    reference age/models.py:37-51)."""
+    if tuple(module.kernel_size) != (4, 4) or tuple(module.stride) != (2, 2) or tuple(module.padding) != (1, 1) or \
+            tuple(module.output_padding) != (0, 0):
+        raise ValueError('blocked16.conv_transpose4x4s2: 4x4 / stride 2 / padding 1 transposed convolutions')
+    return _layer(x, module, shadow_of(module, 'k4s2', x.meta.code), False, 1, 1.0 if slope is None else float(slope), None, True)
+
+
+def seed_conv_transpose(x, module, slope=None):
+    """``conv_transpose2d`` of a [N, Cin] code (a 1 x 1 plane) with a full-plane kernel, stride 1, no padding (the generator's
+    ``fc``, reference age/models.py:37,47): a linear map onto a [N, Cout, R, S] tensor."""
+    if tuple(module.stride) != (1, 1) or tuple(module.padding) != (0, 0) or x.meta.h != 1 or x.meta.w != 1 or x.meta.plane != 1:
+        raise ValueError('blocked16.seed_conv_transpose: a stride-1 unpadded transposed convolution of a 1 x 1 plane')
+    return _layer(x, module, shadow_of(module, 'linear_t', x.meta.code), False, 1, 1.0 if slope is None else float(slope), None, True)
+
+
+def _is_transpose(module):
+    return isinstance(module, torch.nn.ConvTranspose2d)
+
+
+def _launch(x, module, shadow, transposed, epi, slope, ref, bias):
+    """The contraction launch of ``_layer``: returns (output tensor, its Blocked)."""
+    meta, code, stream, device = x.meta, x.meta.code, F._stream(), x.data.device
+    bias_ptr = None if bias is None else bias.data.data_ptr()
     if shadow.kind == 'conv3x3':
         k, c = module.weight.shape[0], module.weight.shape[1]
         c_in, c_out = (k, c) if transposed else (c, k)
         if meta.c != c_in:
             raise ValueError(f'blocked16 conv: input has {meta.c} channels, the layer expects {c_in}')
-        data = _new(meta.n, c_out, meta.h, meta.w, code, x.data.device)
+        data = _new(meta.n, c_out, meta.h, meta.w, code, device)
         operand = shadow.transposed if transposed else shadow.forward
-        _call('srgan_h_conv3x3', x.data.data_ptr(), operand.data_ptr(), _ptr(None if bias is None else bias.data), _ptr(ref),
-              float(slope), epi, data.data_ptr(), meta.n, c_in, c_out, c_out, meta.h, meta.w, code, stream)
-        out_meta = Blocked(meta.n, c_out, meta.h, meta.w, code)
-    else:
-        outputs, inputs = module.weight.shape[0], module.weight.numel() // module.weight.shape[0]
-        blocked = shadow.in_blocked or (inputs + 7) // 8 * 8
-        if transposed:
-            if meta.c != outputs:
-                raise ValueError(f'blocked16 linear (data gradient): input has {meta.c} features, expected {outputs}')
-            data = _new(meta.n, blocked, 1, 1, code, x.data.device)
-            _call('srgan_h_gemm', shadow.transposed.data_ptr(), x.data.data_ptr(), None, _ptr(ref), float(slope), epi,
-                  data.data_ptr(), blocked, meta.n, outputs, blocked, 0, code, stream)
-            out_meta = Blocked(meta.n, blocked, 1, 1, code, plane=shadow.plane, real=inputs)
-        else:
-            if meta.c != blocked:
-                raise ValueError(f'blocked16 linear: input has {meta.c} (blocked) features, the shadow was built for {blocked}')
-            data = _new(meta.n, outputs, 1, 1, code, x.data.device)
-            _call('srgan_h_gemm', shadow.forward.data_ptr(), x.data.data_ptr(), _ptr(None if bias is None else bias.data), _ptr(ref),
-                  float(slope), epi, data.data_ptr(), outputs, meta.n, blocked, outputs, outputs, code, stream)
-            out_meta = Blocked(meta.n, outputs, 1, 1, code)
+        _call('srgan_h_conv3x3', x.data.data_ptr(), operand.data_ptr(), bias_ptr, _ptr(ref), float(slope), epi, data.data_ptr(),
+              meta.n, c_in, c_out, c_out, meta.h, meta.w, code, stream)
+        return data, Blocked(meta.n, c_out, meta.h, meta.w, code)
+    if shadow.kind == 'k4s2':
+        a, b = module.weight.shape[0], module.weight.shape[1]
+        up = _is_transpose(module) != transposed              # small -> big plane
+        if up:
+            if meta.c != a:
+                raise ValueError(f'blocked16 transposed 4x4 / s2: input has {meta.c} channels, expected {a}')
+            data = _new(meta.n, b, 2 * meta.h, 2 * meta.w, code, device)
+            _call('srgan_h_conv_transpose4x4s2', x.data.data_ptr(), shadow.up.data_ptr(), bias_ptr, _ptr(ref), float(slope), epi,
+                  data.data_ptr(), meta.n, a, b, meta.h, meta.w, code, stream)
+            return data, Blocked(meta.n, b, 2 * meta.h, 2 * meta.w, code)
+        if meta.c != b or meta.h % 2 or meta.w % 2:
+            raise ValueError(f'blocked16 4x4 / s2: input [{meta.c}, {meta.h}, {meta.w}], expected {b} channels on an even plane')
+        data = _new(meta.n, a, meta.h // 2, meta.w // 2, code, device)
+        _call('srgan_h_conv4x4s2', x.data.data_ptr(), shadow.down.data_ptr(), bias_ptr, _ptr(ref), float(slope), epi,
+              data.data_ptr(), meta.n, b, a, meta.h, meta.w, code, stream)
+        return data, Blocked(meta.n, a, meta.h // 2, meta.w // 2, code)
+    if shadow.kind == 'linear_t':
+        c_in, c_out, r, s_ = module.weight.shape
+        plane = r * s_
+        blocked = (c_out + 7) // 8 * 8 * plane
+        if transposed:                                         # [N, Cout, R, S] -> [N, Cin]
+            if (meta.c, meta.h, meta.w) != (c_out, r, s_):
+                raise ValueError('blocked16 seed transposed convolution (data gradient): unexpected input shape')
+            data = _new(meta.n, c_in, 1, 1, code, device)
+            _call('srgan_h_gemm', shadow.transposed.data_ptr(), x.data.data_ptr(), None, _ptr(ref), float(slope), epi, data.data_ptr(),
+                  c_in, meta.n, blocked, c_in, 0, code, stream)
+            return data, Blocked(meta.n, c_in, 1, 1, code)
+        if meta.c != c_in:
+            raise ValueError(f'blocked16 seed transposed convolution: input has {meta.c} features, expected {c_in}')
+        data = _new(meta.n, c_out, r, s_, code, device)
+        rows = None if (bias is None or shadow.bias_rows is None) else shadow.bias_rows.data_ptr()
+        _call('srgan_h_gemm', shadow.forward.data_ptr(), x.data.data_ptr(), rows, _ptr(ref), float(slope), epi, data.data_ptr(),
+              blocked, meta.n, (c_in + 7) // 8 * 8, blocked, blocked, code, stream)
+        return data, Blocked(meta.n, c_out, r, s_, code)
+    outputs, inputs = module.weight.shape[0], module.weight.numel() // module.weight.shape[0]
+    blocked = shadow.in_blocked or (inputs + 7) // 8 * 8
+    if transposed:
+        if meta.c != outputs:
+            raise ValueError(f'blocked16 linear (data gradient): input has {meta.c} features, expected {outputs}')
+        data = _new(meta.n, blocked, 1, 1, code, device)
+        _call('srgan_h_gemm', shadow.transposed.data_ptr(), x.data.data_ptr(), None, _ptr(ref), float(slope), epi, data.data_ptr(),
+              blocked, meta.n, outputs, blocked, 0, code, stream)
+        return data, Blocked(meta.n, blocked, 1, 1, code, plane=shadow.plane, real=inputs)
+    if meta.c != blocked:
+        raise ValueError(f'blocked16 linear: input has {meta.c} (blocked) features, the shadow was built for {blocked}')
+    data = _new(meta.n, outputs, 1, 1, code, device)
+    _call('srgan_h_gemm', shadow.forward.data_ptr(), x.data.data_ptr(), bias_ptr, _ptr(ref), float(slope), epi, data.data_ptr(),
+          outputs, meta.n, blocked, outputs, outputs, code, stream)
+    return data, Blocked(meta.n, outputs, 1, 1, code)
+
+
+def _layer(x, module, shadow, transposed, epi, slope, ref, use_bias):
+    """One contraction ``epi(op(x, W) [+ b])`` recorded on the tape.  transposed: the data-gradient direction (x has the
+    layer's OUTPUT features).  epi 1: bias + leaky(slope); epi 2: times mask(ref, slope); epi 0: plain."""
+    meta = x.meta
+    weight = _parameter(module.weight)
+    bias = _parameter(module.bias) if (use_bias and module.bias is not None) else None
+    data, out_meta = _launch(x, module, shadow, transposed, epi, slope, ref, bias)
     if epi == 1 and slope != 1.0:
         out_meta.mask_ref, out_meta.slope = data, slope            # an activated tensor is its own mask
     elif epi == 2:
@@ -332,13 +421,25 @@ def _layer(x, module, shadow, transposed, epi, slope, ref, use_bias):
 
 
 def _weight_gradient(shadow, module, x_side, y_side, into):
-    """into (fp32, the arena's gradient view of the layer's weight) += d loss / d W from the layer's input-side tensor and
-    the (pre-masked) gradient at its output side."""
+    """into (fp32, the arena's gradient view of the layer's weight) += d loss / d W from the tensor at the layer's input side
+    and the (pre-masked) gradient at its output side."""
     xm, ym = x_side.meta, y_side.meta
+    stream = F._stream()
     if shadow.kind == 'conv3x3':
         _call('srgan_h_conv3x3_wgrad', x_side.data.data_ptr(), y_side.data.data_ptr(), into.data_ptr(), xm.n, xm.c, ym.c, xm.h,
-              xm.w, xm.code, F._stream())
+              xm.w, xm.code, stream)
+    elif shadow.kind == 'k4s2':
+        # conv2d: input side = the big plane; conv_transpose2d: input side = the small plane
+        big, small = (y_side, x_side) if _is_transpose(module) else (x_side, y_side)
+        _call('srgan_h_k4s2_wgrad', big.data.data_ptr(), small.data.data_ptr(), into.data_ptr(), big.meta.n, big.meta.c, small.meta.c,
+              big.meta.h, big.meta.w, 1, xm.code, stream)
+    elif shadow.kind == 'linear_t':
+        c_in, c_out, r, s_ = module.weight.shape
+        plane = r * s_
+        blocked = (c_out + 7) // 8 * 8 * plane
+        _call('srgan_h_linear_wgrad', y_side.data.data_ptr(), x_side.data.data_ptr(), into.data_ptr(), xm.n, blocked, xm.c,
+              c_out * plane, c_in, 1, c_out * plane, plane, 1, xm.code, stream)
     else:
         outputs, inputs = module.weight.shape[0], module.weight.numel() // module.weight.shape[0]
         _call('srgan_h_linear_wgrad', y_side.data.data_ptr(), x_side.data.data_ptr(), into.data_ptr(), xm.n, outputs, xm.c,
-              outputs, inputs, inputs, 1, 1, shadow.plane, xm.code, F._stream())
+              outputs, inputs, inputs, 1, 1, shadow.plane, xm.code, stream)

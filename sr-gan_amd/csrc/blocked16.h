@@ -87,6 +87,20 @@ __device__ __forceinline__ f32x16 h_mfma(const Slot& a, const Slot& b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h_f16x8, a), __builtin_bit_cast(h_f16x8, b), c, 0, 0, 0);
 }
 
+// LDS-DMA: 64 lanes x 16 bytes from PER-LANE global addresses to LDS at the wave-uniform byte address `lds_dst` + lane * 16
+// (global_load_lds_dwordx4; M0 carries the LDS base and is compiler-reserved: saved and restored inside the statement).
+__device__ __forceinline__ void h_glds16(const void* lane_pointer, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_pointer), "s"(lds_dst) : "memory");
+}
+// This wave's DMAs down to the N youngest have landed and its LDS reads are done; then the workgroup barrier (raw: a
+// __syncthreads() would drain the whole DMA queue).
+template <int N> __device__ __forceinline__ void h_dma_wait_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+const struct Slot* h_zero_slots();      // 64 bytes of zeros in device memory (blocked16.hip): the source of padding slots
+
 // Declared in gather_gemm_kernels.hip: the bench's live event bracket around a contraction launch, with explicit bytes.
 int profile_bracket_begin(hipStream_t stream);
 int profile_bracket_end_bytes(int slot, hipStream_t stream, int64_t M, int64_t N, int64_t K, int kind, int bm, int bn, int split,

@@ -448,15 +448,7 @@ __global__ __launch_bounds__(256, 2) void hconv3x3_kernel(const HConv3Params p) 
 // L = TP / 4, so `s_waitcnt vmcnt(L * chunks left in flight)` is exact; one raw s_barrier per chunk (a __syncthreads() would
 // drain the DMA queue).  No K split (the small layers keep the register-staged kernel).
 __device__ Slot g_h_zero_slots[4];
-
-__device__ __forceinline__ void h_glds16(const void* lane_pointer, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(lane_pointer), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void h_dma_wait_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
-}
+const Slot* h_zero_slots() { return reinterpret_cast<const Slot*>(device_tickets(g_h_zero_slots)); }
 
 template <int BM, int NI, int TW, int ROWS, int PREC, int RING>
 __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void hconv3x3_dma_kernel(const HConv3Params p, const Slot* zero) {
@@ -1021,7 +1013,7 @@ int srgan_h_conv3x3(const void* x, const void* packed, const float* bias, const 
   static const int ring_env = getenv("SRGAN_H_DMA_RING") ? atoi(getenv("SRGAN_H_DMA_RING")) : -1;
   const int ring = ring_env >= 0 ? ring_env : 2;
   const Slot* zero = (ring == 2 || ring == 3) && split == 1 && plan.bm == 64
-                         ? reinterpret_cast<const Slot*>(device_tickets(g_h_zero_slots)) : nullptr;
+                         ? h_zero_slots() : nullptr;
   const int slot = profile_bracket_begin(stream);
   if (zero) {
     int launched;

@@ -556,16 +556,19 @@ constexpr size_t WORKSPACE_BYTES = (size_t)256 << 20;     // (round 5: 256 MiB -
 struct WorkspaceSlot { float* ptr = nullptr; size_t bytes = 0; int index = -1; };
 static std::mutex g_workspace_mutex;
 static std::map<std::pair<int, hipStream_t>, WorkspaceSlot> g_workspaces;
-static int g_workspace_count = 0;
+static int g_workspace_count[16] = {};        // ticket sets handed out, per device (the ticket arrays are per-device symbols)
 
+// Unregistering (ptr == NULL) keeps the slot and its ticket-set index: a stream that registers again -- a caller that tears its
+// workspace down between phases -- gets the SAME set back, so the 64 sets per device are not used up by re-registration (ADVICE
+// r5: the index used to be re-drawn, and past 64 the ordered finish silently fell back to fp32 atomics).  A stream beyond the
+// 64th of a device has index >= SPLIT_TICKET_SETS and srgan_split_is_ordered() reports 0 for it.
 int workspace_register(float* ptr, size_t bytes, hipStream_t stream) {
   int device = 0;
   SRGAN_HIP(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(g_workspace_mutex);
-  if (ptr == nullptr) { g_workspaces.erase({device, stream}); return SRGAN_OK; }
   WorkspaceSlot& slot = g_workspaces[{device, stream}];
-  slot.ptr = ptr; slot.bytes = bytes;
-  if (slot.index < 0) slot.index = g_workspace_count++;      // (never reused: a re-registered stream keeps its id)
+  slot.ptr = ptr; slot.bytes = ptr ? bytes : 0;
+  if (slot.index < 0 && ptr != nullptr) slot.index = g_workspace_count[device & 15]++;
   return SRGAN_OK;
 }
 
@@ -576,7 +579,7 @@ int workspace_index(hipStream_t stream) {
   if (hipGetDevice(&device) != hipSuccess) return -1;
   std::lock_guard<std::mutex> lock(g_workspace_mutex);
   auto found = g_workspaces.find({device, stream});
-  return found == g_workspaces.end() ? -1 : found->second.index;
+  return (found == g_workspaces.end() || found->second.ptr == nullptr) ? -1 : found->second.index;
 }
 
 size_t workspace_capacity() { return WORKSPACE_BYTES; }
@@ -586,7 +589,7 @@ float* partial_workspace(size_t bytes, hipStream_t stream) {
   if (hipGetDevice(&device) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(g_workspace_mutex);
   auto found = g_workspaces.find({device, stream});
-  if (found == g_workspaces.end() || found->second.bytes < bytes) return nullptr;
+  if (found == g_workspaces.end() || found->second.ptr == nullptr || found->second.bytes < bytes) return nullptr;
   return found->second.ptr;
 }
 

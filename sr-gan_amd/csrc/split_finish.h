@@ -16,10 +16,13 @@
 // stores (global_store_dword ... sc1: write-through) and read with agent-scope relaxed atomic loads (sc1); store and ticket
 // live in different L2 channels, so the ticket's fetch_add must not be ISSUED before the stores are acknowledged:
 // s_waitcnt vmcnt(0) in every thread, then the workgroup barrier, then thread 0 takes the ticket (ADVICE r4 on reduce.hip:
-// a workgroup-scope release fence emits no instruction).  The tickets are device globals, one array per translation unit
+// a workgroup-scope release fence emits no instruction).  The tickets are device globals, one array per kernel family
 // and one row per registered (device, stream) workspace -- launches on one stream are ordered, streams do not share a row --
 // and the last workgroup puts its tile's ticket back to zero.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 namespace srgan {
@@ -103,18 +106,23 @@ constexpr int ROW_FINISH_ROWS = 4096;       // output rows (channels / examples)
 float* partial_workspace(size_t bytes, hipStream_t stream);
 int workspace_index(hipStream_t stream);
 
-// The device address of a translation unit's ticket array (per device: the symbol has one copy on each).
+// The device address of a ticket array (per device: the symbol has one copy on each).  The cache is keyed by the SYMBOL'S
+// ADDRESS, not by its type: several translation units declare arrays of one type (unsigned[64 * 2048]), and a cache per template
+// instantiation handed whichever array was resolved first to all of them (benign while launches on a stream are
+// ordered, wrong as a statement).  Guarded by a mutex: host threads may launch for the first time together.
 template <typename Symbol>
 inline unsigned int* device_tickets(const Symbol& symbol) {
-  static unsigned int* cached[16] = {};
+  static std::mutex guard;
+  static std::map<std::pair<const void*, int>, unsigned int*> cache;
   int device = 0;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return nullptr;
-  if (!cached[device]) {
-    void* address = nullptr;
-    if (hipGetSymbolAddress(&address, HIP_SYMBOL(symbol)) != hipSuccess) return nullptr;
-    cached[device] = static_cast<unsigned int*>(address);
-  }
-  return cached[device];
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(guard);
+  const std::pair<const void*, int> key{static_cast<const void*>(&symbol), device};
+  auto found = cache.find(key);
+  if (found != cache.end()) return found->second;
+  void* address = nullptr;
+  if (hipGetSymbolAddress(&address, HIP_SYMBOL(symbol)) != hipSuccess) return nullptr;
+  return cache[key] = static_cast<unsigned int*>(address);
 }
 
 inline bool split_atomics_forced() {

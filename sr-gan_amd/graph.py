@@ -124,6 +124,10 @@ class CapturedIteration:
         for name, value in host.items():
             record['draws'][name].copy_(value, non_blocking=True)
         self.order_side_streams()
+        # An eager iteration in between (a summary step, a warm-up) may have left an optimizer update waiting for its
+        # gradient exchange (``_pending_updates``); the captured ``finish_update`` was a no-op when it was recorded, so it is
+        # settled here, before the replay overwrites those gradients.
+        e.finish_update()
         record['graph'].replay()
         for optimizer, advanced in zip(self.optimizers(), record['advanced']):
             optimizer.step_count += advanced

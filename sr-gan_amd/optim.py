@@ -34,7 +34,7 @@ class Adam:
     def step(self):
         group = self.param_groups[0]
         self.step_count += 1
-        self.arena.version += 1
+        self.arena.version = getattr(self.arena, 'version', 0) + 1      # (raw-pointer update: torch's version counters do not see it)
         if self.device_state is not None:
             _lib.check(_lib.library().srgan_adam_step_counted(
                 self.arena.data.data_ptr(), self.arena.grad.data_ptr(), self.exp_avg.data_ptr(),
@@ -46,7 +46,7 @@ class Adam:
                 self.arena.data.data_ptr(), self.arena.grad.data_ptr(), self.exp_avg.data_ptr(),
                 self.exp_avg_sq.data_ptr(), self.arena.numel, group['lr'], group['betas'][0], group['betas'][1],
                 group['eps'], group['weight_decay'], self.step_count, F._stream()), 'srgan_adam_step')
-        if self.arena.shadows:          # the 16-bit operand forms of these weights, on the update's own stream
+        if getattr(self.arena, 'shadows', None):          # the 16-bit operand forms of these weights, on the update's own stream
             from . import blocked16
             blocked16.refresh(self.arena)
 

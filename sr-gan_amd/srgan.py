@@ -196,6 +196,7 @@ class Experiment(ABC):
         print('Completed {}'.format(self.trial_directory))
         if settings.should_save_models:
             self.save_models(step=settings.steps_to_run)
+        self.close()
 
     # (network attribute, optimizer attribute): also the keys of the checkpoint dictionary (reference srgan.py:88-97)
     CHECKPOINT_PARTS = (('DNN', 'dnn_optimizer'), ('D', 'd_optimizer'), ('G', 'g_optimizer'))
@@ -251,7 +252,8 @@ class Experiment(ABC):
         """The body of the reference's loop (srgan.py:104-118): the DNN step, then the GAN step.  With
         ``settings.step_graph`` on a single device the iteration is captured once as a HIP graph and replayed
         (``graph.CapturedIteration``); summary steps and the first ``settings.step_graph_warmup`` iterations run eagerly."""
-        if getattr(self.settings, 'step_graph', False) and examples_on_gpu() and self._exchanges_are_capturable():
+        if getattr(self.settings, 'step_graph', False) and examples_on_gpu() and not getattr(self.settings, 'storage_dtype', None) \
+                and self._exchanges_are_capturable():
             if getattr(self, '_captured_iteration', None) is None:
                 from .graph import CapturedIteration
                 self._captured_iteration = CapturedIteration(self)
@@ -259,29 +261,47 @@ class Experiment(ABC):
         self.dnn_training_step(labeled_examples, labels, step)
         self.gan_training_step(labeled_examples, labels, unlabeled_examples, step)
 
+    def _stream_setting(self, name):
+        """A side-stream switch of ``settings`` as THIS iteration sees it: off while the iteration is captured / replayed as a
+        HIP graph under data parallelism (``_single_compute_stream``), without touching ``settings`` itself."""
+        if getattr(self, '_single_compute_stream', False):
+            return False
+        return getattr(self.settings, name, False)
+
     def _exchanges_are_capturable(self):
-        """A HIP graph can hold the data-parallel exchanges only as launches on streams this process owns: the C ABI's RCCL
-        entry points on the communicator's stream (``DataParallel.use_abi_collectives``; round 5).  Collectives that go
-        through a host-side process group (gloo, or torch's own NCCL work queue) keep the run eager."""
+        """True when this run's iterations can be captured as HIP graphs.  Single device: always.  Data parallel: only when the
+        caller OPTED IN with ``settings.step_graph_collectives = 'abi'`` -- the exchanges then run through the C ABI's RCCL entry
+        points on a stream this process owns (``DataParallel.use_abi_collectives``; a second communicator next to torch's,
+        destroyed by ``close()``) and are captured with the iteration; collectives that go through a host-side process group
+        (gloo, torch's own NCCL work queue) keep the run eager.  No setting is modified: the compute side streams are switched
+        off for such a run through ``_stream_setting`` (hipStreamEndCapture crashes -- ROCm 7.0 runtime, a segmentation fault
+        inside capture_end, round 5 -- when a capture holds the compute side streams AND the communication stream)."""
         if not self.parallel:
             return True
-        if getattr(self.dp, 'abi', None) is None and torch.distributed.get_backend(self.dp.group) == 'nccl' and \
-                getattr(self.settings, 'step_graph_collectives', 'abi') == 'abi':
+        if getattr(self.settings, 'step_graph_collectives', None) != 'abi':
+            if not getattr(self, '_graph_note', False):
+                print('[srgan_amd] step_graph under data parallelism needs settings.step_graph_collectives = "abi" '
+                      '(the C ABI\'s RCCL entry points); running eagerly')
+                self._graph_note = True
+            return False
+        if getattr(self.dp, 'abi', None) is None and torch.distributed.get_backend(self.dp.group) == 'nccl':
             self.dp.use_abi_collectives()
         if getattr(self.dp, 'abi', None) is None:
             return False
-        # hipStreamEndCapture crashes (ROCm 7.0 runtime, measured round 5: a segmentation fault inside capture_end) when the
-        # capture holds the compute side streams AND the communication stream joined from several of them; one compute
-        # stream + the communication stream captures and replays correctly (tests/test_round5_gpu.py).  A data-parallel run
-        # that asks for the step graph therefore runs its chains on one stream.
-        for name in ('overlap_dnn_step', 'overlap_gradient_penalty', 'overlap_generator_forwards', 'wgrad_stream'):
-            if getattr(self.settings, name, False):
-                if not getattr(self, '_graph_streams_note', False):
-                    print('[srgan_amd] step_graph under data parallelism: side streams off (one compute stream + RCCL\'s)')
-                    self._graph_streams_note = True
-                self.join_dnn_stream()
-                setattr(self.settings, name, False)
+        if not getattr(self, '_single_compute_stream', False):
+            self.join_dnn_stream()                  # an eager iteration may have left work on a side stream
+            self._single_compute_stream = True
+            print('[srgan_amd] step_graph under data parallelism: one compute stream + RCCL\'s (side streams off for this run)')
         return True
+
+    def close(self):
+        """Releases what the experiment created outside torch: the C ABI's RCCL communicator (before the process group goes)."""
+        self.join_dnn_stream()
+        abi = getattr(self.dp, 'abi', None) if self.dp is not None else None
+        if abi is not None:
+            torch.cuda.synchronize()
+            abi.close()
+            self.dp.abi = None
 
     def prepare_optimizers(self):
         """Adam for D (with coupled L2), G and DNN (reference srgan.py:131-138) on the flat arenas."""
@@ -487,7 +507,7 @@ class Experiment(ABC):
             self._dnn_training_step(examples, labels, step)
 
     def _dnn_side_stream(self):
-        if not getattr(self.settings, 'overlap_dnn_step', False) or not examples_on_gpu():
+        if not self._stream_setting('overlap_dnn_step') or not examples_on_gpu():
             return None
         if getattr(self, '_dnn_stream', None) is None:
             self._dnn_stream = torch.cuda.Stream()
@@ -495,7 +515,7 @@ class Experiment(ABC):
 
     def _auxiliary_stream(self):
         """A second stream for forward passes that nothing differentiates (``settings.overlap_generator_forwards``)."""
-        if not getattr(self.settings, 'overlap_generator_forwards', False) or not examples_on_gpu() or self.parallel:
+        if not self._stream_setting('overlap_generator_forwards') or not examples_on_gpu() or self.parallel:
             # (under data parallelism the chains run on THREE streams -- main, gradient penalty, DNN step -- so that RCCL's
             # communication stream gets the fourth hardware queue of the HIP runtime to itself: a fifth stream aliases onto a
             # queue and couples two chains, DESIGN.md §1)
@@ -511,7 +531,7 @@ class Experiment(ABC):
         backward and the backward through the forward graph (reference srgan.py:294-295) are a chain of batch-sized kernels
         that depends on nothing of the stacked pass over [x, u, fake] (srgan.py:279-292) but the generated images -- the two
         chains run next to each other, each into its own gradient buffer of D's arena."""
-        if not getattr(self.settings, 'overlap_gradient_penalty', False) or not examples_on_gpu() or \
+        if not self._stream_setting('overlap_gradient_penalty') or not examples_on_gpu() or \
                 getattr(self.D, '_srgan_arena', None) is None:
             return None
         if getattr(self, '_gp_stream', None) is None:
@@ -540,6 +560,8 @@ class Experiment(ABC):
     def _apply_stream_settings(self):
         """``settings.wgrad_stream`` (None: leave the module default / SRGAN_WGRAD_STREAM) -> ``fused.WGRAD_STREAM``."""
         wanted = getattr(self.settings, 'wgrad_stream', None)
+        if getattr(self, '_single_compute_stream', False):
+            wanted = False
         if wanted is not None:
             from . import fused
             fused.WGRAD_STREAM = bool(wanted)

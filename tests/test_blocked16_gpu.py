@@ -312,3 +312,150 @@ def test_age_vgg_step_on_bf16_storage_against_the_fp32_oracle(monkeypatch, batch
                               size=64, batch=batch, d_scale=1.3,
                               settings_overrides=dict(compute_dtype='bf16', gradient_penalty_dtype='bf16', storage_dtype='bf16'),
                               tolerance=5e-2)
+
+
+# (n, small-plane channels A, big-plane channels B, big plane H x W): the DCGAN stages on driving frames (64 x 192 down to 4 x 12) and
+# on square images, channel tails, a ragged small plane (6 x 10), three big-plane channels (the images)
+K4S2 = [(2, 64, 3, 64, 192), (3, 128, 64, 32, 96), (5, 72, 40, 16, 48), (9, 136, 24, 8, 24), (4, 24, 20, 12, 20), (6, 64, 3, 32, 32),
+        (33, 40, 16, 8, 8), (130, 32, 8, 4, 4)]
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('case', K4S2)
+def test_4x4_stride_2_family_is_exact_on_integers(F, B, mode, case):
+    """conv2d / conv_transpose2d 4x4 / s2 / p1 (reference age/models.py:37-51,61-73): forward with the fused bias + leaky
+    epilogue, both data gradients with the mask epilogue, the weight gradient -- against the fp32 kernels, bit for bit."""
+    n, a, b, h, w = case
+    code = B.CODES[mode]
+    conv = torch.nn.Conv2d(b, a, 4, 2, 1).cuda()
+    deconv = torch.nn.ConvTranspose2d(a, b, 4, 2, 1).cuda()
+    with torch.no_grad():
+        for layer in (conv, deconv):
+            layer.weight.copy_(integers(tuple(layer.weight.shape), -1, 1, 1))
+            layer.bias.copy_(integers(tuple(layer.bias.shape), -3, 3, 2))
+    big = integers((n, b, h, w), -2, 2, 3)
+    small = integers((n, a, h // 2, w // 2), -2, 2, 4)
+    leaky = lambda t, slope: torch.where(t > 0, t, t * slope)
+    from srgan_amd.tape import no_grad
+    with no_grad():
+        bigb, smallb = blocked(F, B, big, mode), blocked(F, B, small, mode)
+        # strided convolution: forward, its data gradient (masked), its weight gradient
+        want = F.conv2d(F.leaf(big), F.leaf(conv.weight.data), F.leaf(conv.bias.data), 2, 1).data
+        assert torch.equal(nchw(B, B.conv4x4s2(bigb, conv, slope=0.25)), rounded(leaky(want, 0.25), mode))
+        assert torch.equal(nchw(B, B.conv4x4s2(bigb, conv)), rounded(want, mode))
+        shadow = B.shadow_of(conv, 'k4s2', code)
+        ref = integers((n, b, h, w), -1, 1, 5)
+        refb = blocked(F, B, ref, mode)
+        want = F.conv2d_backward_data(F.leaf(small), F.leaf(conv.weight.data), (n, b, h, w), (2, 2), (1, 1)).data
+        assert torch.equal(nchw(B, B._layer(smallb, conv, shadow, True, 2, 0.5, refb.data, False)), rounded(want * torch.where(ref > 0, 1.0, 0.5), mode))
+        into = torch.full_like(conv.weight.data, 5.0)
+        B._weight_gradient(shadow, conv, bigb, smallb, into)
+        assert torch.equal(into, F.conv2d_backward_weight(F.leaf(big), F.leaf(small), tuple(conv.weight.shape), (2, 2), (1, 1)).data + 5.0)
+        # transposed convolution: forward, its data gradient (masked), its weight gradient
+        want = F.conv_transpose2d(F.leaf(small), F.leaf(deconv.weight.data), F.leaf(deconv.bias.data), 2, 1).data
+        assert torch.equal(nchw(B, B.conv_transpose4x4s2(smallb, deconv, slope=0.25)), rounded(leaky(want, 0.25), mode))
+        shadow_t = B.shadow_of(deconv, 'k4s2', code)
+        ref_small = integers((n, a, h // 2, w // 2), -1, 1, 6)
+        want = F.conv2d(F.leaf(big), F.leaf(deconv.weight.data), None, 2, 1).data          # d convT / d input = the strided conv
+        got = nchw(B, B._layer(bigb, deconv, shadow_t, True, 2, 0.5, blocked(F, B, ref_small, mode).data, False))
+        assert torch.equal(got, rounded(want * torch.where(ref_small > 0, 1.0, 0.5), mode))
+        into = torch.full_like(deconv.weight.data, -2.0)
+        B._weight_gradient(shadow_t, deconv, smallb, bigb, into)
+        want = F.conv2d_backward_weight(F.leaf(big), F.leaf(small), tuple(deconv.weight.shape), (2, 2), (1, 1)).data
+        assert torch.equal(into, want - 2.0)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('case', [(7, 256, 512, 4, 12), (130, 40, 24, 4, 4), (3, 16, 8, 2, 3)])
+def test_seed_transposed_convolution_is_exact_on_integers(F, B, mode, case):
+    """The generator's ``fc``: conv_transpose2d of a 1 x 1 code with a full-plane kernel (reference age/models.py:37,47)."""
+    n, c_in, c_out, r, s = case
+    layer = torch.nn.ConvTranspose2d(c_in, c_out, (r, s), 1, 0).cuda()
+    with torch.no_grad():
+        layer.weight.copy_(integers(tuple(layer.weight.shape), -1, 1, 1))
+        layer.bias.copy_(integers((c_out,), -3, 3, 2))
+    z = integers((n, c_in), -2, 2, 3)
+    g = integers((n, c_out, r, s), -2, 2, 4)
+    from srgan_amd.tape import no_grad
+    with no_grad():
+        zb, gb = blocked(F, B, z, mode), blocked(F, B, g, mode)
+        want = torch.nn.functional.conv_transpose2d(z.view(n, c_in, 1, 1), layer.weight.data, layer.bias.data)
+        assert torch.equal(nchw(B, B.seed_conv_transpose(zb, layer)), rounded(want, mode))
+        shadow = B.shadow_of(layer, 'linear_t', B.CODES[mode])
+        back = B._layer(gb, layer, shadow, True, 0, 1.0, None, False)
+        assert torch.equal(B.unpack(back).data, rounded(torch.einsum('ncrs,kcrs->nk', g, layer.weight.data), mode))
+        into = torch.full_like(layer.weight.data, 1.0)
+        B._weight_gradient(shadow, layer, zb, gb, into)
+        assert torch.equal(into, torch.einsum('nk,ncrs->kcrs', z, g) + 1.0)
+
+
+def _dcgan_pass(F, size, storage, mode, second_order):
+    """One DCGAN generator -> discriminator pass with a backward into both (and, optionally, the penalty's double backward
+    through the discriminator) -> losses and the two gradient arenas."""
+    import srgan_amd  # noqa: F401
+    from srgan_amd.age import models
+    from srgan_amd import nn
+    from srgan_amd.tape import backward
+    torch.manual_seed(2)
+    G, D = models.Generator(image_size=size, conv_dim=32), models.Discriminator(image_size=size, conv_dim=32)
+    with torch.no_grad():
+        for module in D.modules():
+            if isinstance(module, torch.nn.Conv2d):
+                module.weight.mul_(2.5)
+    for network in (G, D):
+        nn.flatten_parameters(network, torch.device('cuda'))
+    z = torch.randn(6, 256, generator=torch.Generator().manual_seed(3)).cuda()
+    with F.compute_dtype(mode), F.storage_dtype(mode if storage else None):
+        fake = G(F.leaf(z))
+        scores = D(fake)
+        loss = F.add(F.mean_all(F.square(scores)), F.mean_all(F.abs_(D.features)))
+        backward(loss)
+        penalty_value = 0.0
+        if second_order:
+            interpolates = F.leaf(fake.data * 0.7, requires_grad=True)
+            D(interpolates)
+            norms = F.row_norm(F.flatten2d(D.features))
+            gradients, = backward(norms, grad=F.full_like(norms, 1.0), inputs=[interpolates], create_graph=True)
+            penalty = F.mean_all(F.square(F.relu(F.add_scalar(F.row_norm(F.flatten2d(gradients)), -1.0))))
+            backward(penalty)
+            penalty_value = penalty.item()
+    torch.cuda.synchronize()
+    return loss.item(), penalty_value, G._srgan_arena.grad.clone(), D._srgan_arena.grad.clone(), fake.data.clone()
+
+
+@pytest.mark.parametrize('size', [64, (64, 192)])
+@pytest.mark.parametrize('second_order', [False, True])
+def test_dcgan_pair_matches_the_fp32_storage_path(F, size, second_order):
+    loss_a, penalty_a, g_a, d_a, fake_a = _dcgan_pass(F, size, False, 'bf16', second_order)
+    loss_b, penalty_b, g_b, d_b, fake_b = _dcgan_pass(F, size, True, 'bf16', second_order)
+    assert (fake_a - fake_b).abs().max().item() <= 3e-2
+    assert abs(loss_a - loss_b) <= 3e-2 * abs(loss_a)
+    if second_order:
+        assert penalty_a > 1e-3 and abs(penalty_a - penalty_b) <= 8e-2 * penalty_a
+    for a, b in ((g_a, g_b), (d_a, d_b)):
+        # (a bias gradient is a sum of ~7e4 terms of both signs: the rounding of the stored gradients moves a small total by
+        # more than its own size, so the bound is on the arena's scale and the direction)
+        assert (a - b).abs().max().item() <= 1e-1 * a.abs().max().item()
+        assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99
+
+
+@pytest.mark.parametrize('batch', [8, 128])
+def test_driving_step_on_fp16_storage_against_the_fp32_oracle(batch):
+    """BASELINE.json configs[4] on the 16-bit data path (fp16 tensors in the blocked layout for D / DNN / G, the gradient-penalty
+    chain in fp32 on the fp32 kernels, static loss scale) against the fp32 CPU oracle, at a small batch and at 128."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_mixed_precision_gpu import _step_against_fp32_oracle
+    import srgan_amd  # noqa: F401
+    from srgan_amd.driving.srgan import DrivingExperiment
+    from oracle import models as OM
+    size = (64, 192)
+
+    def configure(experiment):
+        experiment.image_size = size
+    _step_against_fp32_oracle(DrivingExperiment, configure,
+                              lambda: (OM.DCGANGenerator(image_size=size), OM.DCGANDiscriminator(image_size=size),
+                                       OM.DCGANDiscriminator(image_size=size)),
+                              size=size, batch=batch, d_scale=2.2,
+                              settings_overrides=dict(compute_dtype='f16', gradient_penalty_dtype='f32', storage_dtype='f16',
+                                                      loss_scale=256.0),
+                              tolerance=2e-2)

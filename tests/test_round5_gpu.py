@@ -198,6 +198,7 @@ def _graph_under_dp_worker(port, queue, streams):
             lambda: (DCGenerator(image_size=size), KnnDenseNetCat(image_size=size), KnnDenseNetCat(image_size=size)),
             dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2, gradient_penalty_multiplier=1e2,
                  map_multiplier=1e-3, step_graph=step_graph, step_graph_warmup=1, steps_to_run=10 ** 9,
+                 step_graph_collectives='abi',          # the opt-in: exchanges through the C ABI's communicator, capturable
                  overlap_dnn_step=streams, overlap_gradient_penalty=streams), crowd=True)
         experiment.dp = dp
         with torch.no_grad():
@@ -205,6 +206,8 @@ def _graph_under_dp_worker(port, queue, streams):
                 if isinstance(module, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
                     module.weight.mul_(1.27)
         finish_setup(experiment)
+        for optimizer in (experiment.d_optimizer, experiment.g_optimizer, experiment.dnn_optimizer):
+            optimizer.count_on_device()      # both runs through the device-counted Adam entry point
         for writer in (experiment.dnn_summary_writer, experiment.gan_summary_writer):
             writer.summary_period, writer.steps_to_run = 10 ** 9, 10 ** 9
         seed_all(5)
@@ -212,7 +215,13 @@ def _graph_under_dp_worker(port, queue, streams):
         losses = []
         for step in range(1, iterations + 1):
             x, labels, u = crowd_inputs(generator, batch, size)
-            experiment.training_iteration(x.cuda(), tuple(t.cuda() for t in labels), u.cuda(), step)
+            if step == 3:
+                # an EAGER iteration between replays (what a summary step is) leaves the generator's update pending;
+                # the next replay must settle it first.  The eager run does the same iteration the same way.
+                experiment.dnn_training_step(x.cuda(), tuple(t.cuda() for t in labels), step)
+                experiment.gan_training_step(x.cuda(), tuple(t.cuda() for t in labels), u.cuda(), step)
+            else:
+                experiment.training_iteration(x.cuda(), tuple(t.cuda() for t in labels), u.cuda(), step)
             losses.append({name: float(value.item()) for name, value in experiment.last_losses.items() if value is not None})
         experiment.finish_update()
         experiment.join_dnn_stream()
@@ -256,16 +265,26 @@ def test_graph_replay_under_data_parallelism_over_rccl(streams):
     (eager_losses, eager_weights, eager_captured), (losses, weights, captured), abi, calls_during_replays = result
     worker.join(timeout=120)
     assert worker.exitcode == 0
-    assert eager_captured is None and captured == (4, 1), captured            # one eager warm-up iteration, four replays
-    assert abi and calls_during_replays > 0                                   # (collectives issued while capturing + the eager one)
-    for step, (a, b) in enumerate(zip(eager_losses, losses)):
-        rtol = 5e-3 if step <= 1 else 0.2                                     # (cf. test_step_graph_gpu: Adam amplifies rounding)
-        for name in a:
-            assert np.isclose(a[name], b[name], rtol=rtol, atol=1e-6), f'step {step} {name}: {a[name]} vs {b[name]}'
+    assert eager_captured is None and captured == (3, 1), captured            # a warm-up iteration, an eager one in between (outside
+    assert abi and calls_during_replays > 0                                   # the captured-iteration counter), three replays
+    if not streams:
+        # one compute stream in both runs: the replay executes the eager run's arithmetic -- losses and weights bit for bit
+        assert eager_losses == losses, (eager_losses, losses)
+        for name in ('D', 'DNN', 'G'):
+            assert np.array_equal(eager_weights[name], weights[name]), (name, float(np.abs(eager_weights[name] - weights[name]).max()))
+    else:
+        # The eager run keeps its side streams, the captured one runs on one compute stream: the penalty chain's gradients of
+        # D then arrive as ONE sum added to the stacked pass's (a + (b1 + b2 + ...)) instead of parameter by parameter
+        # ((a + b1) + b2 ...): D's update differs at rounding level, which the first iteration shows only in generator_loss
+        # (computed behind D's update) and later iterations everywhere, amplified by Adam's first updates.
+        for step, (a, b) in enumerate(zip(eager_losses, losses)):
+            for name in a:
+                rtol = 0.0 if (step == 0 and name != 'generator_loss') else (5e-3 if step <= 1 else 3e-2)     # (1.0e-2 observed at step 3)
+                assert np.isclose(a[name], b[name], rtol=rtol, atol=0.0 if rtol == 0.0 else 1e-6), f'step {step} {name}: {a[name]} vs {b[name]}'
+        for name in ('D', 'DNN', 'G'):
+            difference = np.abs(eager_weights[name] - weights[name])
+            assert float(difference.max()) <= 2.2e-4 * 5 and float(difference.mean()) <= 0.5e-4, name
     assert losses[-1]['gradient_penalty'] > 0.0 and losses[-1] != losses[-2]
-    for name in ('D', 'DNN', 'G'):
-        difference = np.abs(eager_weights[name] - weights[name])
-        assert float(difference.max()) <= 2.2e-4 * 5 and float(difference.mean()) <= 0.5e-4, name
     import conftest
     conftest.PARITY_NOTES.append(f'HIP-graph replay of the data-parallel iteration (RCCL through the C ABI, world size 1, forced; side '
                                  f'streams {"on" if streams else "off"}): 4 replays equal the eager run')
