@@ -152,6 +152,9 @@ def build_experiment(args, dp):
     settings.overlap_generator_forwards = streams and not os.environ.get('SRGAN_NO_AUX_STREAM')
     settings.overlap_gradient_penalty = streams and not os.environ.get('SRGAN_NO_PENALTY_STREAM')
     settings.overlap_gradient_exchange = not args.no_overlap_exchange
+    # the DCGAN stacks' 4x4 / stride 2 stages of every fp32 phase (the crowd generator; the fp32 gradient-penalty chain of the fp16
+    # configuration) on fp32 tensors in the blocked layout: csrc/blocked16_k4s2.hip, dtype 0 (SRGAN_NO_BLOCKED_F32=1: the NCHW kernels)
+    settings.blocked_fp32 = not os.environ.get('SRGAN_NO_BLOCKED_F32')
     settings.step_graph = bool(args.step_graph)
     if args.step_graph and dp is not None:
         settings.step_graph_collectives = 'abi'     # the opt-in: exchanges through the C ABI's own communicator, capturable

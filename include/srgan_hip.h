@@ -446,8 +446,11 @@ int srgan_h_linear_wgrad(const void* s, const void* x, float* gw, int32_t N, int
  * layout -- conv2d weights [K][C][4][4]: A = K, B = C; conv_transpose2d weights [Cin][Cout][4][4]: A = Cin, B = Cout -- always
  * has A = the channels of the tensor on the SMALL (H/2 x W/2) plane.  direction 0 "down" (big -> small plane, rows = A): conv2d's
  * forward, conv_transpose2d's data gradient; direction 1 "up" (small -> big plane, rows = B, the four output parity classes):
- * conv_transpose2d's forward, conv2d's data gradient.  epi as srgan_h_conv3x3. */
-int64_t srgan_h_k4s2_weight_slots(int32_t A, int32_t B, int direction);
+ * conv_transpose2d's forward, conv2d's data gradient.  epi as srgan_h_conv3x3.  This family (and srgan_h_pack / _unpack / _add /
+ * _channel_sums) also takes `dtype` 0: fp32 tensors in the same blocked layout with FOUR channels per 16-byte slot
+ * ([N][ceil(C / 4)][H][W][4]), v_mfma_f32_32x32x2_f32 -- the exact form (the fp32 gradient-penalty chain of configs[4], the
+ * crowd generator, reference crowd/models.py:132-146). */
+int64_t srgan_h_k4s2_weight_slots(int32_t A, int32_t B, int direction, int dtype);
 int srgan_h_pack_k4s2_weights(const float* w, void* packed, int32_t A, int32_t B, int direction, int dtype, void* stream);
 int srgan_h_conv4x4s2(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi, void* out,
                       int32_t N, int32_t C_in, int32_t rows, int32_t H, int32_t W, int dtype, void* stream);

@@ -122,7 +122,7 @@ SIGNATURES = {
     'srgan_h_pack_matrix': ([vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.c_int, vp], ctypes.c_int),
     'srgan_h_gemm': ([vp, vp, vp, vp, f32, ctypes.c_int, vp, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),
     'srgan_h_linear_wgrad': ([vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i32, i32, ctypes.c_int, vp], ctypes.c_int),
-    'srgan_h_k4s2_weight_slots': ([i32, i32, ctypes.c_int], ctypes.c_int64),
+    'srgan_h_k4s2_weight_slots': ([i32, i32, ctypes.c_int, ctypes.c_int], ctypes.c_int64),
     'srgan_h_pack_k4s2_weights': ([vp, vp, i32, i32, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),
     'srgan_h_conv4x4s2': ([vp, vp, vp, vp, f32, ctypes.c_int, vp, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),
     'srgan_h_conv_transpose4x4s2': ([vp, vp, vp, vp, f32, ctypes.c_int, vp, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),

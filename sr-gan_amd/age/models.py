@@ -52,7 +52,8 @@ class Generator(nn.Module):
 
     def forward(self, z):
         if F.STORAGE_DTYPE and z.meta is None and _blocked_stack_ok(self):
-            return self._forward_blocked(z, F.STORAGE_DTYPE)
+            from ..blocked16 import active_code
+            return self._forward_blocked(z, active_code())
         out = self.fc(F.view(z, (z.shape[0], z.shape[1], 1, 1)))
         for stage in (self.layer1, self.layer2, self.layer3):
             out = F.leaky_relu(stage(out), LEAK)
@@ -62,7 +63,10 @@ class Generator(nn.Module):
         """The same graph on the 16-bit data path (``blocked16``): the code and every feature map bf16 / fp16 in the blocked
         layout, ``leaky_relu(convT(x))`` one kernel per stage, fp32 again for the images (tanh on the 3-channel result)."""
         from .. import blocked16 as B
-        h = B.seed_conv_transpose(B.pack(F.view(z, (z.shape[0], z.shape[1])), code), self.fc[0])
+        if code == 0:       # fp32 blocked: the seed layer on the fp32 kernels (one GEMM over its 26-137 M weights), then the stages
+            h = B.pack(self.fc(F.view(z, (z.shape[0], z.shape[1], 1, 1))), 0)
+        else:
+            h = B.seed_conv_transpose(B.pack(F.view(z, (z.shape[0], z.shape[1])), code), self.fc[0])
         for stage in (self.layer1, self.layer2, self.layer3):
             h = B.conv_transpose4x4s2(h, stage[0], slope=LEAK)
         return F.tanh(B.unpack(B.conv_transpose4x4s2(h, self.layer4[0])))
@@ -84,7 +88,8 @@ class Discriminator(nn.Module):
 
     def forward(self, x):
         if F.STORAGE_DTYPE and x.meta is None and _blocked_stack_ok(self):
-            return self._forward_blocked(x, F.STORAGE_DTYPE)
+            from ..blocked16 import active_code
+            return self._forward_blocked(x, active_code())
         out = x
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             out = F.leaky_relu(stage(out), LEAK)
@@ -99,6 +104,9 @@ class Discriminator(nn.Module):
         h = B.pack(x, code)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             h = B.conv4x4s2(h, stage[0], slope=LEAK)
-        self.features = F.flatten2d(B.unpack(h))
-        scores = B.unpack(B.linear(B.flatten(h), self.layer5[0]))
+        trunk = B.unpack(h)
+        self.features = F.flatten2d(trunk)
+        # the full-plane convolution = a linear map over the flattened trunk: 16-bit through the blocked order's shadow, fp32
+        # blocked through the fp32 kernels on the unpacked trunk
+        scores = self.layer5(trunk) if code == 0 else B.unpack(B.linear(B.flatten(h), self.layer5[0]))
         return F.view(scores, (-1,) if self.number_of_outputs == 1 else (-1, self.number_of_outputs))

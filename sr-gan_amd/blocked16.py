@@ -25,8 +25,22 @@ from . import _lib
 from . import functional as F
 from .tape import Var, accumulates_into
 
-TORCH_DTYPE = {1: torch.bfloat16, 2: torch.float16}
-CODES = {'bf16': 1, 'f16': 2, 'fp16': 2}
+TORCH_DTYPE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+CODES = {'f32': 0, 'bf16': 1, 'f16': 2, 'fp16': 2}
+# code 0: fp32 in the same blocked layout with FOUR channels per 16-byte slot -- the exact form of the 4x4 / stride 2 family
+# (v_mfma_f32_32x32x2_f32; the fp32 gradient-penalty chain of the fp16 configuration, the crowd generator).  Conversions, sums
+# and that family take it; the 3x3 / pooling / linear kernels are 16-bit only.
+
+
+def group_size(code):
+    return 4 if code == 0 else 8
+
+
+def active_code():
+    """The blocked dtype code the active ``F.storage_dtype`` asks for (None: plain fp32 tensors)."""
+    if not F.STORAGE_DTYPE:
+        return None
+    return 0 if F.STORAGE_DTYPE == F.STORAGE_BLOCKED_F32 else F.STORAGE_DTYPE
 
 
 class Blocked:
@@ -40,8 +54,12 @@ class Blocked:
         self.real = c if real is None else real          # features that exist (flattened tensors: channels x plane)
 
     @property
+    def group(self):
+        return group_size(self.code)
+
+    @property
     def groups(self):
-        return (self.c + 7) // 8
+        return (self.c + self.group - 1) // self.group
 
     def like(self, **changes):
         values = {name: getattr(self, name) for name in self.__slots__}
@@ -54,7 +72,8 @@ def _call(name, *args):
 
 
 def _new(n, c, h, w, code, device):
-    shape = (n, (c + 7) // 8, h, w, 8)
+    group = group_size(code)
+    shape = (n, (c + group - 1) // group, h, w, group)
     if F.POISON:
         return torch.full(shape, float('nan'), dtype=TORCH_DTYPE[code], device=device)
     return torch.empty(shape, dtype=TORCH_DTYPE[code], device=device)
@@ -99,6 +118,8 @@ def flatten(x):
     meta = x.meta
     if meta.h == meta.w == 1:
         return x
+    if meta.code == 0:
+        raise NotImplementedError('blocked16.flatten: the linear layers behind it are 16-bit only')
     plane, length = meta.h * meta.w, meta.groups * 8 * meta.h * meta.w
 
     def flat(tensor):
@@ -127,7 +148,7 @@ def add(a, b):
     if a.meta is None or b.meta is None or a.data.shape != b.data.shape or a.meta.code != b.meta.code:
         raise ValueError('blocked16.add: both operands must be 16-bit blocked tensors of one shape')
     data = torch.empty_like(a.data)
-    _call('srgan_h_add', a.data.data_ptr(), b.data.data_ptr(), data.data_ptr(), data.numel() // 8, a.meta.code, F._stream())
+    _call('srgan_h_add', a.data.data_ptr(), b.data.data_ptr(), data.data_ptr(), data.numel() // a.meta.group, a.meta.code, F._stream())
     out = F._out(data, (a, b), lambda g, needs: (g, g), 'h_add')
     out.meta = a.meta
     return out
@@ -218,8 +239,8 @@ class Shadow:
             # [A][B][4][4], A = the channels on the small plane: conv2d weights [K][C], conv_transpose2d weights [Cin][Cout]
             a, b = weight.shape[0], weight.shape[1]
             for name, direction in (('down', 0), ('up', 1)):
-                _call('srgan_h_pack_k4s2_weights', weight.data_ptr(), buffer(name, lib.srgan_h_k4s2_weight_slots(a, b, direction)), a, b,
-                      direction, self.code, stream)
+                _call('srgan_h_pack_k4s2_weights', weight.data_ptr(), buffer(name, lib.srgan_h_k4s2_weight_slots(a, b, direction, self.code)),
+                      a, b, direction, self.code, stream)
         elif self.kind == 'linear_t':
             # conv_transpose2d weights [Cin][Cout][R][S] applied to a 1 x 1 input: a linear map Cin -> (Cout, R x S); its outputs
             # in the blocked order of a [Cout, R, S] tensor (plane = R * S)

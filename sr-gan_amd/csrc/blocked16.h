@@ -61,6 +61,40 @@ __device__ __forceinline__ Slot h_pack8(const float (&f)[8]) {
   for (int i = 0; i < 4; ++i) s.v[i] = h_pack2<PREC>(f[2 * i], f[2 * i + 1]);
   return s;
 }
+// Channels per 16-byte slot: 8 for the 16-bit types; dtype 0 = fp32 in the same blocked layout with FOUR channels per slot
+// ([N][ceil(C / 4)][H][W][4] floats): the exact path of the 4x4 / stride 2 family (blocked16_k4s2.hip) -- the fp32 gradient-
+// penalty chain of the fp16 configuration and the crowd generator -- where v_mfma_f32_32x32x2_f32 takes one float per lane
+// and a slot feeds four matrix instructions.
+template <int PREC> struct HGroup { static constexpr int N = PREC == 0 ? 4 : 8; };
+template <int PREC>
+__device__ __forceinline__ void h_unpack(const Slot& s, float (&f)[HGroup<PREC>::N]) {
+  if constexpr (PREC == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(s.v[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = h_lo<PREC>(s.v[i]); f[2 * i + 1] = h_hi<PREC>(s.v[i]); }
+  }
+}
+template <int PREC>
+__device__ __forceinline__ Slot h_pack(const float (&f)[HGroup<PREC>::N]) {
+  Slot s;
+  if constexpr (PREC == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.v[i] = __float_as_uint(f[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.v[i] = h_pack2<PREC>(f[2 * i], f[2 * i + 1]);
+  }
+  return s;
+}
+// [element j of the slot > 0] for the mask by reference
+template <int PREC>
+__device__ __forceinline__ bool h_slot_positive(const Slot& s, int j) {
+  if constexpr (PREC == 0) return __uint_as_float(s.v[j]) > 0.f;
+  else return h_positive((s.v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+}
+
 // The derivative of relu (slope 0) / leaky_relu / identity (slope 1) from the sign pattern of the ACTIVATED value:
 // act(z) > 0 <=> z > 0 for slope >= 0, so the 16-bit output itself is the mask (reference: torch's threshold / leaky_relu
 // backward use x > 0).
@@ -79,9 +113,13 @@ __device__ __forceinline__ uint32_t h_lds_address(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-template <int PREC, typename Frag = typename std::conditional<PREC == 1, h_bf16x8, h_f16x8>::type>
+template <int PREC>
 __device__ __forceinline__ f32x16 h_mfma(const Slot& a, const Slot& b, f32x16 c) {
-  if constexpr (PREC == 1)
+  if constexpr (PREC == 0) {           // fp32: the slot's four channels are four k-steps of v_mfma_f32_32x32x2_f32 (k pair = the
+#pragma unroll                         // same component of the two lane halves' slots)
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.v[i]), __uint_as_float(b.v[i]), c, 0, 0, 0);
+    return c;
+  } else if constexpr (PREC == 1)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h_bf16x8, a), __builtin_bit_cast(h_bf16x8, b), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h_f16x8, a), __builtin_bit_cast(h_f16x8, b), c, 0, 0, 0);

@@ -27,39 +27,41 @@ template <int PREC>
 __global__ __launch_bounds__(256) void h_pack_kernel(const float* __restrict__ x, Slot* __restrict__ out,
                                                      const Slot* __restrict__ ref, float slope, int64_t slots, int32_t C,
                                                      int32_t CG, int32_t HW) {
+  constexpr int G = HGroup<PREC>::N;
   for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
     const int pix = (int)(s % HW);
     const int64_t ng = s / HW;
     const int g = (int)(ng % CG);
     const int64_t n = ng / CG;
-    float v[8];
+    float v[G];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = 8 * g + j;
+    for (int j = 0; j < G; ++j) {
+      const int c = G * g + j;
       v[j] = c < C ? x[(n * C + c) * HW + pix] : 0.f;
     }
     if (ref) {
       const Slot r = ref[s];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= h_mask((r.v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, slope);
+      for (int j = 0; j < G; ++j) v[j] *= h_slot_positive<PREC>(r, j) ? 1.f : slope;
     }
-    out[s] = h_pack8<PREC>(v);
+    out[s] = h_pack<PREC>(v);
   }
 }
 
 template <int PREC>
 __global__ __launch_bounds__(256) void h_unpack_kernel(const Slot* __restrict__ x, float* __restrict__ out, int64_t slots,
                                                        int32_t C, int32_t CG, int32_t HW) {
+  constexpr int G = HGroup<PREC>::N;
   for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
     const int pix = (int)(s % HW);
     const int64_t ng = s / HW;
     const int g = (int)(ng % CG);
     const int64_t n = ng / CG;
-    float v[8];
-    h_unpack8<PREC>(x[s], v);
+    float v[G];
+    h_unpack<PREC>(x[s], v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = 8 * g + j;
+    for (int j = 0; j < G; ++j) {
+      const int c = G * g + j;
       if (c < C) out[(n * C + c) * HW + pix] = v[j];
     }
   }
@@ -68,13 +70,14 @@ __global__ __launch_bounds__(256) void h_unpack_kernel(const Slot* __restrict__ 
 template <int PREC>
 __global__ __launch_bounds__(256) void h_add_kernel(const Slot* __restrict__ a, const Slot* __restrict__ b,
                                                     Slot* __restrict__ out, int64_t slots) {
+  constexpr int G = HGroup<PREC>::N;
   for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (int64_t)gridDim.x * 256) {
-    float x[8], y[8];
-    h_unpack8<PREC>(a[s], x);
-    h_unpack8<PREC>(b[s], y);
+    float x[G], y[G];
+    h_unpack<PREC>(a[s], x);
+    h_unpack<PREC>(b[s], y);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] += y[j];
-    out[s] = h_pack8<PREC>(x);
+    for (int j = 0; j < G; ++j) x[j] += y[j];
+    out[s] = h_pack<PREC>(x);
   }
 }
 
@@ -83,38 +86,40 @@ __global__ __launch_bounds__(256) void h_add_kernel(const Slot* __restrict__ a, 
 template <int PREC>
 __global__ __launch_bounds__(256) void h_channel_sums_kernel(const Slot* __restrict__ x, float* __restrict__ part, int32_t N,
                                                              int32_t CG, int32_t HW, int32_t parts) {
+  constexpr int G = HGroup<PREC>::N;
   __shared__ float scratch[4 * 8];
   const int g = (int)blockIdx.x, part_id = (int)blockIdx.y;
   const int64_t total = (int64_t)N * HW;
-  float sum[8];
+  float sum[G];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+  for (int j = 0; j < G; ++j) sum[j] = 0.f;
   for (int64_t i = (int64_t)part_id * 256 + threadIdx.x; i < total; i += (int64_t)parts * 256) {
     const int64_t n = i / HW;
     const int pix = (int)(i - n * HW);
-    float v[8];
-    h_unpack8<PREC>(x[(n * CG + g) * HW + pix], v);
+    float v[G];
+    h_unpack<PREC>(x[(n * CG + g) * HW + pix], v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sum[j] += v[j];
+    for (int j = 0; j < G; ++j) sum[j] += v[j];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < G; ++j) {
     const float w = wave_sum(sum[j]);
     if (lane == 0) scratch[wave * 8 + j] = w;
   }
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x < G) {
     const int j = threadIdx.x;
     part[((int64_t)g * parts + part_id) * 8 + j] = (scratch[j] + scratch[8 + j]) + (scratch[16 + j] + scratch[24 + j]);
   }
 }
 
+// `group` = channels per slot (8; 4 for the fp32 blocked form)
 __global__ __launch_bounds__(256) void h_channel_sums_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                                    int32_t C, int32_t parts) {
+                                                                    int32_t C, int32_t parts, int32_t group) {
   const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (c >= C) return;
-  const float* mine = part + (int64_t)(c >> 3) * parts * 8 + (c & 7);
+  const float* mine = part + (int64_t)(c / group) * parts * 8 + (c % group);
   float total = 0.f;
   for (int s = 0; s < parts; ++s) total += mine[s * 8];
   out[c] += total;
@@ -852,6 +857,10 @@ static int check_dtype(int dtype) {
   SRGAN_REQUIRE(dtype == 1 || dtype == 2, SRGAN_EINVAL, "blocked 16-bit tensors are bf16 (1) or fp16 (2)");
   return SRGAN_OK;
 }
+static int check_dtype_or_f32(int dtype) {        // the layout conversions and sums also take dtype 0: fp32, four channels per slot
+  SRGAN_REQUIRE(dtype >= 0 && dtype <= 2, SRGAN_EINVAL, "blocked tensors are fp32 (0), bf16 (1) or fp16 (2)");
+  return SRGAN_OK;
+}
 
 }  // namespace srgan
 
@@ -861,44 +870,47 @@ extern "C" {
 
 int srgan_h_pack(const float* x, void* out, const void* mask_ref, float slope, int32_t N, int32_t C, int64_t HW, int dtype,
                  hipStream_t stream) {
-  if (const int status = check_dtype(dtype)) return status;
+  if (const int status = check_dtype_or_f32(dtype)) return status;
   SRGAN_REQUIRE(x && out && N >= 0 && C > 0 && HW > 0 && HW < ((int64_t)1 << 31), SRGAN_EINVAL, "srgan_h_pack arguments");
-  const int CG = (C + 7) / 8;
+  const int group = dtype == 0 ? 4 : 8, CG = (C + group - 1) / group;
   const int64_t slots = (int64_t)N * CG * HW;
   if (slots == 0) return SRGAN_OK;
   const dim3 grid(stream_grid(slots, 256));
-  if (dtype == 1) hipLaunchKernelGGL(h_pack_kernel<1>, grid, dim3(256), 0, stream, x, (Slot*)out, (const Slot*)mask_ref, slope, slots, C, CG, (int32_t)HW);
+  if (dtype == 0) hipLaunchKernelGGL(h_pack_kernel<0>, grid, dim3(256), 0, stream, x, (Slot*)out, (const Slot*)mask_ref, slope, slots, C, CG, (int32_t)HW);
+  else if (dtype == 1) hipLaunchKernelGGL(h_pack_kernel<1>, grid, dim3(256), 0, stream, x, (Slot*)out, (const Slot*)mask_ref, slope, slots, C, CG, (int32_t)HW);
   else hipLaunchKernelGGL(h_pack_kernel<2>, grid, dim3(256), 0, stream, x, (Slot*)out, (const Slot*)mask_ref, slope, slots, C, CG, (int32_t)HW);
   return launch_status();
 }
 
 int srgan_h_unpack(const void* x, float* out, int32_t N, int32_t C, int64_t HW, int dtype, hipStream_t stream) {
-  if (const int status = check_dtype(dtype)) return status;
+  if (const int status = check_dtype_or_f32(dtype)) return status;
   SRGAN_REQUIRE(x && out && N >= 0 && C > 0 && HW > 0 && HW < ((int64_t)1 << 31), SRGAN_EINVAL, "srgan_h_unpack arguments");
-  const int CG = (C + 7) / 8;
+  const int group = dtype == 0 ? 4 : 8, CG = (C + group - 1) / group;
   const int64_t slots = (int64_t)N * CG * HW;
   if (slots == 0) return SRGAN_OK;
   const dim3 grid(stream_grid(slots, 256));
-  if (dtype == 1) hipLaunchKernelGGL(h_unpack_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, out, slots, C, CG, (int32_t)HW);
+  if (dtype == 0) hipLaunchKernelGGL(h_unpack_kernel<0>, grid, dim3(256), 0, stream, (const Slot*)x, out, slots, C, CG, (int32_t)HW);
+  else if (dtype == 1) hipLaunchKernelGGL(h_unpack_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, out, slots, C, CG, (int32_t)HW);
   else hipLaunchKernelGGL(h_unpack_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)x, out, slots, C, CG, (int32_t)HW);
   return launch_status();
 }
 
 int srgan_h_add(const void* a, const void* b, void* out, int64_t slots, int dtype, hipStream_t stream) {
-  if (const int status = check_dtype(dtype)) return status;
+  if (const int status = check_dtype_or_f32(dtype)) return status;
   SRGAN_REQUIRE(a && b && out && slots >= 0, SRGAN_EINVAL, "srgan_h_add arguments");
   if (slots == 0) return SRGAN_OK;
   const dim3 grid(stream_grid(slots, 256));
-  if (dtype == 1) hipLaunchKernelGGL(h_add_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)a, (const Slot*)b, (Slot*)out, slots);
+  if (dtype == 0) hipLaunchKernelGGL(h_add_kernel<0>, grid, dim3(256), 0, stream, (const Slot*)a, (const Slot*)b, (Slot*)out, slots);
+  else if (dtype == 1) hipLaunchKernelGGL(h_add_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)a, (const Slot*)b, (Slot*)out, slots);
   else hipLaunchKernelGGL(h_add_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)a, (const Slot*)b, (Slot*)out, slots);
   return launch_status();
 }
 
 // out[c] += sum over n and pixels of x[n, c, pixel]   (c < C; fp32; the bias gradient of a fused convolution / linear layer)
 int srgan_h_channel_sums(const void* x, float* out, int32_t N, int32_t C, int64_t HW, int dtype, hipStream_t stream) {
-  if (const int status = check_dtype(dtype)) return status;
+  if (const int status = check_dtype_or_f32(dtype)) return status;
   SRGAN_REQUIRE(x && out && N > 0 && C > 0 && HW > 0 && HW < ((int64_t)1 << 31), SRGAN_EINVAL, "srgan_h_channel_sums arguments");
-  const int CG = (C + 7) / 8;
+  const int group = dtype == 0 ? 4 : 8, CG = (C + group - 1) / group;
   const int64_t per_group = (int64_t)N * HW;
   int parts = (int)((per_group + 4095) / 4096);
   if (parts > 256) parts = 256;
@@ -907,9 +919,10 @@ int srgan_h_channel_sums(const void* x, float* out, int32_t N, int32_t C, int64_
   float* part = partial_workspace((size_t)CG * parts * 8 * sizeof(float), stream);
   SRGAN_REQUIRE(part, SRGAN_EINVAL, "srgan_h_channel_sums: register a workspace for this stream first (srgan_set_workspace)");
   const dim3 grid((unsigned)CG, (unsigned)parts);
-  if (dtype == 1) hipLaunchKernelGGL(h_channel_sums_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
+  if (dtype == 0) hipLaunchKernelGGL(h_channel_sums_kernel<0>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
+  else if (dtype == 1) hipLaunchKernelGGL(h_channel_sums_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
   else hipLaunchKernelGGL(h_channel_sums_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
-  hipLaunchKernelGGL(h_channel_sums_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, out, C, parts);
+  hipLaunchKernelGGL(h_channel_sums_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, out, C, parts, group);
   return launch_status();
 }
 

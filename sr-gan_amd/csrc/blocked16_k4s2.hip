@@ -31,7 +31,8 @@ float* partial_workspace(size_t bytes, hipStream_t stream);
 constexpr int K4_CK = 4;          // k-slots per chunk
 constexpr int K4_TAPS = 4;
 
-// mode 0 ("down"): slot (chunk, tap = 2a + b, j = 2 qy + qx, o) = 8 reduced channels 8 chunk .. of w[o][.][2a + qy][2b + qx]
+// (G = channels per slot: 8, or 4 for the fp32 form)
+// mode 0 ("down"): slot (chunk, tap = 2a + b, j = 2 qy + qx, o) = G reduced channels G chunk .. of w[o][.][2a + qy][2b + qx]
 // mode 1 + 2 ry + rx ("up", one output parity class): slot (chunk, tap, j, o) = 8 reduced channels 8 (4 chunk + j) .. of
 //   w[.][o][kh(ry, a)][kw(rx, b)]
 // element (row o, reduced r, kh, kw) at w[o * row_stride + r * reduced_stride + kh * 4 + kw]
@@ -47,19 +48,20 @@ __global__ __launch_bounds__(256) void h_pack_k4s2_weights_kernel(const float* _
   const int tap = (int)(rest % K4_TAPS);
   const int chunk = (int)(rest / K4_TAPS);
   const int a = tap >> 1, b = tap & 1;
+  constexpr int G = HGroup<PREC>::N;
   int kh, kw, first;
-  if (mode == 0) { kh = 2 * a + (j >> 1); kw = 2 * b + (j & 1); first = 8 * chunk; }
+  if (mode == 0) { kh = 2 * a + (j >> 1); kw = 2 * b + (j & 1); first = G * chunk; }
   else {
     const int ry = (mode - 1) >> 1, rx = (mode - 1) & 1;
     kh = ry == 0 ? 3 - 2 * a : 2 - 2 * a;
     kw = rx == 0 ? 3 - 2 * b : 2 - 2 * b;
-    first = 8 * (K4_CK * chunk + j);
+    first = G * (K4_CK * chunk + j);
   }
-  float v[8];
+  float v[G];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < G; ++i)
     v[i] = first + i < reduced ? w[o * row_stride + (int64_t)(first + i) * reduced_stride + kh * 4 + kw] : 0.f;
-  packed[slot] = h_pack8<PREC>(v);
+  packed[slot] = h_pack<PREC>(v);
 }
 
 struct HConv2Params {
@@ -74,10 +76,19 @@ struct HConv2Params {
   int32_t chunks;
   int32_t tiles_x, tiles_y, tiles_m;
   int32_t xcd_remap;
+  int64_t class_stride;               // "up": blockIdx.y = the output parity class 2 ry + rx; its operand starts class_stride slots further
 };
 
 template <int BM, int NI, int TW, int ROWS, int PREC>
-__global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params p, const Slot* zero) {
+__global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params pp, const Slot* zero) {
+  // the four output parity classes of the "up" direction are ONE launch (gridDim.y = 4): a class alone is a quarter of the
+  // convolution and leaves the chip under-filled on the small planes (192 workgroups on a 4 x 12 plane at batch 128)
+  HConv2Params p = pp;
+  if (!p.down) {
+    const int ry = (int)blockIdx.y >> 1, rx = (int)blockIdx.y & 1;
+    p.oy = ry ? 0 : -1; p.ox = rx ? 0 : -1; p.doy = ry; p.dox = rx;
+    p.wp += (int64_t)blockIdx.y * p.class_stride;
+  }
   constexpr int RING = 2, CK = K4_CK, TAPS = K4_TAPS;
   constexpr int P = 128 * NI, IMG = P / (ROWS * TW), PW = TW + 1, PH = ROWS + 1, PLANE = PH * PW;
   static_assert(IMG * ROWS * TW == P && IMG >= 1, "the pixel tile is IMG x ROWS x TW");
@@ -188,9 +199,11 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params p, 
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        const int group = (m0 + mi * 32) / 8 + qd;
-        if (group >= p.CGO) continue;
+        // registers 4 qd .. 4 qd + 3 = the four consecutive channels o .. o + 3: half a slot of the 16-bit forms, a whole
+        // slot (group o / 4) of the fp32 form
         const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
+        const int group = PREC == 0 ? o / 4 : o / 8;
+        if (group >= p.CGO) continue;
         const int64_t slot = ((int64_t)n * p.CGO + group) * OHW + pixel;
         float v[4];
 #pragma unroll
@@ -201,15 +214,25 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params p, 
             if (p.bias != nullptr && o + jj < p.C_real) v[jj] += p.bias[o + jj];
             v[jj] = v[jj] > 0.f ? v[jj] : v[jj] * p.slope;
           }
-        } else if (p.epi == 2) {
-          const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
-          v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
-          v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
         }
-        uint2 packed;
-        packed.x = h_pack2<PREC>(v[0], v[1]);
-        packed.y = h_pack2<PREC>(v[2], v[3]);
-        *(reinterpret_cast<uint2*>(p.out + slot) + lhi) = packed;
+        if constexpr (PREC == 0) {
+          if (p.epi == 2) {
+            const float4 r = *reinterpret_cast<const float4*>(p.ref + slot);
+            v[0] *= r.x > 0.f ? 1.f : p.slope; v[1] *= r.y > 0.f ? 1.f : p.slope;
+            v[2] *= r.z > 0.f ? 1.f : p.slope; v[3] *= r.w > 0.f ? 1.f : p.slope;
+          }
+          *reinterpret_cast<float4*>(p.out + slot) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          if (p.epi == 2) {
+            const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
+            v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
+            v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
+          }
+          uint2 packed;
+          packed.x = h_pack2<PREC>(v[0], v[1]);
+          packed.y = h_pack2<PREC>(v[2], v[3]);
+          *(reinterpret_cast<uint2*>(p.out + slot) + lhi) = packed;
+        }
       }
     }
   }
@@ -262,7 +285,7 @@ static int hconv2_run(HConv2Params& p, int dtype, int64_t flops_k, hipStream_t s
     const int rows = rows_of(ni), img = 128 * ni / (rows * tw);
     return (int64_t)((p.GW + tw - 1) / tw) * ((p.GH + rows - 1) / rows) * ((p.N + img - 1) / img) * p.tiles_m;
   };
-  const int ni = (tw != 4 && count(2) >= 512) ? 2 : 1;
+  const int ni = (tw != 4 && count(2) * (p.down ? 1 : 4) >= 512) ? 2 : 1;
   const int rows = rows_of(ni), img = 128 * ni / (rows * tw);
   p.tiles_x = (p.GW + tw - 1) / tw;
   p.tiles_y = (p.GH + rows - 1) / rows;
@@ -270,17 +293,16 @@ static int hconv2_run(HConv2Params& p, int dtype, int64_t flops_k, hipStream_t s
   SRGAN_REQUIRE(blocks < ((int64_t)1 << 31), SRGAN_ERANGE, "k4s2 convolution grid");
   (void)img;
   p.xcd_remap = (blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
-  const dim3 grid((unsigned)blocks);
+  const dim3 grid((unsigned)blocks, p.down ? 1u : 4u);
   const int slot = profile_bracket_begin(stream);
   int launched;
-  if (bm == 64) launched = dtype == 1 ? hconv2_launch<64, 1>(p, ni, tw, grid, stream) : hconv2_launch<64, 2>(p, ni, tw, grid, stream);
-  else launched = dtype == 1 ? hconv2_launch<32, 1>(p, ni, tw, grid, stream) : hconv2_launch<32, 2>(p, ni, tw, grid, stream);
+  if (bm == 64) launched = dtype == 0 ? hconv2_launch<64, 0>(p, ni, tw, grid, stream) : (dtype == 1 ? hconv2_launch<64, 1>(p, ni, tw, grid, stream) : hconv2_launch<64, 2>(p, ni, tw, grid, stream));
+  else launched = dtype == 0 ? hconv2_launch<32, 0>(p, ni, tw, grid, stream) : (dtype == 1 ? hconv2_launch<32, 1>(p, ni, tw, grid, stream) : hconv2_launch<32, 2>(p, ni, tw, grid, stream));
   if (launched != SRGAN_OK) return launched;
   const int status = launch_status();
-  const double positions = (double)p.N * p.GH * p.GW;
-  profile_bracket_end_bytes(slot, stream, p.CO < p.CGO * 8 ? p.CO : p.CGO * 8, (int64_t)positions, flops_k, 18, bm, ni * 128, 1,
-                            2.0 * ((double)p.N * p.CGI * 8 * p.IH * p.IW / (p.down ? 1 : 4) + positions * p.CGO * 8 * (p.epi == 2 ? 2 : 1)),
-                            dtype);
+  const double positions = (double)p.N * p.GH * p.GW * (p.down ? 1 : 4);       // output pixels
+  profile_bracket_end_bytes(slot, stream, p.CO, (int64_t)positions, flops_k, 18, bm, ni * 128, 1,
+                            16.0 * ((double)p.N * p.CGI * p.IH * p.IW + positions * p.CGO * (p.epi == 2 ? 2 : 1)), dtype);
   return status;
 }
 
@@ -424,36 +446,177 @@ __global__ __launch_bounds__(256, 2) void hwgrad4x4s2_kernel(const HWgrad4Params
       for (int r = 0; r < 16; ++r) mine[((mi * 4 + t) * 16 + r) * 256] = acc[mi][t][r];
 }
 
+// The same weight gradient on fp32 blocked tensors (four channels per slot; the exact gradient-penalty chain of the fp16
+// configuration, the crowd generator).  v_mfma_f32_32x32x2_f32 takes ONE float per lane -- A[i = lane & 31][k = lane >> 5] -- so a
+// fragment is a plain ds_read_b32 of (pixel 2 s + k, channel i) and no transposition is involved; 32 small-plane pixels per staged
+// tile = 16 matrix steps x 8 accumulators x 64 cycles of matrix work per wave and barrier.  The LDS images are [16 small groups]
+// [33] and [4 parities][8 big groups][IMG x patch, stride = 1 mod 8]: the 32 lanes of a read (8 groups x 4 channels) then fall
+// on 32 different banks.  Same tile ownership, partial layout and finish as hwgrad4x4s2_kernel.
+constexpr int h4_stride_f32(int slots) { return ((slots + 6) / 8) * 8 + 1; }      // = 1 (mod 8), >= slots
+
+template <int TW, int ROWS>
+__global__ __launch_bounds__(256, 2) void hwgrad4x4s2_f32_kernel(const HWgrad4Params p) {
+  constexpr int P = 32, IMG = P / (ROWS * TW), PW = TW + 1, PH = ROWS + 1, PLANE = PH * PW;
+  static_assert(IMG * ROWS * TW == P && IMG >= 1, "the pixel tile is IMG x ROWS x TW");
+  constexpr int SS = h4_stride_f32(P), BS = h4_stride_f32(IMG * PLANE);
+  constexpr int SQ = 16 * P, BQ = 32 * IMG * PLANE;         // 16 small groups of 4 channels; 8 big groups x 4 parities
+  constexpr int NS = SQ / 256, NB = (BQ + 255) / 256;
+  __shared__ Slot lds[16 * SS + 32 * BS];
+  Slot* ss = lds;
+  Slot* bs = lds + 16 * SS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int qy = wave >> 1, qx = wave & 1;
+  const int tc = (int)blockIdx.x % p.tiles_c, tk = (int)blockIdx.x / p.tiles_c;
+  const int walker = (int)blockIdx.y;
+  const int HW = p.H * p.W, SHW = p.SH * p.SW;
+
+  Slot rs_[NS], rb[NB];
+  uint32_t oks = 0, okb = 0;
+  auto fetch = [&](int tile) {
+    const int tx = tile % p.tiles_x;
+    const int rest_t = tile / p.tiles_x;
+    const int ty = rest_t % p.tiles_y;
+    const int n0 = (rest_t / p.tiles_y) * IMG;
+    const int y0 = ty * ROWS, x0 = tx * TW;
+    oks = okb = 0;
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      const int flat = e * 256 + tid;
+      const int grp = flat / P, q = flat % P;
+      const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
+      const int group = tk * 16 + grp;
+      const bool ok = n < p.N && y < p.SH && x < p.SW && group < p.CGS;
+      oks |= (ok ? 1u : 0u) << e;
+      rs_[e] = p.small[ok ? ((int64_t)n * p.CGS + group) * SHW + y * p.SW + x : 0];
+    }
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      const int flat = e * 256 + tid;
+      const int qg = flat / (IMG * PLANE), rest = flat - qg * (IMG * PLANE);      // qg = parity * 8 + group
+      const int img = rest / PLANE, pix = rest % PLANE;
+      const int n = n0 + img;
+      const int parity = qg >> 3;
+      const int sy = 2 * (y0 + pix / PW) - 1 + (parity >> 1), sx = 2 * (x0 + pix % PW) - 1 + (parity & 1);
+      const int group = tc * 8 + (qg & 7);
+      const bool ok = flat < BQ && n < p.N && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W && group < p.CGB;
+      okb |= (ok ? 1u : 0u) << e;
+      rb[e] = p.big[ok ? ((int64_t)n * p.CGB + group) * HW + sy * p.W + sx : 0];
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.f;
+
+  // fragment addresses (floats): A = small[pixel 2 s + lhi][channel 32 mi + l31], B = big-parity image[window of pixel 2 s + lhi][channel l31]
+  const float* a_base[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+    a_base[mi] = reinterpret_cast<const float*>(ss) + ((8 * mi + (l31 >> 2)) * SS + lhi) * 4 + (l31 & 3);
+  const float* b_base = reinterpret_cast<const float*>(bs) + (((2 * qy + qx) * 8 + (l31 >> 2)) * BS + lhi) * 4 + (l31 & 3);
+  const bool active = tk * 64 < p.CGS * 4 && tc * 32 < p.CGB * 4;
+
+  int tile = walker;
+  if (tile < p.pixel_tiles) fetch(tile);
+  for (; tile < p.pixel_tiles; tile += p.walkers) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      const int flat = e * 256 + tid;
+      Slot v = rs_[e];
+      if (!((oks >> e) & 1u)) v = Slot{{0u, 0u, 0u, 0u}};
+      ss[(flat / P) * SS + flat % P] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      const int flat = e * 256 + tid;
+      const int qg = flat / (IMG * PLANE), rest = flat - qg * (IMG * PLANE);
+      Slot v = rb[e];
+      if (!((okb >> e) & 1u)) v = Slot{{0u, 0u, 0u, 0u}};
+      if (flat < BQ) bs[qg * BS + rest] = v;
+    }
+    __syncthreads();
+    const int next = tile + p.walkers;
+    if (next < p.pixel_tiles) fetch(next);
+    if (active)
+#pragma unroll 4
+    for (int st = 0; st < P / 2; ++st) {
+      const int pix = 2 * st;                      // (an even pixel and its right neighbour: the same row of the tile)
+      const int origin = ((pix / (ROWS * TW)) * PH + (pix / TW) % ROWS) * PW + pix % TW;
+      float a[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = a_base[mi][pix * 4];
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        const float b = b_base[(origin + (tap >> 1) * PW + (tap & 1)) * 4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[mi][tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b, acc[mi][tap], 0, 0, 0);
+      }
+    }
+  }
+
+  float* mine = p.partial + ((int64_t)blockIdx.x * p.walkers + walker) * (8 * 16 * 256) + tid;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[((mi * 4 + t) * 16 + r) * 256] = acc[mi][t][r];
+}
+
 // One workgroup per (block, row k of the block): 32 columns c x 16 taps = 512 floats; element (c, kh, kw) of row k at
 // gw[k * sk + c * sc + kh * 4 + kw].  Wave = parity (qy, qx) of the producing kernel, so the reader of (kh, kw) looks into
 // wave 2 (kh & 1) + (kw & 1), tap 2 (kh >> 1) + (kw >> 1); C/D row k % 32 = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column c = lane & 31.
+// The eight 32-lane groups of the workgroup take the walkers w = group, group + 8, ...: a lane adds its column of all sixteen
+// taps (sixteen independent 128-byte-run loads per walker), and the eight sums meet in a fixed tree -- the first version walked
+// up to 384 walkers serially in every thread (362 us for the three-channel first layer, profiles/r06l_*).
 __global__ __launch_bounds__(256) void hwgrad4x4s2_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                                  int32_t K, int32_t C, int32_t tiles_c, int32_t walkers, int64_t sk,
                                                                  int64_t sc) {
+  __shared__ float sums[8][16][32];
   const int block = (int)blockIdx.x / 64, row = (int)blockIdx.x % 64;
   const int tk = block / tiles_c, tc = block % tiles_c;
   const int k = tk * 64 + row;
   if (k >= K) return;
   const int64_t per_walker = 8 * 16 * 256;
   const int mi = row >> 5, r32 = row & 31, lhi = (r32 >> 2) & 1, r = (r32 & 3) + 4 * (r32 >> 3);
-  // thread t -> (tap16 = t >> 4 within two passes, c32): 512 outputs = 2 per thread; reads: for a fixed (wave, tap, r) the 32
-  // columns are 32 consecutive floats
+  const int c32 = (int)threadIdx.x & 31, part = (int)threadIdx.x >> 5;
+  const float* base = partial + (int64_t)block * walkers * per_walker + lhi * 32 + c32;
+  float total[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) total[t] = 0.f;
+  for (int w = part; w < walkers; w += 8) {
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int kh = t >> 2, kw = t & 3;
+      v[t] = base[(int64_t)w * per_walker + ((mi * 4 + 2 * (kh >> 1) + (kw >> 1)) * 16 + r) * 256 + (2 * (kh & 1) + (kw & 1)) * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) total[t] += v[t];
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) sums[part][t][c32] = total[t];
+  __syncthreads();
   for (int i = (int)threadIdx.x; i < 512; i += 256) {
-    const int tap16 = i >> 5, c32 = i & 31;
-    const int kh = tap16 >> 2, kw = tap16 & 3;
-    const int wave = 2 * (kh & 1) + (kw & 1), tap = 2 * (kh >> 1) + (kw >> 1);
-    const float* mine = partial + (int64_t)block * walkers * per_walker + ((mi * 4 + tap) * 16 + r) * 256 + wave * 64 + lhi * 32 + c32;
-    float total = 0.f;
-    for (int w = 0; w < walkers; ++w) total += mine[(int64_t)w * per_walker];
-    const int c = tc * 32 + c32;
-    if (c < C) gw[(int64_t)k * sk + (int64_t)c * sc + tap16] += total;
+    const int cc = i >> 4, t = i & 15;                    // consecutive threads: the 16 taps of one column = 64 contiguous bytes
+    const int c = tc * 32 + cc;
+    if (c < C)
+      gw[(int64_t)k * sk + (int64_t)c * sc + t] += ((sums[0][t][cc] + sums[1][t][cc]) + (sums[2][t][cc] + sums[3][t][cc])) +
+                                                   ((sums[4][t][cc] + sums[5][t][cc]) + (sums[6][t][cc] + sums[7][t][cc]));
   }
 }
 
 static int check_dtype_k(int dtype) {
-  SRGAN_REQUIRE(dtype == 1 || dtype == 2, SRGAN_EINVAL, "blocked 16-bit tensors are bf16 (1) or fp16 (2)");
+  SRGAN_REQUIRE(dtype >= 0 && dtype <= 2, SRGAN_EINVAL, "blocked tensors are fp32 (0: four channels per slot), bf16 (1) or fp16 (2)");
   return SRGAN_OK;
 }
+static inline int group_of(int dtype) { return dtype == 0 ? 4 : 8; }
 
 }  // namespace srgan
 
@@ -463,28 +626,34 @@ extern "C" {
 
 // 16-byte slots of one operand of a [A][B][4][4] weight tensor: direction 0 "down" (rows = A: the strided convolution's forward /
 // a transposed convolution's data gradient), 1 "up" (rows = B, all four output parity classes, class-major).
-int64_t srgan_h_k4s2_weight_slots(int32_t A, int32_t B, int direction) {
-  if (direction == 0) return (int64_t)((B + 7) / 8) * K4_TAPS * K4_CK * A;
-  return (int64_t)4 * (((A + 7) / 8 + K4_CK - 1) / K4_CK) * K4_TAPS * K4_CK * B;
+int64_t srgan_h_k4s2_weight_slots(int32_t A, int32_t B, int direction, int dtype) {
+  const int g = group_of(dtype);
+  if (direction == 0) return (int64_t)((B + g - 1) / g) * K4_TAPS * K4_CK * A;
+  return (int64_t)4 * (((A + g - 1) / g + K4_CK - 1) / K4_CK) * K4_TAPS * K4_CK * B;
 }
 
 int srgan_h_pack_k4s2_weights(const float* w, void* packed, int32_t A, int32_t B, int direction, int dtype, hipStream_t stream) {
   if (const int status = check_dtype_k(dtype)) return status;
   SRGAN_REQUIRE(w && packed && A > 0 && B > 0 && (direction == 0 || direction == 1), SRGAN_EINVAL, "srgan_h_pack_k4s2_weights arguments");
+#define K4_PACK(...)                                                                                                     \
+  do {                                                                                                                  \
+    if (dtype == 0) hipLaunchKernelGGL(h_pack_k4s2_weights_kernel<0>, __VA_ARGS__);                                     \
+    else if (dtype == 1) hipLaunchKernelGGL(h_pack_k4s2_weights_kernel<1>, __VA_ARGS__);                                \
+    else hipLaunchKernelGGL(h_pack_k4s2_weights_kernel<2>, __VA_ARGS__);                                                \
+  } while (0)
   if (direction == 0) {
-    const int64_t slots = srgan_h_k4s2_weight_slots(A, B, 0);
+    const int64_t slots = srgan_h_k4s2_weight_slots(A, B, 0, dtype);
     const dim3 grid((unsigned)((slots + 255) / 256));
-    if (dtype == 1) hipLaunchKernelGGL(h_pack_k4s2_weights_kernel<1>, grid, dim3(256), 0, stream, w, (Slot*)packed, slots, A, B, (int64_t)B * 16, (int64_t)16, 0);
-    else hipLaunchKernelGGL(h_pack_k4s2_weights_kernel<2>, grid, dim3(256), 0, stream, w, (Slot*)packed, slots, A, B, (int64_t)B * 16, (int64_t)16, 0);
+    K4_PACK(grid, dim3(256), 0, stream, w, (Slot*)packed, slots, A, B, (int64_t)B * 16, (int64_t)16, 0);
     return launch_status();
   }
-  const int64_t per_class = srgan_h_k4s2_weight_slots(A, B, 1) / 4;
+  const int64_t per_class = srgan_h_k4s2_weight_slots(A, B, 1, dtype) / 4;
   const dim3 grid((unsigned)((per_class + 255) / 256));
   for (int cls = 0; cls < 4; ++cls) {
     Slot* into = (Slot*)packed + cls * per_class;
-    if (dtype == 1) hipLaunchKernelGGL(h_pack_k4s2_weights_kernel<1>, grid, dim3(256), 0, stream, w, into, per_class, B, A, (int64_t)16, (int64_t)B * 16, 1 + cls);
-    else hipLaunchKernelGGL(h_pack_k4s2_weights_kernel<2>, grid, dim3(256), 0, stream, w, into, per_class, B, A, (int64_t)16, (int64_t)B * 16, 1 + cls);
+    K4_PACK(grid, dim3(256), 0, stream, w, into, per_class, B, A, (int64_t)16, (int64_t)B * 16, 1 + cls);
   }
+#undef K4_PACK
   return launch_status();
 }
 
@@ -498,42 +667,41 @@ int srgan_h_conv4x4s2(const void* x, const void* packed, const float* bias, cons
   HConv2Params p;
   p.in = (const Slot*)x; p.wp = (const Slot*)packed; p.out = (Slot*)out; p.bias = bias; p.ref = (const Slot*)ref;
   p.slope = slope; p.epi = epi;
-  p.N = N; p.CGI = (C_in + 7) / 8; p.IH = H; p.IW = W;
+  const int g = group_of(dtype);
+  p.N = N; p.CGI = (C_in + g - 1) / g; p.IH = H; p.IW = W;
   p.down = 1; p.oy = -1; p.ox = -1;
   p.GH = H / 2; p.GW = W / 2;
-  p.CGO = (rows + 7) / 8; p.OH = H / 2; p.OW = W / 2; p.dsy = p.dsx = 1; p.doy = p.dox = 0;
+  p.CGO = (rows + g - 1) / g; p.OH = H / 2; p.OW = W / 2; p.dsy = p.dsx = 1; p.doy = p.dox = 0;
   p.CO = rows; p.C_real = rows;
   p.chunks = p.CGI;
+  p.class_stride = 0;
   SRGAN_REQUIRE((int64_t)N * p.CGI * H * W < ((int64_t)1 << 31) && (int64_t)N * p.CGO * p.OH * p.OW < ((int64_t)1 << 31), SRGAN_ERANGE,
                 "srgan_h_conv4x4s2 tensor size");
-  return hconv2_run(p, dtype, (int64_t)p.CGI * 8 * 16, stream);
+  return hconv2_run(p, dtype, (int64_t)p.CGI * g * 16, stream);
 }
 
 // "up": out[N, rows, 2h, 2w] = epi(conv_transpose2d 4x4 / stride 2 / pad 1 of x[N, C_in, h, w]) with the direction-1 operand
-// (rows = its B, C_in = its A): four launches, one per output parity.
+// (rows = its B, C_in = its A): one launch, gridDim.y = the four output parity classes.
 int srgan_h_conv_transpose4x4s2(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi,
                                 void* out, int32_t N, int32_t C_in, int32_t rows, int32_t h, int32_t w, int dtype,
                                 hipStream_t stream) {
   if (const int status = check_dtype_k(dtype)) return status;
   SRGAN_REQUIRE(x && packed && out && N > 0 && C_in > 0 && rows > 0 && h > 0 && w > 0 && epi >= 0 && epi <= 2 && (epi != 2 || ref),
                 SRGAN_EINVAL, "srgan_h_conv_transpose4x4s2 arguments");
-  const int64_t per_class = srgan_h_k4s2_weight_slots(C_in, rows, 1) / 4;
-  for (int cls = 0; cls < 4; ++cls) {
-    const int ry = cls >> 1, rx = cls & 1;
-    HConv2Params p;
-    p.in = (const Slot*)x; p.wp = (const Slot*)packed + cls * per_class; p.out = (Slot*)out; p.bias = bias; p.ref = (const Slot*)ref;
-    p.slope = slope; p.epi = epi;
-    p.N = N; p.CGI = (C_in + 7) / 8; p.IH = h; p.IW = w;
-    p.down = 0; p.oy = ry == 0 ? -1 : 0; p.ox = rx == 0 ? -1 : 0;
-    p.GH = h; p.GW = w;
-    p.CGO = (rows + 7) / 8; p.OH = 2 * h; p.OW = 2 * w; p.dsy = p.dsx = 2; p.doy = ry; p.dox = rx;
-    p.CO = rows; p.C_real = rows;
-    p.chunks = (p.CGI + K4_CK - 1) / K4_CK;
-    SRGAN_REQUIRE((int64_t)N * p.CGI * h * w < ((int64_t)1 << 31) && (int64_t)N * p.CGO * p.OH * p.OW < ((int64_t)1 << 31), SRGAN_ERANGE,
-                  "srgan_h_conv_transpose4x4s2 tensor size");
-    if (const int status = hconv2_run(p, dtype, (int64_t)p.CGI * 8 * 4, stream)) return status;
-  }
-  return SRGAN_OK;
+  const int g = group_of(dtype);
+  HConv2Params p;
+  p.in = (const Slot*)x; p.wp = (const Slot*)packed; p.out = (Slot*)out; p.bias = bias; p.ref = (const Slot*)ref;
+  p.slope = slope; p.epi = epi;
+  p.N = N; p.CGI = (C_in + g - 1) / g; p.IH = h; p.IW = w;
+  p.down = 0; p.oy = p.ox = -1;                                  // (set per class in the kernel)
+  p.GH = h; p.GW = w;
+  p.CGO = (rows + g - 1) / g; p.OH = 2 * h; p.OW = 2 * w; p.dsy = p.dsx = 2; p.doy = p.dox = 0;
+  p.CO = rows; p.C_real = rows;
+  p.chunks = (p.CGI + K4_CK - 1) / K4_CK;
+  p.class_stride = srgan_h_k4s2_weight_slots(C_in, rows, 1, dtype) / 4;
+  SRGAN_REQUIRE((int64_t)N * p.CGI * h * w < ((int64_t)1 << 31) && (int64_t)N * p.CGO * p.OH * p.OW < ((int64_t)1 << 31), SRGAN_ERANGE,
+                "srgan_h_conv_transpose4x4s2 tensor size");
+  return hconv2_run(p, dtype, (int64_t)p.CGI * g * 4, stream);
 }
 
 // gw (fp32 [A][B][4][4] in torch's layout) += the weight gradient of the 4x4 / stride 2 / pad 1 pair from `small` [N, C_small, H/2,
@@ -545,15 +713,17 @@ int srgan_h_k4s2_wgrad(const void* big, const void* small, float* gw, int32_t N,
   SRGAN_REQUIRE(big && small && gw && N > 0 && C_big > 0 && C_small > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SRGAN_EINVAL,
                 "srgan_h_k4s2_wgrad arguments");
   HWgrad4Params p;
+  const int g = group_of(dtype);
   p.big = (const Slot*)big; p.small = (const Slot*)small;
-  p.N = N; p.CGB = (C_big + 7) / 8; p.CGS = (C_small + 7) / 8; p.H = H; p.W = W; p.SH = H / 2; p.SW = W / 2;
+  p.N = N; p.CGB = (C_big + g - 1) / g; p.CGS = (C_small + g - 1) / g; p.H = H; p.W = W; p.SH = H / 2; p.SW = W / 2;
   int tw = 32, best = 1 << 30;
   for (int candidate : {32, 16, 8, 4}) {
     const int covered = (p.SW + candidate - 1) / candidate * candidate;
     if (covered < best) { best = covered; tw = candidate; }
   }
-  const int rows = tw == 32 ? 2 : (tw == 16 ? 4 : tw);
-  const int img = 64 / (rows * tw);
+  const int pixels_per_tile = dtype == 0 ? 32 : 64;
+  const int rows = pixels_per_tile / tw > 0 ? (tw == 4 ? 4 : pixels_per_tile / tw) : 1;      // 32: 2 (1) rows, 16: 4 (2), 8: 8 (4), 4: 4
+  const int img = pixels_per_tile / (rows * tw);
   p.tiles_x = (p.SW + tw - 1) / tw;
   p.tiles_y = (p.SH + rows - 1) / rows;
   p.tiles_n = (N + img - 1) / img;
@@ -569,15 +739,16 @@ int srgan_h_k4s2_wgrad(const void* big, const void* small, float* gw, int32_t N,
   SRGAN_REQUIRE(p.partial, SRGAN_EINVAL, "srgan_h_k4s2_wgrad: register a workspace for this stream first (srgan_set_workspace)");
   const dim3 grid((unsigned)blocks, (unsigned)walkers);
   const int slot = profile_bracket_begin(stream);
-#define HWGRAD4_LAUNCH(TWv, ROWSv)                                                                                     \
+#define HWGRAD4_LAUNCH(TWv, ROWSv, ROWSf)                                                                              \
   do {                                                                                                                  \
-    if (dtype == 1) hipLaunchKernelGGL((hwgrad4x4s2_kernel<TWv, ROWSv, 1>), grid, dim3(256), 0, stream, p);           \
+    if (dtype == 0) hipLaunchKernelGGL((hwgrad4x4s2_f32_kernel<TWv, ROWSf>), grid, dim3(256), 0, stream, p);           \
+    else if (dtype == 1) hipLaunchKernelGGL((hwgrad4x4s2_kernel<TWv, ROWSv, 1>), grid, dim3(256), 0, stream, p);      \
     else hipLaunchKernelGGL((hwgrad4x4s2_kernel<TWv, ROWSv, 2>), grid, dim3(256), 0, stream, p);                      \
   } while (0)
-  if (tw == 32) HWGRAD4_LAUNCH(32, 2);
-  else if (tw == 16) HWGRAD4_LAUNCH(16, 4);
-  else if (tw == 8) HWGRAD4_LAUNCH(8, 8);
-  else HWGRAD4_LAUNCH(4, 4);
+  if (tw == 32) HWGRAD4_LAUNCH(32, 2, 1);
+  else if (tw == 16) HWGRAD4_LAUNCH(16, 4, 2);
+  else if (tw == 8) HWGRAD4_LAUNCH(8, 8, 4);
+  else HWGRAD4_LAUNCH(4, 4, 4);
 #undef HWGRAD4_LAUNCH
   const int64_t sk = small_is_rows ? (int64_t)C_big * 16 : 16, sc = small_is_rows ? 16 : (int64_t)C_small * 16;
   hipLaunchKernelGGL(hwgrad4x4s2_finish_kernel, dim3((unsigned)(blocks * 64)), dim3(256), 0, stream, p.partial, gw, C_small, C_big,

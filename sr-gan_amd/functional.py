@@ -30,13 +30,18 @@ COMPUTE_DTYPE = 0
 # tensors (the operands are rounded per fragment when COMPUTE_DTYPE asks for it), 1 / 2 = bf16 / fp16 tensors in the
 # blocked layout with fused activations.  Read when a network's forward runs.
 STORAGE_DTYPE = 0
+STORAGE_BLOCKED_F32 = 4        # 'f32b': fp32 tensors in the blocked layout (four channels per slot): the exact form of the 4x4 / s2 family
 
 
 class storage_dtype:
-    """``with F.storage_dtype('bf16'): ...`` -- networks with a 16-bit data path run it inside."""
+    """``with F.storage_dtype('bf16'): ...`` -- networks with a 16-bit data path run it inside; ``'f32b'``: the DCGAN stacks
+    run their 4x4 / stride 2 stages on fp32 tensors in the blocked layout (exact arithmetic, other kernels)."""
 
     def __init__(self, name):
-        self.code = (COMPUTE_DTYPES[name] if isinstance(name, str) else int(name)) if name else 0
+        if name == 'f32b':
+            self.code = STORAGE_BLOCKED_F32
+        else:
+            self.code = (COMPUTE_DTYPES[name] if isinstance(name, str) else int(name)) if name else 0
 
     def __enter__(self):
         global STORAGE_DTYPE

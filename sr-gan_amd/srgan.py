@@ -604,6 +604,10 @@ class Experiment(ABC):
         storage = getattr(self.settings, 'storage_dtype', None)
         if storage and F.COMPUTE_DTYPES[storage] == F.COMPUTE_DTYPES[name]:
             return _Contexts(F.compute_dtype(name), F.storage_dtype(storage))
+        # settings.blocked_fp32: a phase that computes in fp32 runs the DCGAN stacks' 4x4 / stride 2 stages on fp32 tensors in
+        # the blocked layout (exact arithmetic on the LDS-DMA kernels of csrc/blocked16_k4s2.hip)
+        if F.COMPUTE_DTYPES[name] == 0 and getattr(self.settings, 'blocked_fp32', False):
+            return _Contexts(F.compute_dtype(name), F.storage_dtype('f32b'))
         return _Contexts(F.compute_dtype(name), F.storage_dtype(None))
 
     def scaled_backward(self, root, **arguments):

@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODES = ['bf16', 'f16']
-TORCH = {'bf16': torch.bfloat16, 'f16': torch.float16}
+TORCH = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}
 
 
 @pytest.fixture(scope='module')
@@ -320,11 +320,12 @@ K4S2 = [(2, 64, 3, 64, 192), (3, 128, 64, 32, 96), (5, 72, 40, 16, 48), (9, 136,
         (33, 40, 16, 8, 8), (130, 32, 8, 4, 4)]
 
 
-@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('mode', MODES + ['f32'])
 @pytest.mark.parametrize('case', K4S2)
 def test_4x4_stride_2_family_is_exact_on_integers(F, B, mode, case):
     """conv2d / conv_transpose2d 4x4 / s2 / p1 (reference age/models.py:37-51,61-73): forward with the fused bias + leaky
-    epilogue, both data gradients with the mask epilogue, the weight gradient -- against the fp32 kernels, bit for bit."""
+    epilogue, both data gradients with the mask epilogue, the weight gradient -- against the fp32 kernels, bit for bit.  Mode
+    'f32' = fp32 tensors in the blocked layout (four channels per slot, v_mfma_f32_32x32x2_f32): the exact form."""
     n, a, b, h, w = case
     code = B.CODES[mode]
     conv = torch.nn.Conv2d(b, a, 4, 2, 1).cuda()
@@ -389,7 +390,7 @@ def test_seed_transposed_convolution_is_exact_on_integers(F, B, mode, case):
         assert torch.equal(into, torch.einsum('nk,ncrs->kcrs', z, g) + 1.0)
 
 
-def _dcgan_pass(F, size, storage, mode, second_order):
+def _dcgan_pass(F, size, storage, mode, second_order, conv_dim=32):
     """One DCGAN generator -> discriminator pass with a backward into both (and, optionally, the penalty's double backward
     through the discriminator) -> losses and the two gradient arenas."""
     import srgan_amd  # noqa: F401
@@ -397,7 +398,7 @@ def _dcgan_pass(F, size, storage, mode, second_order):
     from srgan_amd import nn
     from srgan_amd.tape import backward
     torch.manual_seed(2)
-    G, D = models.Generator(image_size=size, conv_dim=32), models.Discriminator(image_size=size, conv_dim=32)
+    G, D = models.Generator(image_size=size, conv_dim=conv_dim), models.Discriminator(image_size=size, conv_dim=conv_dim)
     with torch.no_grad():
         for module in D.modules():
             if isinstance(module, torch.nn.Conv2d):
@@ -405,7 +406,7 @@ def _dcgan_pass(F, size, storage, mode, second_order):
     for network in (G, D):
         nn.flatten_parameters(network, torch.device('cuda'))
     z = torch.randn(6, 256, generator=torch.Generator().manual_seed(3)).cuda()
-    with F.compute_dtype(mode), F.storage_dtype(mode if storage else None):
+    with F.compute_dtype('f32' if mode == 'f32b' else mode), F.storage_dtype(mode if storage else None):
         fake = G(F.leaf(z))
         scores = D(fake)
         loss = F.add(F.mean_all(F.square(scores)), F.mean_all(F.abs_(D.features)))
@@ -439,6 +440,19 @@ def test_dcgan_pair_matches_the_fp32_storage_path(F, size, second_order):
         assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99
 
 
+@pytest.mark.parametrize('size,conv_dim', [(64, 64), ((64, 192), 32), (32, 16)])
+def test_dcgan_pair_on_blocked_fp32_equals_the_nchw_kernels(F, size, conv_dim):
+    """The exact form (fp32 tensors, four channels per slot): generator and discriminator stages on the blocked kernels
+    against the fp32 NCHW kernels -- the same fp32 products in another summation order: 1e-5 of the scale, first and second
+    order."""
+    loss_a, penalty_a, g_a, d_a, fake_a = _dcgan_pass(F, size, False, 'f32b', True, conv_dim)
+    loss_b, penalty_b, g_b, d_b, fake_b = _dcgan_pass(F, size, True, 'f32b', True, conv_dim)
+    assert (fake_a - fake_b).abs().max().item() <= 1e-5, (fake_a - fake_b).abs().max().item()
+    assert abs(loss_a - loss_b) <= 1e-5 * abs(loss_a) and penalty_a > 1e-3 and abs(penalty_a - penalty_b) <= 1e-4 * penalty_a
+    for a, b in ((g_a, g_b), (d_a, d_b)):
+        assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item(), ((a - b).abs().max().item(), a.abs().max().item())
+
+
 @pytest.mark.parametrize('batch', [8, 128])
 def test_driving_step_on_fp16_storage_against_the_fp32_oracle(batch):
     """BASELINE.json configs[4] on the 16-bit data path (fp16 tensors in the blocked layout for D / DNN / G, the gradient-penalty
@@ -459,3 +473,15 @@ def test_driving_step_on_fp16_storage_against_the_fp32_oracle(batch):
                               settings_overrides=dict(compute_dtype='f16', gradient_penalty_dtype='f32', storage_dtype='f16',
                                                       loss_scale=256.0),
                               tolerance=2e-2)
+
+
+@pytest.mark.parametrize('name,steps', [('g7b_crowd64', 2), ('g7c_crowd64_gp_active', 1)])
+def test_blocked_fp32_stages_in_a_crowd_step_match_the_goldens(F, name, steps):
+    """``settings.blocked_fp32``: the crowd generator's 4x4 / stride 2 transposed convolutions (reference
+    crowd/models.py:132-146) on fp32 tensors in the blocked layout -- forward in the discriminator and generator steps, data
+    and weight gradients in the generator step -- against the reference-generated goldens (forward outputs, every logged loss,
+    the post-step weights), 1e-3."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import srgan_amd
+    import test_steps_gpu as reference_tests
+    reference_tests.test_crowd_steps(srgan_amd, name, 64, steps, False, extra_settings=dict(blocked_fp32=True))

@@ -4,7 +4,7 @@ The step tests inject z_D / alpha / z_G from the goldens; here nothing is inject
 `dataset_setup`, `model_setup`, loaders and `Experiment.draw_*` must walk the NumPy / torch host streams exactly as
 the reference does (utility.py:102-116, srgan.py:286-289,301,364, coefficient/srgan.py:17-38).  CPU only: the draws are
 host tensors on both sides (the reference's device draw of alpha came from the CPU generator when the goldens were made).
-The same sequence through an un-injected training step on the device is tests/test_round5_gpu.py."""
+The same sequence through an un-injected training step on the device is tests/test_reference_runs_gpu.py."""
 import numpy as np
 import torch
 

@@ -1,5 +1,6 @@
-"""Round-3 GPU checks of host-side mechanisms around the kernels: cached launch tables against changed batch-norm
-statistics, the side-stream schedules against the goldens, the forced data-parallel bench line."""
+"""Host-side mechanisms around the kernels on the device: the side-stream schedules (DNN step, gradient-penalty chain, D(unlabeled)
+on streams of their own) against the goldens and on NaN-poisoned allocations, and the cached launch tables of the fused dense
+blocks against changed batch-norm statistics."""
 import json
 import os
 import subprocess
@@ -137,22 +138,3 @@ def test_side_streams_on_poisoned_allocations(pkg, single_stream_afterwards, mon
     reference_tests.test_crowd_steps(pkg, name, SIZE, steps, reference_schedule, streams=True)
 
 
-def _bench_line(*arguments, environment=None):
-    """bench.py as the driver starts it (a fresh process), small settings; returns rank 0's JSON line."""
-    command = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--image-size', '64',
-               '--batch-per-gpu', '2', '--no-cpu-baseline', '--no-roofline'] + list(arguments)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(environment or {}))
-    done = subprocess.run(command, capture_output=True, text=True, timeout=900, env=env)
-    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
-    return json.loads([line for line in done.stdout.splitlines() if line.startswith('{')][-1])
-
-
-def test_bench_with_the_exchanges_forced_through_rccl_on_one_rank(pkg):
-    """``bench.py --gpus 1 --force-dp --backend nccl``: an nccl (= RCCL) process group of one rank, every collective of the
-    data-parallel path on it; the last step's gradient penalty must equal the plain run's."""
-    plain = _bench_line()
-    forced = _bench_line('--force-dp', '--backend', 'nccl')
-    assert 'forced' in forced['config']['parallelism'] and 'nccl' in forced['config']['gradient_exchange']
-    a, b = plain['config']['gradient_penalty_last'], forced['config']['gradient_penalty_last']
-    # (the third training step on noise: rounding-level differences of the first two Adam updates have grown to ~5e-4)
-    assert a > 0 and abs(a - b) <= 5e-3 * abs(a), (a, b)

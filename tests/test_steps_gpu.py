@@ -230,7 +230,7 @@ def crowd_inputs(generator, batch, size):
 @pytest.mark.parametrize('name,size,steps,reference_schedule', [
     ('g7b_crowd64', 64, 2, False), ('g7b_crowd64', 64, 1, True), ('g7c_crowd64_gp_active', 64, 1, False),
     ('g7c_crowd64_gp_active', 64, 1, True), ('g7_crowd224', 224, 1, False)])
-def test_crowd_steps(pkg, name, size, steps, reference_schedule, overlap=False, streams=False):
+def test_crowd_steps(pkg, name, size, steps, reference_schedule, overlap=False, streams=False, extra_settings=None):
     from srgan_amd.crowd.models import DCGenerator, KnnDenseNetCat
     g = load_golden(name)
     batch = int(g['batch_size'])
@@ -239,7 +239,7 @@ def test_crowd_steps(pkg, name, size, steps, reference_schedule, overlap=False, 
         dict(batch_size=batch, matching_loss_multiplier=1e3, contrasting_loss_multiplier=1e2,
              gradient_penalty_multiplier=1e2, map_multiplier=1e-3, reference_schedule=reference_schedule,
              overlap_dnn_step=overlap or streams, wgrad_stream=streams, overlap_generator_forwards=streams,
-             overlap_gradient_penalty=streams), crowd=True)
+             overlap_gradient_penalty=streams, **(extra_settings or {})), crowd=True)
     scale = float(g['d_scale'])
     if scale != 1.0:
         with torch.no_grad():
@@ -402,7 +402,7 @@ def test_crowd_step_at_the_benchmark_size_matches_the_oracle(pkg):
             assert np.abs(got - expected).mean() <= 2e-5 + 1e-4 * np.abs(expected).mean(), f'{name} {pname} (mean)'
 
 
-def _hip_and_oracle_step(experiment_class, configure, oracle_networks, size, batch, d_scale):
+def _hip_and_oracle_step(experiment_class, configure, oracle_networks, size, batch, d_scale, settings_overrides=None):
     """One dnn + gan step of a task experiment on the HIP path and of the oracle composed from the same
     architecture, from identical weights (state copied HIP -> oracle), inputs and random draws."""
     import os
@@ -417,6 +417,8 @@ def _hip_and_oracle_step(experiment_class, configure, oracle_networks, size, bat
     settings.batch_size = batch
     settings.matching_loss_multiplier, settings.contrasting_loss_multiplier = 1e2, 1e1
     settings.gradient_penalty_multiplier = 1e2
+    for key, value in (settings_overrides or {}).items():
+        setattr(settings, key, value)
     experiment = experiment_class(settings)
     configure(experiment)
     seed_all(0)

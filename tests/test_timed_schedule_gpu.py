@@ -1,4 +1,4 @@
-"""Round-4 GPU checks: the schedule bench.py TIMES, at the size it is timed at (VERDICT r3 "What's weak" 1).
+"""The schedule bench.py TIMES, at the size it is timed at (four streams; the same chains as branches of one HIP graph).
 
 ``bench.py`` runs its timed region on four streams (main chain, gradient-penalty chain into the arena's alternate gradient
 buffer, the DNN step never joined across iterations, D(unlabeled) of the generator step) and, with ``--step-graph``, as
@@ -101,7 +101,7 @@ def compare_hip_runs(a_losses, b_losses, a, b, first_rtol, later_rtol, lr=1e-4):
 
 
 def _host_memory_gib():
-    from test_parity_holes_gpu import _host_memory_gib as available
+    from test_config_parity_gpu import _host_memory_gib as available
     return available()
 
 
@@ -266,115 +266,6 @@ def test_two_captured_graphs_alternating_in_one_memory_pool(pkg):
     for name in ('D', 'DNN', 'G'):
         difference = (getattr(replayed, name)._srgan_arena.data - getattr(eager, name)._srgan_arena.data).abs()
         assert float(difference.max()) <= 2.2e-4 * iterations, name
-
-
-def test_bf16_pack_and_unpack_kernels(pkg):
-    """``srgan_pack_bf16`` / ``srgan_unpack_bf16`` (the bf16 gradient buckets): round to nearest even, bit-identical to
-    torch's conversion, NaN and infinities kept, lengths that are no multiple of 8."""
-    from srgan_amd import _lib
-    lib = _lib.library()
-    generator = torch.Generator().manual_seed(3)
-    for n in (1, 7, 8, 1000003):
-        values = torch.randn(n, generator=generator) * torch.logspace(-20, 20, n)
-        values[0] = float('inf')
-        if n > 4:
-            values[1], values[2], values[3], values[4] = float('-inf'), float('nan'), 0.0, -0.0
-        source = values.cuda()
-        packed = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
-        _lib.check(lib.srgan_pack_bf16(source.data_ptr(), packed.data_ptr(), n, _lib.stream_handle()), 'srgan_pack_bf16')
-        expected = values.to(torch.bfloat16)
-        got = packed.cpu()
-        finite = ~torch.isnan(expected)
-        assert torch.equal(got.view(torch.int16)[finite], expected.view(torch.int16)[finite]), n
-        assert bool(torch.isnan(got[~finite]).all())
-        back = torch.full((n,), 7.0, device='cuda')
-        _lib.check(lib.srgan_unpack_bf16(packed.data_ptr(), back.data_ptr(), n, _lib.stream_handle()), 'srgan_unpack_bf16')
-        assert torch.equal(back.cpu()[finite], expected.float()[finite]), n
-
-
-def _exchange_worker(rank, world, port, backend, queue):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    import srgan_amd  # noqa: F401
-    from srgan_amd.parallel import DataParallel, GradientExchange
-    torch.cuda.set_device(0)
-    dp = DataParallel.from_environment(backend, force=True)
-    generator = torch.Generator().manual_seed(50 + rank)
-    source = torch.randn(3000004, generator=generator) * torch.logspace(-6, 2, 3000004)
-    results = {}
-    for wire, form in (('f32', 'all_reduce'), ('f32', 'reduce_scatter'), ('bf16', 'all_reduce'), ('bf16', 'reduce_scatter')):
-        flat = source.cuda()
-        exchange = GradientExchange(dp, flat, bucket_elements=1 << 20, min_bucket_elements=1 << 12, wire=wire, form=form)
-        exchange.ready_from(2999000 // 4 * 4)        # (16-byte aligned offsets, as the arena's parameter offsets are)
-        exchange.ready_from(1200004)
-        exchange.finish().wait()
-        torch.cuda.synchronize()
-        results[f'{wire}/{form}'] = (flat.cpu().numpy(), list(exchange.launched))
-    queue.put((rank, source.numpy(), results))
-    dp.barrier()
-    torch.distributed.destroy_process_group()
-
-
-@pytest.mark.parametrize('backend,world', [('nccl', 1), ('gloo', 2), ('nccl', 2)])
-def test_gradient_exchange_forms_on_the_device(pkg, backend, world):
-    """The exchange on DEVICE buffers through the library's staging kernels: one rank over nccl (= RCCL; all-reduce,
-    reduce-scatter and all-gather of a world of one are identities, so the fp32 forms return the input bit for bit and the
-    bf16 forms its bf16 rounding), two ranks sharing this GPU over gloo, two ranks over nccl when the box has two GPUs."""
-    import socket
-    import torch.multiprocessing as mp
-    if backend == 'nccl' and world > torch.cuda.device_count():
-        pytest.skip('two ranks over nccl (RCCL) need two GPUs; this box has %d (the world-size-1 nccl case ran)'
-                    % torch.cuda.device_count())
-    with socket.socket() as probe:
-        probe.bind(('127.0.0.1', 0))
-        port = probe.getsockname()[1]
-    context = mp.get_context('spawn')
-    queue = context.Queue()
-    workers = [context.Process(target=_exchange_worker, args=(rank, world, port, backend, queue)) for rank in range(world)]
-    for worker in workers:
-        worker.start()
-    outputs = sorted((queue.get(timeout=600) for _ in workers), key=lambda item: item[0])
-    for worker in workers:
-        worker.join(timeout=120)
-        assert worker.exitcode == 0
-    sources = [output[1] for output in outputs]
-    exact = sum(sources[1:], sources[0].copy())
-    scale = np.max(np.abs(np.stack(sources)), axis=0)
-    for key in outputs[0][2]:
-        values, launched = outputs[0][2][key]
-        for other in outputs[1:]:
-            np.testing.assert_array_equal(values, other[2][key][0])
-            assert launched == other[2][key][1]
-        assert launched[-1][0] == 0 and len(launched) >= 4
-        if key.startswith('f32/'):
-            np.testing.assert_array_equal(values, exact)
-        elif world == 1:
-            np.testing.assert_array_equal(values, torch.from_numpy(exact).to(torch.bfloat16).float().numpy())
-        else:
-            assert np.all(np.abs(values - exact) <= 4 * 2.0 ** -8 * scale + 1e-30), key
-    import conftest
-    conftest.PARITY_NOTES.append(f'gradient exchange on device buffers over {backend}, world size {world}: fp32 / bf16 buckets x '
-                                 'all-reduce / reduce-scatter + all-gather agree')
-
-
-def test_bench_line_with_bf16_buckets_and_reduce_scatter_over_rccl(pkg):
-    """``bench.py --force-dp --backend nccl --grad-wire bf16 --exchange-form reduce_scatter``: the whole timed loop with
-    every gradient arena exchanged as bf16 reduce-scatter + all-gather buckets through RCCL on one rank; the line carries
-    the schedule check (three compute streams under data parallelism against one)."""
-    from test_round3_gpu import _bench_line
-    line = _bench_line('--force-dp', '--backend', 'nccl', '--grad-wire', 'bf16', '--exchange-form', 'reduce_scatter')
-    config = line['config']
-    assert config['gradient_wire'] == 'bf16' and config['gradient_exchange_form'] == 'reduce_scatter'
-    assert 'saw 1 ranks' in config['collective_world'] and len(config['per_rank_ms_per_step']) == 1
-    assert 'THREE compute streams' in config['streams']
-    # (the gradients went through bf16: the schedule check compares two runs that both did, so it still holds)
-    def held(check):      # ONE comparison against the fixed limit (round 5: no repetition, no limit scaled by the schedule's own noise)
-        return check['within_limit'] and check['max_relative_loss_difference'] <= check['limit']
-    assert held(config['schedule_check']), config['schedule_check']
-    plain = _bench_line()
-    assert held(plain['config']['schedule_check']), plain['config']['schedule_check']
-    a, b = plain['config']['gradient_penalty_last'], config['gradient_penalty_last']
-    assert a > 0 and b > 0 and abs(a - b) <= 0.1 * abs(a), (a, b)     # (two Adam updates from bf16-rounded gradients)
 
 
 def test_driving_validation_mae_after_twenty_fp16_steps_matches_the_fp32_oracle(pkg):
