@@ -652,7 +652,7 @@ def main():
     del snapshot
     per_rank_ms = None
     if dp is not None:
-        own = torch.zeros(world, dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+        own = torch.zeros(world, dtype=torch.float64, device=dp._scalar_device())
         own[rank] = 1e3 * elapsed / args.steps
         per_rank_ms = [round(v, 3) for v in dp.all_reduce_sum_(own).tolist()]
         elapsed = dp.all_reduce_max_float(elapsed)
@@ -712,8 +712,14 @@ def main():
     result['config']['schedule_check'] = check if check is not None else 'not applicable: the timed region ran on one stream, eagerly'
     if dp is not None:
         import torch.distributed as dist
-        result['config']['collective_world'] = (f'{dist.get_backend()} ({"RCCL" if dist.get_backend() == "nccl" else "host"}) saw '
-                                                f'{dist.get_world_size()} ranks')
+        if dp.abi is not None:
+            seen = f'RCCL communicator of the C ABI (srgan_comm_init) saw {dp.abi.world_size} ranks'
+        else:
+            seen = (f'{dp.device_backend or dp.host_backend} ({"RCCL" if dp.device_backend == "nccl" else "host"}) saw '
+                    f'{dist.get_world_size()} ranks')
+        result['config']['collective_world'] = seen
+        result['config']['collective_transport'] = dp.transport
+        result['config']['control_plane'] = f'torch.distributed ({dp.host_backend or dp.device_backend})' 
         result['config']['per_rank_ms_per_step'] = per_rank_ms
         result['config']['gradient_wire'] = getattr(experiment.settings, 'gradient_wire_dtype', None) or 'f32'
         result['config']['gradient_exchange_form'] = getattr(experiment.settings, 'gradient_exchange_form', None) or 'all_reduce'
@@ -796,12 +802,16 @@ def main():
         torch.cuda.synchronize()
         result['secondary'] = {'age_vgg_bf16': secondary_line('age-vgg-bf16', args.secondary_steps),
                                'driving_fp16': secondary_line('driving-fp16', args.secondary_steps)}
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if dp is not None:
         dp.barrier()
         experiment.close()                        # the C ABI's communicator, before the process group goes
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is flushed when the process exits -- i.e. AFTER a Python print:
+        # push it out first, so that the JSON line is the last line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
     return 0
 
 

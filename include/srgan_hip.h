@@ -17,9 +17,10 @@
  *     srgan_last_error is thread-local); two threads must not launch on the SAME stream with the same workspace
  *     concurrently, as with any stream-ordered resource.
  *   - collectives: thin RCCL entry points (srgan_comm_*, srgan_all_reduce_sum, srgan_reduce_scatter_sum,
- *     srgan_all_gather, at the end of this file) carry the data-parallel exchange for a caller without torch.distributed;
- *     the Python host keeps torch.distributed (backend "nccl" = the same RCCL over xGMI) as its default transport and can
- *     be switched onto these entry points (`SRGAN_ABI_COLLECTIVES=1`, sr-gan_amd/parallel.py), see INTEGRATION.md.
+ *     srgan_all_gather, srgan_broadcast, at the end of this file) carry the data-parallel exchange for a caller without
+ *     torch.distributed; they are the Python host's default device transport as well (sr-gan_amd/parallel.py: torch.distributed
+ *     keeps the rendezvous and the host-side control messages; `SRGAN_ABI_COLLECTIVES=0` puts the device collectives back on
+ *     torch.distributed's "nccl" backend = the same RCCL over xGMI), see INTEGRATION.md.
  *   - `stream` is a hipStream_t (NULL = default stream); every call is asynchronous on it.
  *   - `accumulate` != 0 adds into the existing output (gradient accumulation across the four
  *     discriminator backward passes, reference srgan.py:280-295) instead of overwriting it.
@@ -398,6 +399,9 @@ int srgan_all_reduce_sum(void* comm, const void* send, void* recv, int64_t count
  * of the sum of send[0 .. world * recv_count); all_gather puts rank r's send_count elements at [r, r + 1) * send_count */
 int srgan_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t recv_count, int32_t dtype, void* stream);
 int srgan_all_gather(void* comm, const void* send, void* recv, int64_t send_count, int32_t dtype, void* stream);
+/* ABI 1.1: buffer[0 .. count) of rank `root` to every rank, in place (ncclBroadcast): the initial weights, so that a caller whose
+ * control plane is a host channel (TCP store, gloo) needs no second device transport */
+int srgan_broadcast(void* comm, void* buffer, int64_t count, int32_t dtype, int32_t root, void* stream);
 
 /* ---- 16-bit data path (ABI 1.1; BASELINE.json configs[1] "bf16" and configs[4] "fp16") ---------------------------------
  * "Blocked" tensors: logical [N, C, H, W] stored as [N][ceil(C / 8)][H][W][8] elements of bf16 (`dtype` 1) or fp16 (2); the 8

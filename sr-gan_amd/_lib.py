@@ -135,6 +135,7 @@ SIGNATURES = {
     'srgan_all_reduce_sum': ([vp, vp, vp, i64, i32, vp], ctypes.c_int),
     'srgan_reduce_scatter_sum': ([vp, vp, vp, i64, i32, vp], ctypes.c_int),
     'srgan_all_gather': ([vp, vp, vp, i64, i32, vp], ctypes.c_int),
+    'srgan_broadcast': ([vp, vp, i64, i32, i32, vp], ctypes.c_int),
 }
 
 

@@ -29,6 +29,7 @@ struct Rccl {
   Result (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   Result (*ReduceScatter)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   Result (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+  Result (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(Result) = nullptr;
   bool ok = false;
 };
@@ -56,7 +57,8 @@ const Rccl* rccl() {
     g_rccl.ok = resolve(g_rccl.GetUniqueId, "ncclGetUniqueId") && resolve(g_rccl.CommInitRank, "ncclCommInitRank") &&
                 resolve(g_rccl.CommDestroy, "ncclCommDestroy") && resolve(g_rccl.CommCount, "ncclCommCount") &&
                 resolve(g_rccl.AllReduce, "ncclAllReduce") && resolve(g_rccl.ReduceScatter, "ncclReduceScatter") &&
-                resolve(g_rccl.AllGather, "ncclAllGather") && resolve(g_rccl.GetErrorString, "ncclGetErrorString");
+                resolve(g_rccl.AllGather, "ncclAllGather") && resolve(g_rccl.Broadcast, "ncclBroadcast") &&
+                resolve(g_rccl.GetErrorString, "ncclGetErrorString");
   });
   return g_rccl.ok ? &g_rccl : nullptr;
 }
@@ -151,6 +153,15 @@ int srgan_all_gather(void* comm, const void* send, void* recv, int64_t send_coun
   SRGAN_REQUIRE(r, SRGAN_EUNSUPPORTED, "srgan_all_gather: librccl.so.1 could not be loaded");
   if (send_count == 0) return SRGAN_OK;
   SRGAN_RCCL(r, r->AllGather(send, recv, (size_t)send_count, wire_type(dtype), comm, (hipStream_t)stream), "ncclAllGather");
+  return SRGAN_OK;
+}
+
+int srgan_broadcast(void* comm, void* buffer, int64_t count, int32_t dtype, int32_t root, void* stream) {
+  SRGAN_REQUIRE(comm && buffer && count >= 0 && root >= 0 && wire_type(dtype) >= 0, SRGAN_EINVAL, "srgan_broadcast arguments");
+  const Rccl* r = rccl();
+  SRGAN_REQUIRE(r, SRGAN_EUNSUPPORTED, "srgan_broadcast: librccl.so.1 could not be loaded");
+  if (count == 0) return SRGAN_OK;
+  SRGAN_RCCL(r, r->Broadcast(buffer, buffer, (size_t)count, wire_type(dtype), root, comm, (hipStream_t)stream), "ncclBroadcast");
   return SRGAN_OK;
 }
 

@@ -87,7 +87,8 @@ class GradientExchange:
         self.works = []
         self.pending = []                   # (staging buffer, first, stop): unpacked / copied back in wait()
         self.launched = []                  # (start, stop) of every bucket, in launch order (tests / diagnostics)
-        self.in_order = dist.get_backend(dp.group) == 'nccl'    # one communication stream: collectives run in issue order
+        # one communication stream (RCCL through either transport): collectives run in issue order
+        self.in_order = getattr(dp, 'abi', None) is not None or getattr(dp, 'device_backend', None) == 'nccl'
 
     def _bucket(self, first, stop):
         """Start the sum of flat[first:stop]."""
@@ -250,6 +251,13 @@ class AbiCommunicator:
         return self._on_communication_stream(lambda stream: self.check(self.lib.srgan_all_gather(
             self.comm, shard.data_ptr(), tensor.data_ptr(), shard.numel(), wire, stream), 'srgan_all_gather'), shard, tensor)
 
+    def broadcast_(self, tensor, source=0):
+        """Rank ``source``'s ``tensor`` to every rank, in place; the current stream continues behind it."""
+        wire = self._wire(tensor)
+        self._on_communication_stream(lambda stream: self.check(self.lib.srgan_broadcast(
+            self.comm, tensor.data_ptr(), tensor.numel(), wire, source, stream), 'srgan_broadcast'), tensor).wait()
+        return tensor
+
     def close(self):
         if self.comm is not None and self.comm.value:
             torch.cuda.synchronize()
@@ -257,7 +265,26 @@ class AbiCommunicator:
             self.comm = None
 
 
+def _backend_of(group, device_type):
+    """Name of the backend that serves ``device_type`` tensors in ``group`` ('nccl', 'gloo', ...) or None."""
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    try:
+        return pg._get_backend(torch.device(device_type)).name().lower()
+    except Exception:
+        return None
+
+
 class DataParallel:
+    """One process per GPU.  Two planes:
+
+    * CONTROL (rendezvous, the trial-directory / stdin objects, barriers, the bench's max-over-ranks scalars): ``torch.distributed``
+      on host tensors when the group has a host backend (``from_environment`` initialises ``cpu:gloo,cuda:nccl``), otherwise
+      on device tensors through nccl;
+    * DATA (the feature sums, the gradient buckets, the initial weight broadcast): RCCL over xGMI -- by default through the C
+      ABI's own entry points (``AbiCommunicator``: one communicator, one communication stream this process owns, so the
+      exchanges are capturable and the process runs FOUR streams = the runtime's four hardware queues; with torch's NCCL
+      stream next to it a fifth stream aliased a chain onto another's queue: 81.5 against 85.1 images/s on the forced world-1
+      line, profiles/r06q_*), or with ``SRGAN_ABI_COLLECTIVES=0`` through ``torch.distributed``'s nccl backend."""
     force = False
     abi = None           # an AbiCommunicator when the exchanges go through the C ABI's RCCL entry points
 
@@ -267,19 +294,36 @@ class DataParallel:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        self.host_backend = _backend_of(group, 'cpu')                 # 'gloo' or None
+        self.device_backend = _backend_of(group, 'cuda') if torch.cuda.is_available() else None   # 'nccl', 'gloo' or None
         # ``force``: run every exchange even on a world of one (SRGAN_FORCE_DP=1, ``bench.py --force-dp``).  Two ranks
         # cannot share a device under RCCL, one rank can: this is how a one-GPU box pushes the feature-sum all-reduce, the
-        # asynchronous gradient buckets, their stream-side ``wait()`` and the broadcasts through the nccl backend.
+        # asynchronous gradient buckets, their stream-side ``wait()`` and the broadcasts through RCCL.
         self.force = bool(int(os.environ.get('SRGAN_FORCE_DP', '0'))) if force is None else bool(force)
-        if os.environ.get('SRGAN_ABI_COLLECTIVES') == '1' and torch.cuda.is_available():
+        wanted = os.environ.get('SRGAN_ABI_COLLECTIVES')
+        if wanted == '1' and torch.cuda.is_available():
             self.use_abi_collectives()
+        elif wanted is None and self.device_backend == 'nccl' and self.host_backend is not None:
+            # the default device transport where RCCL is the device backend and a host channel can carry the unique id
+            # without waking torch's own communicator; a box without librccl keeps torch.distributed, and says so
+            try:
+                self.use_abi_collectives()
+            except Exception as error:
+                print(f'[srgan_amd] C-ABI collectives unavailable ({error}); the device collectives stay on torch.distributed',
+                      flush=True)
 
     def use_abi_collectives(self):
-        """Route the feature-sum all-reduce and the gradient buckets through the C ABI's RCCL entry points
-        (``SRGAN_ABI_COLLECTIVES=1``); rendezvous, broadcasts and barriers stay on the process group."""
+        """Route the feature-sum all-reduce, the gradient buckets and the weight broadcast through the C ABI's RCCL entry
+        points; rendezvous, object broadcasts and barriers stay on the process group."""
         if self.abi is None:
             self.abi = AbiCommunicator(self)
         return self.abi
+
+    @property
+    def transport(self):
+        if self.abi is not None:
+            return 'RCCL through the C ABI (srgan_all_reduce_sum / _reduce_scatter_sum / _all_gather / _broadcast)'
+        return f'torch.distributed ({self.device_backend or self.host_backend})'
 
     @property
     def active(self):
@@ -293,6 +337,12 @@ class DataParallel:
                 backend = 'nccl' if torch.cuda.is_available() else 'gloo'
             if backend == 'nccl' and 'LOCAL_RANK' in os.environ and torch.cuda.device_count() > 1:
                 torch.cuda.set_device(int(os.environ['LOCAL_RANK']))
+            if backend == 'nccl' and dist.is_gloo_available():
+                # host tensors (objects, barriers, scalars) over gloo, device tensors over RCCL: torch's own RCCL communicator
+                # and its stream only come into being if a device tensor is ever handed to torch.distributed
+                if os.environ.get('MASTER_ADDR', '') in ('127.0.0.1', 'localhost'):
+                    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')      # (the container's hostname may not resolve)
+                backend = 'cpu:gloo,cuda:nccl'
             dist.init_process_group(backend=backend)
         return cls(force=force)
 
@@ -312,20 +362,25 @@ class DataParallel:
 
     # ---- collectives -----------------------------------------------------------------------------------
     def all_reduce_sum_(self, tensor):
+        if self.abi is not None and tensor.is_cuda:
+            return self.abi.all_reduce_sum_(tensor)
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
     def all_reduce_sum_autograd(self, tensor):
         return _AllReduceSum.apply(tensor, self.group)
 
+    def _scalar_device(self):
+        return 'cpu' if self.host_backend is not None else torch.device('cuda', torch.cuda.current_device())
+
     def all_reduce_sum_float(self, value):
-        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        device = self._scalar_device()
         holder = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(holder, op=dist.ReduceOp.SUM, group=self.group)
         return float(holder.item())
 
     def all_reduce_max_float(self, value):
-        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        device = self._scalar_device()
         holder = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(holder, op=dist.ReduceOp.MAX, group=self.group)
         return float(holder.item())
@@ -365,14 +420,19 @@ class DataParallel:
     def broadcast_object(self, value, source=0):
         """A small picklable host object from rank ``source`` to every rank (trial directory, stdin commands)."""
         holder = [value if self.rank == source else None]
-        dist.broadcast_object_list(holder, src=source, group=self.group,
-                                   device=torch.device('cuda', torch.cuda.current_device())
-                                   if dist.get_backend(self.group) == 'nccl' else None)
+        dist.broadcast_object_list(holder, src=source, group=self.group, device=torch.device(self._scalar_device()))
         return holder[0]
 
     def broadcast_parameters(self, arena, source=0):
         """Make every rank start from rank ``source``'s weights."""
-        dist.broadcast(arena.data, src=source, group=self.group)
+        if self.abi is not None and arena.data.is_cuda:
+            self.abi.broadcast_(arena.data, source)
+        else:
+            dist.broadcast(arena.data, src=source, group=self.group)
 
     def barrier(self):
-        dist.barrier(group=self.group)
+        """Host-side meeting point of the ranks (the caller synchronises its device around it where it times something)."""
+        if self.host_backend is not None:
+            dist.all_reduce(torch.zeros(1), group=self.group)       # host tensors: no device transport involved
+        else:
+            dist.barrier(group=self.group)

@@ -271,8 +271,8 @@ class Experiment(ABC):
     def _exchanges_are_capturable(self):
         """True when this run's iterations can be captured as HIP graphs.  Single device: always.  Data parallel: only when the
         caller OPTED IN with ``settings.step_graph_collectives = 'abi'`` -- the exchanges then run through the C ABI's RCCL entry
-        points on a stream this process owns (``DataParallel.use_abi_collectives``; a second communicator next to torch's,
-        destroyed by ``close()``) and are captured with the iteration; collectives that go through a host-side process group
+        points on a stream this process owns (``DataParallel.use_abi_collectives``, the default device transport; destroyed by
+        ``close()``) and are captured with the iteration; collectives that go through a host-side process group
         (gloo, torch's own NCCL work queue) keep the run eager.  No setting is modified: the compute side streams are switched
         off for such a run through ``_stream_setting`` (hipStreamEndCapture crashes -- ROCm 7.0 runtime, a segmentation fault
         inside capture_end, round 5 -- when a capture holds the compute side streams AND the communication stream)."""
@@ -284,7 +284,7 @@ class Experiment(ABC):
                       '(the C ABI\'s RCCL entry points); running eagerly')
                 self._graph_note = True
             return False
-        if getattr(self.dp, 'abi', None) is None and torch.distributed.get_backend(self.dp.group) == 'nccl':
+        if getattr(self.dp, 'abi', None) is None and getattr(self.dp, 'device_backend', None) == 'nccl':
             self.dp.use_abi_collectives()
         if getattr(self.dp, 'abi', None) is None:
             return False

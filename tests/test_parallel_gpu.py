@@ -93,7 +93,7 @@ def _worker(rank, world_size, port, queue, backend='gloo', force=False, streams=
     import srgan_amd  # noqa: F401
     from srgan_amd.parallel import DataParallel
     dp = DataParallel.from_environment(backend, force=force)
-    assert torch.distributed.get_backend() == backend
+    assert (dp.device_backend if backend == 'nccl' else dp.host_backend) == backend, (dp.device_backend, dp.host_backend)
     if force:                                            # what Experiment.train() does before the first step
         assert dp.broadcast_object({'trial': 'x', 'skip': False}) == {'trial': 'x', 'skip': False}
     assert (dp.abi is not None) == bool(abi)
@@ -112,7 +112,15 @@ def _run_ranks(world_size, backend, force=False, streams=False, normalize=False,
                for rank in range(world_size)]
     for worker in workers:
         worker.start()
-    outputs = [queue.get(timeout=600) for _ in workers]
+    import queue as queues
+    outputs, waited = [], 0
+    while len(outputs) < len(workers):
+        try:
+            outputs.append(queue.get(timeout=5))
+        except queues.Empty:
+            waited += 5
+            dead = [worker.exitcode for worker in workers if worker.exitcode not in (None, 0)]
+            assert not dead and waited < 600, f'a rank died (exit codes {dead}) or nothing arrived for {waited} s'
     for worker in workers:
         worker.join(timeout=120)
         assert worker.exitcode == 0
