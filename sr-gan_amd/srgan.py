@@ -275,7 +275,8 @@ class Experiment(ABC):
         ``close()``) and are captured with the iteration; collectives that go through a host-side process group
         (gloo, torch's own NCCL work queue) keep the run eager.  No setting is modified: the compute side streams are switched
         off for such a run through ``_stream_setting`` (hipStreamEndCapture crashes -- ROCm 7.0 runtime, a segmentation fault
-        inside capture_end, round 5 -- when a capture holds the compute side streams AND the communication stream)."""
+        inside capture_end, round 5; re-tested in round 6 with the process on four streams: gpurun_out/r6u -- when a capture holds
+        the compute side streams AND the communication stream)."""
         if not self.parallel:
             return True
         if getattr(self.settings, 'step_graph_collectives', None) != 'abi':
