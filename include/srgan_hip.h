@@ -456,6 +456,17 @@ int srgan_h_linear_wgrad(const void* s, const void* x, float* gw, int32_t N, int
  * crowd generator, reference crowd/models.py:132-146). */
 int64_t srgan_h_k4s2_weight_slots(int32_t A, int32_t B, int direction, int dtype);
 int srgan_h_pack_k4s2_weights(const float* w, void* packed, int32_t A, int32_t B, int direction, int dtype, void* stream);
+/* The batched form of the two weight packers above: every convolution shadow of a network re-rounded by ONE launch behind its
+ * optimizer update.  The caller keeps a device array of jobs, srgan_h_pack_job_bytes() each; a job function takes the arguments
+ * of its single-layer call, writes the job(s) at `jobs` (HOST memory; the "up" direction of the 4x4 family writes four) with
+ * workgroups from `first_block` on and returns the number of workgroups they take (< 0: error); srgan_h_pack_batched launches
+ * `count` jobs of `blocks` workgroups in total from the device copy of the array. */
+int32_t srgan_h_pack_job_bytes(void);
+int64_t srgan_h_pack_job_conv_weights(void* jobs, int64_t first_block, const float* w, void* packed, int32_t K, int32_t C, int32_t R,
+                                      int32_t S, int transposed, int dtype);
+int64_t srgan_h_pack_job_k4s2_weights(void* jobs, int64_t first_block, const float* w, void* packed, int32_t A, int32_t B,
+                                      int direction, int dtype, int32_t* jobs_written);
+int srgan_h_pack_batched(const void* jobs_device, int32_t count, int64_t blocks, void* stream);
 int srgan_h_conv4x4s2(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi, void* out,
                       int32_t N, int32_t C_in, int32_t rows, int32_t H, int32_t W, int dtype, void* stream);
 int srgan_h_conv_transpose4x4s2(const void* x, const void* packed, const float* bias, const void* ref, float slope, int epi,

@@ -124,6 +124,10 @@ SIGNATURES = {
     'srgan_h_linear_wgrad': ([vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i32, i32, ctypes.c_int, vp], ctypes.c_int),
     'srgan_h_k4s2_weight_slots': ([i32, i32, ctypes.c_int, ctypes.c_int], ctypes.c_int64),
     'srgan_h_pack_k4s2_weights': ([vp, vp, i32, i32, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),
+    'srgan_h_pack_job_bytes': ([], ctypes.c_int32),
+    'srgan_h_pack_job_conv_weights': ([vp, i64, vp, vp, i32, i32, i32, i32, ctypes.c_int, ctypes.c_int], ctypes.c_int64),
+    'srgan_h_pack_job_k4s2_weights': ([vp, i64, vp, vp, i32, i32, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int64),
+    'srgan_h_pack_batched': ([vp, i32, i64, vp], ctypes.c_int),
     'srgan_h_conv4x4s2': ([vp, vp, vp, vp, f32, ctypes.c_int, vp, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),
     'srgan_h_conv_transpose4x4s2': ([vp, vp, vp, vp, f32, ctypes.c_int, vp, i32, i32, i32, i32, i32, ctypes.c_int, vp], ctypes.c_int),
     'srgan_h_k4s2_wgrad': ([vp, vp, vp, i32, i32, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp], ctypes.c_int),

@@ -19,6 +19,8 @@ piecewise linear, so every backward operation is again "a linear map, then a mas
 backward is the same kind of call with the roles swapped (the LINEARISED forward: ``conv(s, W) * mask(ref')``) plus a
 weight gradient from (tangent, first-backward gradient), so the recorded backward and its double backward reuse the
 forward kernels; masks and arg-max positions are constants."""
+import os
+
 import torch
 
 from . import _lib
@@ -217,10 +219,7 @@ class Shadow:
         weight = self.module.weight
         lib, stream, device = _lib.library(), F._stream(), weight.device
 
-        def buffer(name, slots):
-            if getattr(self, name, None) is None:
-                setattr(self, name, torch.empty(slots * 4, dtype=torch.int32, device=device))
-            return getattr(self, name).data_ptr()
+        buffer = self._buffer
         if self.kind == 'conv3x3':
             k, c, r, s = weight.shape
             for name, transposed, rows, reduced in (('forward', 0, k, c), ('transposed', 1, c, k)):
@@ -260,6 +259,12 @@ class Shadow:
             raise ValueError(self.kind)
         self.key = self._version()
 
+    def _buffer(self, name, slots):
+        """The device buffer of one operand form (``slots`` 16-byte slots), allocated on first use and then kept."""
+        if getattr(self, name, None) is None:
+            setattr(self, name, torch.empty(slots * 4, dtype=torch.int32, device=self.module.weight.device))
+        return getattr(self, name).data_ptr()
+
     def _version(self):
         weight = self.module.weight
         arena = getattr(weight, '_srgan_arena', None)
@@ -277,11 +282,75 @@ def shadow_of(module, kind, code, in_blocked=0, plane=1):
     return found.fresh()
 
 
+class _PackPlan:
+    """The convolution shadows of one arena as ONE launch (``srgan_h_pack_batched``): a device array of jobs, built once from
+    the arguments the single-layer packers would get -- the masters live at fixed arena addresses and a shadow keeps its
+    buffers, so the table stays valid until the set of shadows changes."""
+
+    def __init__(self, shadows):
+        import ctypes
+        lib = _lib.library()
+        size = lib.srgan_h_pack_job_bytes()
+        self.shadows = list(shadows)
+        self.signature = tuple((id(s), s.module.weight.data_ptr()) for s in self.shadows)
+        host = ctypes.create_string_buffer(size * 5 * max(1, len(self.shadows)))
+        count = blocks = 0
+        written = ctypes.c_int32()
+        device = None
+        for shadow in self.shadows:
+            weight = shadow.module.weight
+            device = weight.device
+            if shadow.kind == 'conv3x3':
+                k, c, r, s = weight.shape
+                for name, transposed, rows, reduced in (('forward', 0, k, c), ('transposed', 1, c, k)):
+                    target = shadow._buffer(name, lib.srgan_h_conv_weight_slots(rows, reduced, r, s))
+                    taken = lib.srgan_h_pack_job_conv_weights(ctypes.byref(host, count * size), blocks, weight.data_ptr(), target,
+                                                              k, c, r, s, transposed, shadow.code)
+                    _lib.check(min(taken, 0), 'srgan_h_pack_job_conv_weights')
+                    count, blocks = count + 1, blocks + taken
+            else:                                           # 'k4s2'
+                a, b = weight.shape[0], weight.shape[1]
+                for name, direction in (('down', 0), ('up', 1)):
+                    target = shadow._buffer(name, lib.srgan_h_k4s2_weight_slots(a, b, direction, shadow.code))
+                    taken = lib.srgan_h_pack_job_k4s2_weights(ctypes.byref(host, count * size), blocks, weight.data_ptr(), target,
+                                                              a, b, direction, shadow.code, ctypes.byref(written))
+                    _lib.check(min(taken, 0), 'srgan_h_pack_job_k4s2_weights')
+                    count, blocks = count + written.value, blocks + taken
+        self.count, self.blocks = count, blocks
+        self.table = None
+        if count:
+            self.table = torch.frombuffer(bytearray(host.raw[:count * size]), dtype=torch.uint8).to(device)
+
+    def run(self):
+        if self.table is not None:
+            _call('srgan_h_pack_batched', self.table.data_ptr(), self.count, self.blocks, F._stream())
+        for shadow in self.shadows:
+            shadow.key = shadow._version()
+
+
+BATCHED_KINDS = ('conv3x3', 'k4s2')
+
+
 def refresh(arena):
     """Re-round every shadow of the networks' weights in ``arena`` (called right behind the optimizer update, on its stream:
-    whatever orders a later reader behind the update orders it behind the shadows too)."""
-    for shadow in getattr(arena, 'shadows', ()):
-        shadow.repack()
+    whatever orders a later reader behind the update orders it behind the shadows too).  The convolution shadows go as one
+    batched launch, the few matrix shadows (linear layers) one by one."""
+    shadows = getattr(arena, 'shadows', ())
+    if not shadows:
+        return
+    batched = [s for s in shadows if s.kind in BATCHED_KINDS]
+    plan = getattr(arena, '_pack_plan', None)
+    if batched and os.environ.get('SRGAN_H_NO_BATCHED_PACK') != '1':
+        signature = tuple((id(s), s.module.weight.data_ptr()) for s in batched)
+        if plan is None or plan.signature != signature:
+            plan = arena._pack_plan = _PackPlan(batched)
+        plan.run()
+    else:
+        for shadow in batched:
+            shadow.repack()
+    for shadow in shadows:
+        if shadow.kind not in BATCHED_KINDS:
+            shadow.repack()
 
 
 # ------------------------------------------------------------------------------------------------ fused layers

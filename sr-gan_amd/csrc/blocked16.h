@@ -137,6 +137,68 @@ __device__ __forceinline__ void h_glds16(const void* lane_pointer, uint32_t lds_
 template <int N> __device__ __forceinline__ void h_dma_wait_and_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
 }
+// ---- weight-shadow packers: the bodies (one thread = one slot) are shared by the single-layer kernels and by the batched
+// launch that re-rounds every convolution shadow of a network behind its optimizer update (h_pack_batched_kernel, blocked16.hip)
+constexpr int K4_CK = 4;          // k-slots per chunk of the 4x4 / stride 2 family (blocked16_k4s2.hip)
+constexpr int K4_TAPS = 4;
+
+// conv weights (R x S taps) as the operand of the LDS-staged kernels: slot (chunk, tap, half g, row o) holds the 8 reduced
+// channels chunk * 16 + g * 8 .. + 7 of row o at that tap.
+template <int PREC>
+__device__ __forceinline__ void h_pack_conv_weights_slot(const float* __restrict__ w, Slot* __restrict__ packed, int64_t slot,
+                                                         int32_t CO, int32_t CI, int32_t R, int32_t S, int32_t base, int32_t so,
+                                                         int32_t si, int32_t skh, int32_t skw) {
+  const int T = R * S;
+  const int o = (int)(slot % CO);
+  const int64_t rest = slot / CO;
+  const int g = (int)(rest & 1);
+  const int64_t ct = rest >> 1;
+  const int tap = (int)(ct % T), chunk = (int)(ct / T);
+  const int kh = tap / S, kw = tap - kh * S;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = chunk * 16 + g * 8 + j;
+    v[j] = c < CI ? w[base + o * so + c * si + kh * skh + kw * skw] : 0.f;
+  }
+  packed[slot] = h_pack8<PREC>(v);
+}
+
+// 4x4 / stride 2 weights as 2x2-tap operands (mode 0: "down", 1 .. 4: the "up" parity classes; layout in blocked16_k4s2.hip)
+template <int PREC>
+__device__ __forceinline__ void h_pack_k4s2_weights_slot(const float* __restrict__ w, Slot* __restrict__ packed, int64_t slot,
+                                                         int32_t rows, int32_t reduced, int64_t row_stride, int64_t reduced_stride,
+                                                         int32_t mode) {
+  const int o = (int)(slot % rows);
+  int64_t rest = slot / rows;
+  const int j = (int)(rest % K4_CK); rest /= K4_CK;
+  const int tap = (int)(rest % K4_TAPS);
+  const int chunk = (int)(rest / K4_TAPS);
+  const int a = tap >> 1, b = tap & 1;
+  constexpr int G = HGroup<PREC>::N;
+  int kh, kw, first;
+  if (mode == 0) { kh = 2 * a + (j >> 1); kw = 2 * b + (j & 1); first = G * chunk; }
+  else {
+    const int ry = (mode - 1) >> 1, rx = (mode - 1) & 1;
+    kh = ry == 0 ? 3 - 2 * a : 2 - 2 * a;
+    kw = rx == 0 ? 3 - 2 * b : 2 - 2 * b;
+    first = G * (K4_CK * chunk + j);
+  }
+  float v[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i)
+    v[i] = first + i < reduced ? w[o * row_stride + (int64_t)(first + i) * reduced_stride + kh * 4 + kw] : 0.f;
+  packed[slot] = h_pack<PREC>(v);
+}
+
+// one problem of the batched launch (80 bytes, filled on the host by srgan_h_pack_job_*)
+struct HPackJob {
+  const float* w; Slot* packed;
+  int64_t slots, first_block;       // this job's workgroups are [first_block, first_block + ceil(slots / 256))
+  int32_t kind, prec;               // kind 0: conv weights, 1: 4x4 / stride 2 weights; prec = dtype
+  int32_t p[10];                    // the body's integer arguments, in its order
+};
+
 const struct Slot* h_zero_slots();      // 64 bytes of zeros in device memory (blocked16.hip): the source of padding slots
 
 // Declared in gather_gemm_kernels.hip: the bench's live event bracket around a contraction launch, with explicit bytes.

@@ -13,6 +13,7 @@
 //                                                                      an ordered finish (bit-reproducible)
 //   pool / pack / unpack / add / channel sums                          HBM-bound streaming kernels on 16-byte slots
 #include <type_traits>
+#include <string.h>
 #include "blocked16.h"
 #include "split_finish.h"
 #include <stdlib.h>
@@ -219,20 +220,31 @@ __global__ __launch_bounds__(256) void h_pack_conv_weights_kernel(const float* _
                                                                   int32_t base, int32_t so, int32_t si, int32_t skh, int32_t skw) {
   const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (slot >= slots) return;
-  const int T = R * S;
-  const int o = (int)(slot % CO);
-  const int64_t rest = slot / CO;
-  const int g = (int)(rest & 1);
-  const int64_t ct = rest >> 1;
-  const int tap = (int)(ct % T), chunk = (int)(ct / T);
-  const int kh = tap / S, kw = tap - kh * S;
-  float v[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = chunk * 16 + g * 8 + j;
-    v[j] = c < CI ? w[base + o * so + c * si + kh * skh + kw * skw] : 0.f;
+  h_pack_conv_weights_slot<PREC>(w, packed, slot, CO, CI, R, S, base, so, si, skh, skw);
+}
+
+// Every convolution shadow of one network in ONE launch: a workgroup finds its job by bisection over the jobs' first blocks
+// (wave-uniform), then runs that job's body.  A step of the driving configuration re-rounds 80 operands, of the VGG
+// configuration 52: as single launches they were 0.45 / 0.34 ms of 5 us kernels with the launch gaps on top.
+__global__ __launch_bounds__(256) void h_pack_batched_kernel(const HPackJob* __restrict__ jobs, int32_t count) {
+  int lo = 0, hi = count - 1;
+  const int64_t block = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= block) lo = mid; else hi = mid - 1;
   }
-  packed[slot] = h_pack8<PREC>(v);
+  const HPackJob job = jobs[lo];
+  const int64_t slot = (block - job.first_block) * 256 + threadIdx.x;
+  if (slot >= job.slots) return;
+  const int32_t* q = job.p;
+  if (job.kind == 0) {
+    if (job.prec == 1) h_pack_conv_weights_slot<1>(job.w, job.packed, slot, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]);
+    else h_pack_conv_weights_slot<2>(job.w, job.packed, slot, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]);
+  } else {
+    if (job.prec == 0) h_pack_k4s2_weights_slot<0>(job.w, job.packed, slot, q[0], q[1], q[2], q[3], q[4]);
+    else if (job.prec == 1) h_pack_k4s2_weights_slot<1>(job.w, job.packed, slot, q[0], q[1], q[2], q[3], q[4]);
+    else h_pack_k4s2_weights_slot<2>(job.w, job.packed, slot, q[0], q[1], q[2], q[3], q[4]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- 3x3 convolution
@@ -866,6 +878,24 @@ static int check_dtype_or_f32(int dtype) {        // the layout conversions and 
 
 using namespace srgan;
 
+extern "C" int64_t srgan_h_k4s2_weight_slots(int32_t A, int32_t B, int direction, int dtype);     // (blocked16_k4s2.hip)
+
+namespace srgan {
+// the job (= the single-layer kernel's arguments) of one conv-weight operand; transposed: rows = C, taps mirrored
+static void conv_weights_job(HPackJob& job, const float* w, void* packed, int32_t K, int32_t C, int32_t R, int32_t S, int transposed,
+                             int dtype) {
+  memset(&job, 0, sizeof(job));
+  const int rows = transposed ? C : K, reduced = transposed ? K : C;
+  job.w = w; job.packed = (Slot*)packed; job.kind = 0; job.prec = dtype;
+  job.slots = (int64_t)((reduced + 15) / 16) * R * S * 2 * rows;
+  job.p[0] = rows; job.p[1] = reduced; job.p[2] = R; job.p[3] = S;
+  job.p[4] = transposed ? R * S - 1 : 0;                    // base
+  job.p[5] = transposed ? R * S : C * R * S;                // row stride
+  job.p[6] = transposed ? C * R * S : R * S;                // reduced-channel stride
+  job.p[7] = transposed ? -S : S; job.p[8] = transposed ? -1 : 1;
+}
+}  // namespace srgan
+
 extern "C" {
 
 int srgan_h_pack(const float* x, void* out, const void* mask_ref, float slope, int32_t N, int32_t C, int64_t HW, int dtype,
@@ -970,13 +1000,57 @@ int srgan_h_pack_conv_weights(const float* w, void* packed, int32_t K, int32_t C
                               hipStream_t stream) {
   if (const int status = check_dtype(dtype)) return status;
   SRGAN_REQUIRE(w && packed && K > 0 && C > 0 && R > 0 && S > 0, SRGAN_EINVAL, "srgan_h_pack_conv_weights arguments");
-  const int rows = transposed ? C : K, reduced = transposed ? K : C;
-  const int64_t slots = srgan_h_conv_weight_slots(rows, reduced, R, S);
-  const int so = transposed ? R * S : C * R * S, si = transposed ? C * R * S : R * S;
-  const int base = transposed ? R * S - 1 : 0, skh = transposed ? -S : S, skw = transposed ? -1 : 1;
-  const dim3 grid((unsigned)((slots + 255) / 256));
-  if (dtype == 1) hipLaunchKernelGGL(h_pack_conv_weights_kernel<1>, grid, dim3(256), 0, stream, w, (Slot*)packed, slots, rows, reduced, R, S, base, so, si, skh, skw);
-  else hipLaunchKernelGGL(h_pack_conv_weights_kernel<2>, grid, dim3(256), 0, stream, w, (Slot*)packed, slots, rows, reduced, R, S, base, so, si, skh, skw);
+  HPackJob job;
+  conv_weights_job(job, w, packed, K, C, R, S, transposed, dtype);
+  const dim3 grid((unsigned)((job.slots + 255) / 256));
+  const int32_t* q = job.p;
+  if (dtype == 1) hipLaunchKernelGGL(h_pack_conv_weights_kernel<1>, grid, dim3(256), 0, stream, w, (Slot*)packed, job.slots, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]);
+  else hipLaunchKernelGGL(h_pack_conv_weights_kernel<2>, grid, dim3(256), 0, stream, w, (Slot*)packed, job.slots, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]);
+  return launch_status();
+}
+
+// ---- the batched form: the caller keeps a device array of jobs (srgan_h_pack_job_bytes() each), filled on the host by the two
+// functions below with the arguments of the single-layer calls, and launches them all at once.  A job function writes its jobs
+// at `jobs` (host memory) with workgroups from `first_block` on and returns the number of workgroups they take (< 0: error).
+int32_t srgan_h_pack_job_bytes(void) { return (int32_t)sizeof(HPackJob); }
+
+int64_t srgan_h_pack_job_conv_weights(void* jobs, int64_t first_block, const float* w, void* packed, int32_t K, int32_t C, int32_t R,
+                                      int32_t S, int transposed, int dtype) {
+  if (const int status = check_dtype(dtype)) return status;
+  SRGAN_REQUIRE(jobs && first_block >= 0 && w && packed && K > 0 && C > 0 && R > 0 && S > 0, SRGAN_EINVAL,
+                "srgan_h_pack_job_conv_weights arguments");
+  HPackJob job;
+  conv_weights_job(job, w, packed, K, C, R, S, transposed, dtype);
+  job.first_block = first_block;
+  memcpy(jobs, &job, sizeof(job));
+  return (job.slots + 255) / 256;
+}
+
+int64_t srgan_h_pack_job_k4s2_weights(void* jobs, int64_t first_block, const float* w, void* packed, int32_t A, int32_t B,
+                                      int direction, int dtype, int32_t* jobs_written) {
+  SRGAN_REQUIRE(dtype >= 0 && dtype <= 2, SRGAN_EINVAL, "srgan_h_pack_job_k4s2_weights dtype");
+  SRGAN_REQUIRE(jobs && first_block >= 0 && w && packed && A > 0 && B > 0 && (direction == 0 || direction == 1) && jobs_written,
+                SRGAN_EINVAL, "srgan_h_pack_job_k4s2_weights arguments");
+  const int64_t slots = srgan_h_k4s2_weight_slots(A, B, direction, dtype) / (direction ? 4 : 1);
+  const int64_t blocks = (slots + 255) / 256;
+  const int count = direction ? 4 : 1;
+  for (int cls = 0; cls < count; ++cls) {
+    HPackJob job;
+    memset(&job, 0, sizeof(job));
+    job.w = w; job.packed = (Slot*)packed + cls * slots; job.slots = slots; job.first_block = first_block + cls * blocks;
+    job.kind = 1; job.prec = dtype;
+    // the body's (rows, reduced, row_stride, reduced_stride, mode): "down" reads w[A][B] as rows A, "up" as rows B
+    job.p[0] = direction ? B : A; job.p[1] = direction ? A : B;
+    job.p[2] = direction ? 16 : B * 16; job.p[3] = direction ? B * 16 : 16; job.p[4] = direction ? 1 + cls : 0;
+    memcpy((char*)jobs + cls * sizeof(job), &job, sizeof(job));
+  }
+  *jobs_written = count;
+  return count * blocks;
+}
+
+int srgan_h_pack_batched(const void* jobs_device, int32_t count, int64_t blocks, hipStream_t stream) {
+  SRGAN_REQUIRE(jobs_device && count > 0 && blocks > 0 && blocks < ((int64_t)1 << 31), SRGAN_EINVAL, "srgan_h_pack_batched arguments");
+  hipLaunchKernelGGL(h_pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const HPackJob*)jobs_device, count);
   return launch_status();
 }
 

@@ -28,8 +28,6 @@ namespace srgan {
 
 float* partial_workspace(size_t bytes, hipStream_t stream);
 
-constexpr int K4_CK = 4;          // k-slots per chunk
-constexpr int K4_TAPS = 4;
 
 // (G = channels per slot: 8, or 4 for the fp32 form)
 // mode 0 ("down"): slot (chunk, tap = 2a + b, j = 2 qy + qx, o) = G reduced channels G chunk .. of w[o][.][2a + qy][2b + qx]
@@ -42,26 +40,7 @@ __global__ __launch_bounds__(256) void h_pack_k4s2_weights_kernel(const float* _
                                                                   int64_t reduced_stride, int32_t mode) {
   const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (slot >= slots) return;
-  const int o = (int)(slot % rows);
-  int64_t rest = slot / rows;
-  const int j = (int)(rest % K4_CK); rest /= K4_CK;
-  const int tap = (int)(rest % K4_TAPS);
-  const int chunk = (int)(rest / K4_TAPS);
-  const int a = tap >> 1, b = tap & 1;
-  constexpr int G = HGroup<PREC>::N;
-  int kh, kw, first;
-  if (mode == 0) { kh = 2 * a + (j >> 1); kw = 2 * b + (j & 1); first = G * chunk; }
-  else {
-    const int ry = (mode - 1) >> 1, rx = (mode - 1) & 1;
-    kh = ry == 0 ? 3 - 2 * a : 2 - 2 * a;
-    kw = rx == 0 ? 3 - 2 * b : 2 - 2 * b;
-    first = G * (K4_CK * chunk + j);
-  }
-  float v[G];
-#pragma unroll
-  for (int i = 0; i < G; ++i)
-    v[i] = first + i < reduced ? w[o * row_stride + (int64_t)(first + i) * reduced_stride + kh * 4 + kw] : 0.f;
-  packed[slot] = h_pack<PREC>(v);
+  h_pack_k4s2_weights_slot<PREC>(w, packed, slot, rows, reduced, row_stride, reduced_stride, mode);
 }
 
 struct HConv2Params {

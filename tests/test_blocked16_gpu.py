@@ -294,6 +294,51 @@ def test_shadows_follow_the_optimizer(F, B):
     assert torch.allclose(after.data, want.data, rtol=3e-2, atol=3e-2 * want.data.abs().max().item())
 
 
+def test_batched_shadow_refresh_equals_the_single_layer_packers(F, B, monkeypatch):
+    """``refresh(arena)`` re-rounds every convolution shadow of a network in ONE launch (srgan_h_pack_batched) from a device
+    job table; the result must be the single-layer packers' bit for bit -- 3x3 shadows in bf16 (VGG) and the 4x4 / stride 2
+    shadows in fp16 and in blocked fp32 (the DCGAN discriminator: down and the four up classes)."""
+    from srgan_amd import nn
+    from srgan_amd.age.models import Discriminator
+    from srgan_amd.utility import seed_all
+    seed_all(3)
+    vgg = _vgg(32, 1.0)
+    dcgan = Discriminator(image_size=64)
+    nn.flatten_parameters(dcgan, torch.device('cuda'))
+    with F.compute_dtype('bf16'), F.storage_dtype('bf16'):
+        vgg(F.leaf((torch.rand(2, 3, 32, 32) * 2 - 1).cuda()))
+    x = F.leaf((torch.rand(2, 3, 64, 64) * 2 - 1).cuda())
+    with F.compute_dtype('f16'), F.storage_dtype('f16'):
+        dcgan(x)
+    with F.compute_dtype('f32'), F.storage_dtype('f32b'):
+        dcgan(x)
+    checked = 0
+    for model in (vgg, dcgan):
+        arena = model._srgan_arena
+        shadows = [s for s in arena.shadows if s.kind in B.BATCHED_KINDS]
+        assert shadows
+        with torch.no_grad():
+            arena.data.mul_(1.37).add_(0.01)
+        forms = ('forward', 'transposed', 'down', 'up')
+        monkeypatch.setenv('SRGAN_H_NO_BATCHED_PACK', '1')
+        B.refresh(arena)
+        single = [[getattr(s, name).clone() for name in forms if getattr(s, name) is not None] for s in shadows]
+        for s in shadows:
+            for name in forms:
+                if getattr(s, name) is not None:
+                    getattr(s, name).fill_(-1)
+        monkeypatch.delenv('SRGAN_H_NO_BATCHED_PACK')
+        B.refresh(arena)
+        assert arena._pack_plan.count >= 2 * len(shadows)
+        for s, want in zip(shadows, single):
+            got = [getattr(s, name) for name in forms if getattr(s, name) is not None]
+            assert len(got) == len(want) == 2
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (s.kind, s.code)
+                checked += 1
+    assert checked >= 2 * (13 + 2 * 4)
+
+
 @pytest.mark.parametrize('batch', [8, 128])
 def test_age_vgg_step_on_bf16_storage_against_the_fp32_oracle(monkeypatch, batch):
     """BASELINE.json configs[1] on the 16-bit data path (bf16 activations / gradients / weight shadows in the blocked layout,
