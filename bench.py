@@ -58,8 +58,8 @@ WORKLOADS = {
                                        matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
                                        gradient_penalty_multiplier=1e2),
                          name='age SRGAN, VGG-16 D/DNN + DCGAN G on 64x64 faces (BASELINE.json configs[1]), bf16: activations, gradients '
-                              'and weight shadows of D / DNN stored as bf16 in the blocked layout with fused activations (gradient-penalty '
-                              'chain included), fp32 master weights / Adam / losses; the DCGAN generator on fp32 tensors with bf16 MFMA operands'),
+                              'and weight shadows of the three networks stored as bf16 in the blocked layout with fused activations (gradient-penalty '
+                              'chain included), fp32 master weights / Adam / losses'),
     'driving-fp16': dict(application='driving', image_size=(64, 192), batch_per_gpu=128, gp_scale=3.0, dtype='f16',
                          settings=dict(compute_dtype='f16', gradient_penalty_dtype='f32', storage_dtype='f16', loss_scale=256.0,
                                        matching_loss_multiplier=1e2, contrasting_loss_multiplier=1e1,
