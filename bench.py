@@ -124,7 +124,7 @@ def parse():
     parser.add_argument('--no-secondary', action='store_true',
                         help='crowd headline on one GPU: do not append the two mixed-precision configurations (age-vgg-bf16, '
                              'driving-fp16) as `secondary` entries (each is this script run as a child process)')
-    parser.add_argument('--secondary-steps', type=int, default=30, help='timed steps of each secondary configuration')
+    parser.add_argument('--secondary-steps', type=int, default=100, help='timed steps of each secondary configuration')
     return parser.parse_args()
 
 
@@ -325,7 +325,8 @@ def schedule_check(experiment, labeled, unlabeled, step):
 
 
 def pmc_traffic(args):
-    """(HBM bytes per contraction launch, provenance) from the committed rocprofv3 PMC passes -- FETCH_SIZE x 2 +
+    """(HBM bytes of the contraction kernels of ONE step -- the caller divides by its own bracketed launches --, provenance)
+    from the committed rocprofv3 PMC passes -- FETCH_SIZE x 2 +
     WRITE_SIZE per the guide's gfx950 correction, see profiles/README.md -- or (None, reason) unless the file was
     measured at THIS image size and batch on THESE kernel sources.  PMC collection needs rocprofv3 around the process, so
     it cannot be measured from inside this script; a constant from another configuration is not a measurement."""
@@ -339,7 +340,7 @@ def pmc_traffic(args):
     for entry in entries:
         if (entry.get('workload', 'crowd') == args.workload and entry.get('image_size') == size and
                 entry.get('batch_per_gpu') == args.batch_per_gpu and entry.get('kernel_source_id') == _build.source_id()):
-            return entry['hbm_bytes_per_launch'], entry.get('source', path)
+            return entry['hbm_bytes_per_step'], entry.get('source', path)
     return None, (f'no PMC entry for workload {args.workload}, image size {size}, batch {args.batch_per_gpu}, kernel sources '
                   f'{_build.source_id()}')
 
@@ -759,6 +760,8 @@ def main():
                 handle.write(text.value.decode())
         achieved = flops.value / (kernel_ms.value * 1e-3) / 1e12 if kernel_ms.value > 0 else 0.0
         traffic, traffic_source = pmc_traffic(args)
+        if traffic is not None:                    # per launch like `achieved`: the counters' step total over THIS step's brackets
+            traffic = traffic / max(launches.value, 1)
         step_seconds = elapsed / args.steps
         result['roofline'] = {
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

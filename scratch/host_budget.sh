@@ -13,11 +13,13 @@ run() {  # <name> <cpus or all> <bench arguments...>
 }
 for cpus in all 0,1; do
   c=${cpus/,/_}
+  # (dp_eager = the default transport: RCCL through the C ABI; dp_torch = SRGAN_ABI_COLLECTIVES=0: torch.distributed's nccl backend)
   run crowd512_dp_eager_$c $cpus --force-dp --backend nccl
   run crowd224_dp_eager_$c $cpus --force-dp --backend nccl --image-size 224
   run driving_dp_eager_$c $cpus --force-dp --backend nccl --workload driving-fp16
-  SRGAN_ABI_COLLECTIVES=1 run crowd512_dp_abi_$c $cpus --force-dp --backend nccl
-  SRGAN_ABI_COLLECTIVES=1 run crowd224_dp_abi_$c $cpus --force-dp --backend nccl --image-size 224
+  run age_dp_eager_$c $cpus --force-dp --backend nccl --workload age-vgg-bf16
+  SRGAN_ABI_COLLECTIVES=0 run crowd512_dp_torch_$c $cpus --force-dp --backend nccl
+  SRGAN_ABI_COLLECTIVES=0 run crowd224_dp_torch_$c $cpus --force-dp --backend nccl --image-size 224
   run crowd512_dp_graph_$c $cpus --force-dp --backend nccl --step-graph
   run crowd224_dp_graph_$c $cpus --force-dp --backend nccl --step-graph --image-size 224
   run crowd224_plain_$c $cpus --image-size 224

@@ -25,8 +25,13 @@ CONTRACTION = ('gg_mfma_kernel', 'gg_direct_kernel', 'gg_rows_kernel', 'gg_dot_k
                'pointwise_ksplit_kernel', 'pointwise_kernel', 'pointwise_ring_kernel', 'pointwise_wgrad_kernel', 'pointwise_wgrad_grouped_kernel',
                'conv3x3_wgrad_grouped_kernel', 'conv3x3_mixed_kernel', 'stem7x7_fwd_kernel', 'stem7x7_wgrad_kernel',
                'stem7x7_bwd_data_kernel', 'pointwise_wgrad_lds_kernel', 'pointwise_wgrad_lds_grouped_kernel',
-               'hconv3x3_kernel', 'hwgrad3x3_kernel', 'hgemm_kernel', 'hlinear_wgrad_kernel', 'hconv4x4s2_kernel', 'hwgrad4x4s2_kernel',
-               'conv3x3_mixed_small_kernel')
+               'hconv3x3_kernel', 'hconv3x3_dma_kernel', 'hwgrad3x3_kernel', 'hgemm_kernel', 'hlinear_wgrad_kernel', 'hconv2x2_kernel',
+               'hwgrad4x4s2_kernel', 'hwgrad4x4s2_f32_kernel', 'conv3x3_mixed_small_kernel',
+               # the finish / reduce launches a contraction call's bracket covers (their partial-tile traffic belongs to the call)
+               'hwgrad3x3_finish_kernel', 'hwgrad4x4s2_finish_kernel', 'pointwise_wgrad_grouped_finish_kernel',
+               'conv3x3_wgrad_grouped_finish_kernel', 'stem7x7_wgrad_finish_kernel', 'gg_reduce_partials_kernel',
+               'gg_reduce_partials_wide_kernel')
+HELPERS = ('_finish_kernel', 'gg_reduce_partials')        # counted in the bytes, not in the launches
 
 
 def family(name):
@@ -80,8 +85,10 @@ def main():
         rows.append((hbm, f'| {kernel} | {launches} | {hbm / 1e9:.2f} | {f[0]:.0f} | {w[0]:.0f} | '
                           f'{ratio(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), 4 * busy)} | {ratio(s.get("SQ_WAIT_INST_ANY", 0.0), wave)} | '
                           f'{ratio(s.get("SQ_WAIT_ANY", 0.0), wave)} | {ratio(s.get("SQ_ACTIVE_INST_ANY", 0.0), wave)} |'))
-        if any(kernel.startswith(c) for c in CONTRACTION):
-            totals['fetch'] += f[0]; totals['write'] += w[0]; totals['launches'] += launches
+        if any(kernel == c for c in CONTRACTION):
+            totals['fetch'] += f[0]; totals['write'] += w[0]
+            if not any(h in kernel for h in HELPERS):
+                totals['launches'] += launches
         else:
             totals['other_fetch'] += f[0]; totals['other_write'] += w[0]; totals['other_launches'] += launches
     lines += [row for _, row in sorted(rows, reverse=True)]
