@@ -594,20 +594,6 @@ static bool hconv3_plan(int32_t N, int32_t CGI, int32_t CO_rows, int32_t H, int3
   int ni = 1;
   if (rows_for_ni[4] && plan.bm == 64 && count(4) >= 512) ni = 4;
   else if (rows_for_ni[2] && count(2) >= 512) ni = 2;
-  // ... corrected for ROUNDS: the chip holds 512 of these workgroups; 768 tiles of 512 pixels are two rounds of which the second
-  // is half empty, 1536 tiles of 256 pixels three full ones (the stacked pass of 384 images through VGG's 16 x 16 and 8 x 8
-  // stages).  Cost = rounds x pixels per tile, smaller tiles charged 4 % / 10 % for their extra weight staging.
-  static const bool by_rounds = getenv("SRGAN_H_NO_ROUNDS") == nullptr;
-  if (by_rounds && count(ni) > 512) {
-    double best = 0.0;
-    int chosen = ni;
-    for (int candidate : {4, 2, 1}) {
-      if (!rows_for_ni[candidate] || (candidate == 4 && plan.bm != 64) || candidate > ni) continue;
-      const double cost = (double)((count(candidate) + 511) / 512) * candidate * (candidate == 4 ? 1.0 : (candidate == 2 ? 1.04 : 1.10));
-      if (best == 0.0 || cost < best) { best = cost; chosen = candidate; }
-    }
-    ni = chosen;
-  }
   if (const char* forced = getenv("SRGAN_H_CONV_NI")) {          // tests: every tile shape on small tensors
     const int want = atoi(forced);
     if ((want == 1 || want == 2 || want == 4) && rows_for_ni[want] && (want != 4 || plan.bm == 64)) ni = want;

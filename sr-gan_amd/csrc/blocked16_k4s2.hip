@@ -257,7 +257,7 @@ static int hconv2_run(HConv2Params& p, int dtype, int64_t flops_k, hipStream_t s
     const int covered = (p.GW + candidate - 1) / candidate * candidate;
     if (covered < best) { best = covered; tw = candidate; }
   }
-  int bm = p.CO > 32 ? 64 : 32;
+  const int bm = p.CO > 32 ? 64 : 32;
   p.tiles_m = (p.CO + bm - 1) / bm;
   auto rows_of = [&](int ni) { return tw == 32 ? 4 * ni : (tw == 16 ? 8 * ni : tw); };
   auto count = [&](int ni) {
@@ -266,19 +266,6 @@ static int hconv2_run(HConv2Params& p, int dtype, int64_t flops_k, hipStream_t s
   };
   const int classes = p.down ? 1 : 4;
   const int ni = (tw != 4 && count(2) * classes >= 512) ? 2 : 1;
-  // Rounds: the chip holds 512 of these workgroups (2 per CU); a launch of 768 runs two rounds, the second half empty.  32-row
-  // tiles double the workgroups at half the matrix work each (the pixel tile's patch is staged twice: ~10 %): taken where that
-  // fills the rounds better -- most launches of the DCGAN stages at batch 128 are 192 .. 1536 workgroups.
-  static const char* forced_bm = getenv("SRGAN_H_K4_BM");
-  if (bm == 64 && !(forced_bm && atoi(forced_bm) == 64)) {
-    const int64_t total = count(ni) * classes;
-    const double tall = (double)((total + 511) / 512);
-    const double low = 0.55 * (double)((2 * total + 511) / 512);
-    if (low < tall || (forced_bm && atoi(forced_bm) == 32)) {
-      bm = 32;
-      p.tiles_m = (p.CO + bm - 1) / bm;
-    }
-  }
   const int rows = rows_of(ni), img = 128 * ni / (rows * tw);
   p.tiles_x = (p.GW + tw - 1) / tw;
   p.tiles_y = (p.GH + rows - 1) / rows;
