@@ -332,6 +332,9 @@ def pmc_traffic(args):
     it cannot be measured from inside this script; a constant from another configuration is not a measurement."""
     from srgan_amd import _build
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    switched = [name for name in ('SRGAN_NO_STORAGE16', 'SRGAN_NO_BLOCKED_F32', 'SRGAN_ATOMIC_SPLIT') if os.environ.get(name)]
+    if switched:
+        return None, f'the PMC passes ran on the default kernels, this run has {", ".join(switched)} set'
     try:
         entries = json.load(open(path))['entries']
     except (OSError, KeyError, ValueError):

@@ -45,7 +45,7 @@ def test_bench_with_the_exchanges_forced_through_rccl_on_one_rank(pkg):
 
 def test_rccl_entry_points_of_the_abi_on_one_rank(pkg):
     """include/srgan_hip.h "collectives": a communicator of ONE rank from a unique id (two ranks cannot share a device under
-    RCCL, one rank can); all-reduce, reduce-scatter and all-gather in fp32 and bf16 on the caller's stream are the identity
+    RCCL, one rank can); all-reduce, reduce-scatter, all-gather and broadcast in fp32 and bf16 on the caller's stream are the identity
     there, and they must leave exactly that; argument errors come back as -1 before RCCL is reached."""
     import ctypes
     from srgan_amd import _lib
@@ -73,6 +73,10 @@ def test_rccl_entry_points_of_the_abi_on_one_rank(pkg):
         gathered = torch.zeros_like(source)
         _lib.check(lib.srgan_all_gather(comm, shard.data_ptr(), gathered.data_ptr(), source.numel(), code, stream), 'all_gather')
         assert torch.equal(gathered, source)
+        weights = source.clone()
+        _lib.check(lib.srgan_broadcast(comm, weights.data_ptr(), weights.numel(), code, 0, stream), 'broadcast')
+        assert torch.equal(weights, source)
+    assert lib.srgan_broadcast(comm, source.data_ptr(), 4, 0, -1, stream) == _lib.EINVAL                       # negative root
     assert lib.srgan_all_reduce_sum(comm, source.data_ptr(), out.data_ptr(), 4, 7, stream) == _lib.EINVAL     # unknown dtype
     assert lib.srgan_all_reduce_sum(None, source.data_ptr(), out.data_ptr(), 4, 0, stream) == _lib.EINVAL
     torch.cuda.synchronize()
