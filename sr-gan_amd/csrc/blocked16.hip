@@ -262,38 +262,70 @@ struct HConv3Params {
 
 __device__ unsigned int g_hconv3_split_tickets[SPLIT_TICKET_SETS * SPLIT_TICKET_TILES];
 
+// The BM bias values of a workgroup's rows into LDS, at the kernel's start (the barrier behind it is nowhere near the epilogue's
+// stores: a barrier in front of the epilogue would make the four waves' stores wait for the slowest wave's last MFMA).
+template <int BM>
+__device__ __forceinline__ void hconv3_stage_bias(const float* bias, int epi, int C_real, int m0, float* bias_rows) {
+  if (epi == 1 && bias != nullptr) {
+    if ((int)threadIdx.x < BM) bias_rows[threadIdx.x] = m0 + (int)threadIdx.x < C_real ? bias[m0 + threadIdx.x] : 0.f;
+    __syncthreads();
+  }
+}
+
 // Epilogue of the 3x3 kernels.  C/D fragment: column = pixel (lane & 31), rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): registers
 // 4q .. 4q + 3 are four CONSECUTIVE output channels = 8 bytes of the pixel's slot of group (m0 + 32 mi) / 8 + q; the 32 lanes of
 // a half cover 32 consecutive slots (with the other half: 512 contiguous bytes per store instruction).
 template <int BM, int NI, int TW, int ROWS, int PREC>
 __device__ __forceinline__ void hconv3_epilogue(const HConv3Params& p, f32x16 (&acc)[BM / 32][NI], int n0, int y0, int x0, int m0,
-                                                int wave, int l31, int lhi) {
+                                                int wave, int l31, int lhi, const float* bias_rows) {
   constexpr int MI = BM / 32;
   const int HW = p.H * p.W;
+  // bias_rows: the tile's bias values in LDS (hconv3_stage_bias at the kernel's start).  Read per value from global memory
+  // inside the loops below they were 4 dependent loads per quad -- 128 VMEM instructions per wave at 64 rows x 512 pixels, 25 us
+  // of a 59 us launch (conv1_1, batch 128: scratch/h_conv_bench.py).
+  const bool with_bias = p.epi == 1 && p.bias != nullptr;
+  float4 bias4[MI][4];              // this lane's rows are the same for every pixel column: read once
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      bias4[mi][qd] = with_bias ? *reinterpret_cast<const float4*>(&bias_rows[mi * 32 + 8 * qd + 4 * lhi]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // epi 2: the mask references of a pixel column are loaded in ONE batch in front of its stores.  On this ISA loads and stores
+  // return through one in-order counter (vmcnt): interleaved load - use - store, every load waited for the stores in front of it
+  // (32 round trips per wave at 64 rows x 512 pixels: 102 us for the data gradient of a layer whose forward took 69).
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int q = (wave * NI + ni) * 32 + l31;
     const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
     if (n >= p.N || y >= p.H || x >= p.W) continue;
+    const int64_t pixel = (int64_t)n * p.CGO * HW + y * p.W + x;
+    uint2 refs[MI][4];
+    if (p.epi == 2) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int group = (m0 + mi * 32) / 8 + qd;
+          refs[mi][qd] = group < p.CGO ? *(reinterpret_cast<const uint2*>(p.ref + pixel + (int64_t)group * HW) + lhi) : uint2{0u, 0u};
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int group = (m0 + mi * 32) / 8 + qd;
         if (group >= p.CGO) continue;
-        const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
-        const int64_t slot = ((int64_t)n * p.CGO + group) * HW + y * p.W + x;
+        const int64_t slot = pixel + (int64_t)group * HW;
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * qd + j];
         if (p.epi == 1) {
+          const float4 b4 = bias4[mi][qd];
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (p.bias != nullptr && o + j < p.C_real) v[j] += p.bias[o + j];
-            v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
-          }
+          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
         } else if (p.epi == 2) {
-          const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
+          const uint2 r = refs[mi][qd];
           v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
           v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
         }
@@ -332,6 +364,8 @@ __global__ __launch_bounds__(256, 2) void hconv3x3_kernel(const HConv3Params p) 
   const int ty = block % p.tiles_y;
   const int n0 = (block / p.tiles_y) * IMG;
   const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
+  __shared__ __attribute__((aligned(16))) float bias_rows[BM];
+  hconv3_stage_bias<BM>(p.bias, p.epi, p.C_real, m0, bias_rows);
   const int cbeg = (int)blockIdx.y * p.chunks_per_split;
   const int cend = min(p.chunks, cbeg + p.chunks_per_split);
   const int HW = p.H * p.W;
@@ -450,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void hconv3x3_kernel(const HConv3Params p) 
       return;
   }
 
-  hconv3_epilogue<BM, NI, TW, ROWS, PREC>(p, acc, n0, y0, x0, m0, wave, l31, lhi);
+  hconv3_epilogue<BM, NI, TW, ROWS, PREC>(p, acc, n0, y0, x0, m0, wave, l31, lhi, bias_rows);
 }
 
 // ---- the same convolution with LDS-DMA staging (global_load_lds_dwordx4: HBM / L2 -> LDS without passing the registers) -----
@@ -487,6 +521,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void hconv3x3_dma_kernel(co
   const int ty = block % p.tiles_y;
   const int n0 = (block / p.tiles_y) * IMG;
   const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
+  __shared__ __attribute__((aligned(16))) float bias_rows[BM];
   const int HW = p.H * p.W;
   const uint32_t lds0 = h_lds_address(ring);
 
@@ -543,6 +578,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void hconv3x3_dma_kernel(co
   for (int d = 0; d < RING - 1; ++d)
     if (d < chunks) issue(d, d);
   if ((p.debug & 1) && RING - 1 < chunks) issue(RING - 1, RING - 1);       // (experiment: every stage holds finite data)
+  hconv3_stage_bias<BM>(p.bias, p.epi, p.C_real, m0, bias_rows);           // behind the first chunk's requests, not in front of them
   int stage = 0;
   for (int c = 0; c < chunks; ++c) {
     // chunk c has landed (this wave's part: vmcnt; everybody's: the barrier), and everybody is done reading the stage that
@@ -566,7 +602,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void hconv3x3_dma_kernel(co
     }
     stage = stage + 1 == RING ? 0 : stage + 1;
   }
-  hconv3_epilogue<BM, NI, TW, ROWS, PREC>(p, acc, n0, y0, x0, m0, tid >> 6, l31, lhi);
+  hconv3_epilogue<BM, NI, TW, ROWS, PREC>(p, acc, n0, y0, x0, m0, tid >> 6, l31, lhi, bias_rows);
 }
 
 struct HConv3Plan { int bm, ni, tw, rows, tiles_x, tiles_y, tiles_m, tiles_n, split, chunks_per; int64_t blocks; };

@@ -100,6 +100,13 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(const HGemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int tm = (int)blockIdx.x % p.tiles_m, tn = (int)blockIdx.x / p.tiles_m;
   const int m0 = tm * 128, n0 = tn * 128;
+  // the tile's 128 bias values in LDS, staged here and read in the epilogue (as in the convolution kernels)
+  __shared__ __attribute__((aligned(16))) float bias_rows[128];
+  const bool with_bias = p.epi == 1 && p.bias != nullptr;
+  if (with_bias) {
+    if ((int)threadIdx.x < 128) bias_rows[threadIdx.x] = m0 + (int)threadIdx.x < p.M_real ? p.bias[m0 + threadIdx.x] : 0.f;
+    __syncthreads();
+  }
   const int sbeg = (int)blockIdx.y * p.steps_per_split;
   const int send = min(p.steps, sbeg + p.steps_per_split);
 
@@ -188,11 +195,12 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(const HGemmParams p) {
         for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * qd + j];
         uint2* dst = reinterpret_cast<uint2*>(p.out + (int64_t)n * p.ldo + (m >> 3)) + lhi;
         if (p.epi == 1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (p.bias != nullptr && m + j < p.M_real) v[j] += p.bias[m + j];
-            v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+          if (with_bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(&bias_rows[wm * 64 + mi * 32 + 8 * qd + 4 * lhi]);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
           }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
         } else if (p.epi == 2) {
           const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + (int64_t)n * p.ldo + (m >> 3)) + lhi);
           v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);

@@ -87,6 +87,14 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params pp,
   const int ty = block % p.tiles_y;
   const int n0 = (block / p.tiles_y) * IMG;
   const int m0 = tm * BM, y0 = ty * ROWS, x0 = tx * TW;
+  // the tile's bias values in LDS, staged here and read in the epilogue (blocked16.hip, hconv3_stage_bias: per value from global
+  // memory they were 4 dependent loads per quad of the epilogue)
+  __shared__ __attribute__((aligned(16))) float bias_rows[BM];
+  const bool with_bias = p.epi == 1 && p.bias != nullptr;
+  if (with_bias) {
+    if ((int)threadIdx.x < BM) bias_rows[threadIdx.x] = m0 + (int)threadIdx.x < p.C_real ? p.bias[m0 + threadIdx.x] : 0.f;
+    __syncthreads();
+  }
   const int IHW = p.IH * p.IW;
   const uint32_t lds0 = h_lds_address(ring);
 
@@ -174,6 +182,22 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params pp,
     const int n = n0 + q / (ROWS * TW), y = y0 + (q / TW) % ROWS, x = x0 + q % TW;
     if (n >= p.N || y >= p.GH || x >= p.GW) continue;
     const int pixel = (y * p.dsy + p.doy) * p.OW + x * p.dsx + p.dox;
+    // epi 2: the mask references of this pixel column in ONE batch in front of its stores (loads and stores share the in-order
+    // vmcnt: interleaved, every load waited for the stores in front of it -- blocked16.hip, hconv3_epilogue)
+    using RefWord = std::conditional_t<PREC == 0, float4, uint2>;
+    RefWord refs[MI][4];
+    if (p.epi == 2) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
+          const int group = PREC == 0 ? o / 4 : o / 8;
+          const int64_t slot = ((int64_t)n * p.CGO + (group < p.CGO ? group : 0)) * OHW + pixel;
+          if constexpr (PREC == 0) refs[mi][qd] = *reinterpret_cast<const float4*>(p.ref + slot);
+          else refs[mi][qd] = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -188,22 +212,23 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params pp,
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) v[jj] = acc[mi][ni][4 * qd + jj];
         if (p.epi == 1) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            if (p.bias != nullptr && o + jj < p.C_real) v[jj] += p.bias[o + jj];
-            v[jj] = v[jj] > 0.f ? v[jj] : v[jj] * p.slope;
+          if (with_bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(&bias_rows[mi * 32 + 8 * qd + 4 * lhi]);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
           }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) v[jj] = v[jj] > 0.f ? v[jj] : v[jj] * p.slope;
         }
         if constexpr (PREC == 0) {
           if (p.epi == 2) {
-            const float4 r = *reinterpret_cast<const float4*>(p.ref + slot);
+            const float4 r = refs[mi][qd];
             v[0] *= r.x > 0.f ? 1.f : p.slope; v[1] *= r.y > 0.f ? 1.f : p.slope;
             v[2] *= r.z > 0.f ? 1.f : p.slope; v[3] *= r.w > 0.f ? 1.f : p.slope;
           }
           *reinterpret_cast<float4*>(p.out + slot) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           if (p.epi == 2) {
-            const uint2 r = *(reinterpret_cast<const uint2*>(p.ref + slot) + lhi);
+            const uint2 r = refs[mi][qd];
             v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
             v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
           }
