@@ -891,11 +891,17 @@ __global__ __launch_bounds__(256) void hwgrad3x3_finish_kernel(const float* __re
 #pragma unroll
   for (int t = 0; t < 9; ++t) sums[part][t][lane] = total[t];
   __syncthreads();
-  for (int i = (int)threadIdx.x; i < 576; i += 256) {
-    const int ci_local = i / 9, tap = i - ci_local * 9;
-    const int ci = tci * 64 + ci_local;
-    if (ci < CI)
-      gw[((int64_t)co * CI + ci) * 9 + tap] += (sums[0][tap][ci_local] + sums[1][tap][ci_local]) + (sums[2][tap][ci_local] + sums[3][tap][ci_local]);
+  float previous[3];                        // read all, then write all (loads wait for the stores in front of them: one vmcnt)
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int i = (int)threadIdx.x + 256 * e, ci_local = i / 9, tap = i - ci_local * 9, ci = tci * 64 + ci_local;
+    previous[e] = (i < 576 && ci < CI) ? gw[((int64_t)co * CI + ci) * 9 + tap] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int i = (int)threadIdx.x + 256 * e, ci_local = i / 9, tap = i - ci_local * 9, ci = tci * 64 + ci_local;
+    if (i < 576 && ci < CI)
+      gw[((int64_t)co * CI + ci) * 9 + tap] = previous[e] + ((sums[0][tap][ci_local] + sums[1][tap][ci_local]) + (sums[2][tap][ci_local] + sums[3][tap][ci_local]));
   }
 }
 
@@ -1179,7 +1185,11 @@ int srgan_h_conv3x3_wgrad(const void* x, const void* gy, float* gw, int32_t N, i
   // Walkers per block: enough workgroups to occupy the chip, but every walker leaves its accumulators (147 / 295 KB) as a partial
   // block that the finish reads back -- 1024 / blocks walkers made that traffic (and the finish's serial walker loop) the larger
   // part of the launch on both ends of VGG (1 block x 1024 walkers; 64 blocks x 16 walkers: 151 MB each, profiles/r06b_*).
-  const int target = mb == 4 ? 256 : 320;
+  // (64-row blocks run two workgroups per CU: where a walker still gets a long run of tiles -- the 64-channel layers on 64 x 64
+  // planes: one block, 8192+ tiles -- all 512 slots are filled; elsewhere 320, for the partial traffic)
+  static const char* forced_walkers = getenv("SRGAN_H_WGRAD_WALKERS");
+  int target = mb == 4 ? 256 : ((int64_t)p.pixel_tiles >= (int64_t)16 * 512 * blocks ? 512 : 320);
+  if (forced_walkers) target = atoi(forced_walkers);
   int walkers = (target + blocks - 1) / blocks;
   if (walkers > p.pixel_tiles) walkers = p.pixel_tiles;
   if (walkers < 1) walkers = 1;

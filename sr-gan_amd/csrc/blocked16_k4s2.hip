@@ -176,6 +176,12 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params pp,
 
   // epilogue (as hconv3_epilogue, with the output placement)
   const int OHW = p.OH * p.OW;
+  float4 bias4[MI][4];              // this lane's rows are the same for every pixel column: read once
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      bias4[mi][qd] = with_bias ? *reinterpret_cast<const float4*>(&bias_rows[mi * 32 + 8 * qd + 4 * lhi]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int q = ((tid >> 6) * NI + ni) * 32 + l31;
@@ -212,10 +218,8 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params pp,
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) v[jj] = acc[mi][ni][4 * qd + jj];
         if (p.epi == 1) {
-          if (with_bias) {
-            const float4 b4 = *reinterpret_cast<const float4*>(&bias_rows[mi * 32 + 8 * qd + 4 * lhi]);
-            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-          }
+          const float4 b4 = bias4[mi][qd];
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) v[jj] = v[jj] > 0.f ? v[jj] : v[jj] * p.slope;
         }
@@ -608,12 +612,20 @@ __global__ __launch_bounds__(256) void hwgrad4x4s2_finish_kernel(const float* __
 #pragma unroll
   for (int t = 0; t < 16; ++t) sums[part][t][c32] = total[t];
   __syncthreads();
-  for (int i = (int)threadIdx.x; i < 512; i += 256) {
+  float previous[2];                        // read both, then write both (loads wait for the stores in front of them: one vmcnt)
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = (int)threadIdx.x + 256 * e, cc = i >> 4, t = i & 15, c = tc * 32 + cc;
+    previous[e] = c < C ? gw[(int64_t)k * sk + (int64_t)c * sc + t] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = (int)threadIdx.x + 256 * e;
     const int cc = i >> 4, t = i & 15;                    // consecutive threads: the 16 taps of one column = 64 contiguous bytes
     const int c = tc * 32 + cc;
     if (c < C)
-      gw[(int64_t)k * sk + (int64_t)c * sc + t] += ((sums[0][t][cc] + sums[1][t][cc]) + (sums[2][t][cc] + sums[3][t][cc])) +
-                                                   ((sums[4][t][cc] + sums[5][t][cc]) + (sums[6][t][cc] + sums[7][t][cc]));
+      gw[(int64_t)k * sk + (int64_t)c * sc + t] = previous[e] + (((sums[0][t][cc] + sums[1][t][cc]) + (sums[2][t][cc] + sums[3][t][cc])) +
+                                                                  ((sums[4][t][cc] + sums[5][t][cc]) + (sums[6][t][cc] + sums[7][t][cc])));
   }
 }
 
