@@ -310,6 +310,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
     if (y >= p.H || x >= p.W) continue;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      // accumulate: the sixteen old values in one batch in front of the stores (loads and stores return through one in-order
+      // counter, vmcnt: `*dst += v` per element made every load wait for the store in front of it)
+      float previous[16];
+      if (mode == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          previous[r] = o < p.CO ? out_n[(int64_t)o * p.out_plane + y * p.out_sy + x * p.out_sx + p.out_off] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
         if (add_bias) v += p.bias[o];
         float* dst = out_n + (int64_t)o * p.out_plane + y * p.out_sy + x * p.out_sx + p.out_off;
         if (mode == 0) __builtin_nontemporal_store(v, dst);      // consumed by a later kernel, not by this one
-        else if (mode == 1) *dst += v;
+        else if (mode == 1) *dst = previous[r] + v;
         else unsafeAtomicAdd(dst, v);
       }
     }

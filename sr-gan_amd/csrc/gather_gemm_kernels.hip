@@ -299,24 +299,42 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const Side sm = decode(p.cm, i);
-      if (!sm.valid) continue;
-      const float row_bias = (add_bias && !p.bias_cols) ? p.bias[sm.c] : 0.f;
+    for (int rq = 0; rq < 4; ++rq) {
+      // accumulate (every weight gradient: the arena sums four backward passes): the 4 x NI old values of a register quad in
+      // one batch in front of their stores -- loads and stores return through one in-order counter (vmcnt), so `*dst += v`
+      // per element made every load wait for the store in front of it
+      float previous[4][NI];
+      if (mode == GG_ACCUMULATE) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (!sn[ni].valid) continue;
-        float v = acc[mi][ni][r] + row_bias;
-        if (add_bias && p.bias_cols) v += p.bias[sn[ni].c];
-        if (mode == GG_PARTIAL) {
-          p.partial[((int64_t)blockIdx.y * p.M + i) * p.N + (n0 + wn0 + ni * 32 + l31)] = v;
-          continue;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int i = m0 + wm0 + mi * 32 + rr + 8 * rq + 4 * lhi;
+          const Side sm = decode(p.cm, i);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            previous[rr][ni] = (sm.valid && sn[ni].valid) ? p.C[(uint32_t)(sm.off + sn[ni].off)] : 0.f;
         }
-        float* dst = p.C + (uint32_t)(sm.off + sn[ni].off);
-        if (mode == GG_STORE) *dst = v;
-        else if (mode == GG_ACCUMULATE) *dst += v;
-        else unsafeAtomicAdd(dst, v);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * rq + rr;
+        const int i = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const Side sm = decode(p.cm, i);
+        if (!sm.valid) continue;
+        const float row_bias = (add_bias && !p.bias_cols) ? p.bias[sm.c] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (!sn[ni].valid) continue;
+          float v = acc[mi][ni][r] + row_bias;
+          if (add_bias && p.bias_cols) v += p.bias[sn[ni].c];
+          if (mode == GG_PARTIAL) {
+            p.partial[((int64_t)blockIdx.y * p.M + i) * p.N + (n0 + wn0 + ni * 32 + l31)] = v;
+            continue;
+          }
+          float* dst = p.C + (uint32_t)(sm.off + sn[ni].off);
+          if (mode == GG_STORE) *dst = v;
+          else if (mode == GG_ACCUMULATE) *dst = previous[rr][ni] + v;
+          else unsafeAtomicAdd(dst, v);
+        }
       }
     }
   }

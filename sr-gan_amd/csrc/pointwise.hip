@@ -387,9 +387,40 @@ __global__ __launch_bounds__(256, MI * NI >= 4 ? 2 : 4) void pointwise_kernel(co
       }
     }
   };
+  // accumulate: the old values of a 32-row block in one batch in front of its stores (loads and stores return through one
+  // in-order counter, vmcnt: `*dst += v` per element made every load wait for the store in front of it)
+  auto emit_accumulate = [&](auto check_lane) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      float previous[16][NI];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bool ok = o < p.CO;
+          if constexpr (decltype(check_lane)::value) ok = ok && pix + 32 * ni < p.HW;
+          previous[r][ni] = ok ? out_lane[(int64_t)o * p.HW + 32 * ni] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (o >= p.CO) continue;
+        const float bias = add_bias ? p.bias[o] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if constexpr (decltype(check_lane)::value) {
+            if (pix + 32 * ni >= p.HW) continue;
+          }
+          out_lane[(int64_t)o * p.HW + 32 * ni] = previous[r][ni] + (acc[mi][ni][r] + bias);
+        }
+      }
+    }
+  };
   auto emit_mode = [&](auto check_lane) {
     if (mode == 0) emit([](float* dst, float v) { __builtin_nontemporal_store(v, dst); }, check_lane);   // consumed by a later kernel
-    else if (mode == 1) emit([](float* dst, float v) { *dst += v; }, check_lane);
+    else if (mode == 1) emit_accumulate(check_lane);
     else emit([](float* dst, float v) { unsafeAtomicAdd(dst, v); }, check_lane);
   };
   if (ragged) emit_mode(std::true_type{});

@@ -288,22 +288,53 @@ __global__ __launch_bounds__(256, 2) void pointwise_ring_kernel(const RingParams
     return;
   }
   if (!active) return;
+  if (p.mode == 1) {
+    // accumulate: the sixteen rows' old values in one batch, then the stores (loads and stores return through one in-order
+    // counter, vmcnt: `+=` row by row made every load wait for the store in front of it)
+    float previous[16][NI];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* src = out_lane + (int64_t)((r & 3) + 8 * (r >> 2)) * p.HW;
+      if constexpr (NI == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        previous[r][0] = v.x; previous[r][1] = v.y; previous[r][2] = v.z; previous[r][3] = v.w;
+      } else if constexpr (NI == 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(src);
+        previous[r][0] = v.x; previous[r][1] = v.y;
+      } else {
+        previous[r][0] = *src;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* dst = out_lane + (int64_t)((r & 3) + 8 * (r >> 2)) * p.HW;
+      if constexpr (NI == 4) {
+        f32x4 v;
+        v.x = previous[r][0] + acc[0][r]; v.y = previous[r][1] + acc[1][r]; v.z = previous[r][2] + acc[2][r]; v.w = previous[r][3] + acc[3][r];
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else if constexpr (NI == 2) {
+        f32x2 v;
+        v.x = previous[r][0] + acc[0][r]; v.y = previous[r][1] + acc[1][r];
+        *reinterpret_cast<f32x2*>(dst) = v;
+      } else {
+        *dst = previous[r][0] + acc[0][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float* dst = out_lane + (int64_t)((r & 3) + 8 * (r >> 2)) * p.HW;
     if constexpr (NI == 4) {
       f32x4 v;
       v.x = acc[0][r]; v.y = acc[1][r]; v.z = acc[2][r]; v.w = acc[3][r];
-      if (p.mode == 1) *reinterpret_cast<f32x4*>(dst) += v;
-      else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));             // consumed by a later kernel
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));             // consumed by a later kernel
     } else if constexpr (NI == 2) {
       f32x2 v;
       v.x = acc[0][r]; v.y = acc[1][r];
-      if (p.mode == 1) *reinterpret_cast<f32x2*>(dst) += v;
-      else __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(dst));
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(dst));
     } else {
-      if (p.mode == 1) *dst += acc[0][r];
-      else __builtin_nontemporal_store(acc[0][r], dst);
+      __builtin_nontemporal_store(acc[0][r], dst);
     }
   }
 }
