@@ -881,12 +881,21 @@ __global__ __launch_bounds__(256) void hwgrad3x3_finish_kernel(const float* __re
   float total[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) total[t] = 0.f;
-  for (int w = part; w < walkers; w += 4) {
-    float v[9];
+  // four walkers' loads in flight per wave, added in walker order (the sum is the one-at-a-time loop's, bit for bit): the
+  // single-block layers have 512 walkers = 128 dependent round trips per wave
+  for (int w0 = part; w0 < walkers; w0 += 16) {
+    float v[4][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = base[(int64_t)w * per_walker + t * 16 * threads];
+    for (int d = 0; d < 4; ++d) {
+      const int w = w0 + 4 * d;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) total[t] += v[t];
+      for (int t = 0; t < 9; ++t) v[d][t] = w < walkers ? base[(int64_t)w * per_walker + t * 16 * threads] : 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      if (w0 + 4 * d < walkers)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) total[t] += v[d][t];
   }
 #pragma unroll
   for (int t = 0; t < 9; ++t) sums[part][t][lane] = total[t];
