@@ -240,6 +240,12 @@ STREAM_SETTINGS = ('overlap_dnn_step', 'wgrad_stream', 'overlap_generator_forwar
 # atomics (SRGAN_ATOMIC_SPLIT=1) a ReLU mask may flip between two runs of ONE schedule: 1e-4 there.
 SCHEDULE_CHECK_LIMIT = 1e-5
 SCHEDULE_CHECK_LIMIT_ATOMIC_SPLIT = 1e-4
+# 16-bit storage (configs[1] / [4]): the two schedules add the penalty chain's share of D's gradients in a different association
+# (its own buffer, added after the join), so D's updated fp32 weights differ in the last bit here and there -- and a last-bit
+# difference flips the ROUNDING of that weight's bf16 / fp16 shadow now and then (2^-16 of the weights, each then off by 2^-8 / 2^-11
+# relative): the generator loss, computed behind D's update, moves by 1e-5 .. 1e-4 (measured 2.2e-5 on age-vgg-bf16 after 8 steps;
+# each schedule against its own repetition: 0).  The first five losses stay bit-identical.
+SCHEDULE_CHECK_LIMIT_STORAGE16 = 2e-4
 
 
 def schedule_check(experiment, labeled, unlabeled, step):
@@ -317,7 +323,9 @@ def schedule_check(experiment, labeled, unlabeled, step):
             # (several ranks: the two schedules cut the gradient arenas into different buckets, so RCCL's ring adds an element's
             # rank contributions in another order -- the round-4 limit there; never run on more than one rank so far)
             'limit': max(SCHEDULE_CHECK_LIMIT if ordered and not (experiment.dp is not None and experiment.dp.world_size > 1)
-                         else SCHEDULE_CHECK_LIMIT_ATOMIC_SPLIT, 4.0 * single_floor),
+                         else SCHEDULE_CHECK_LIMIT_ATOMIC_SPLIT,
+                         SCHEDULE_CHECK_LIMIT_STORAGE16 if getattr(experiment.settings, 'storage_dtype', None) else 0.0,
+                         4.0 * single_floor),
             'split_k_finish': 'fixed order through the workspace (no atomics on data)' if ordered else 'fp32 atomics',
             'what': 'one iteration on the timed schedule vs the same iteration on ONE stream (eager), from the same weights, '
                     'Adam state, batch and draws, after the timed region; *_twice = a schedule against its own repetition',
@@ -461,11 +469,13 @@ def secondary_line(workload, steps, warmup=5, limit_seconds=600):
     import subprocess
     command = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--steps', str(steps), '--warmup', str(warmup),
                '--no-cpu-baseline', '--no-secondary']
+    completed = None
     try:
         completed = subprocess.run(command, capture_output=True, text=True, timeout=limit_seconds)
-        line = json.loads(completed.stdout.strip().splitlines()[-1])
+        line = json.loads([text for text in completed.stdout.splitlines() if text.startswith('{')][-1])
     except (subprocess.TimeoutExpired, ValueError, IndexError) as error:
-        return {'value': None, 'unit': 'images/s', 'error': f'{type(error).__name__}', 'command': ' '.join(command[1:])}
+        return {'value': None, 'unit': 'images/s', 'error': f'{type(error).__name__}', 'command': ' '.join(command[1:]),
+                'returncode': getattr(completed, 'returncode', None), 'stderr_tail': (getattr(completed, 'stderr', '') or '')[-1500:]}
     roofline = line.get('roofline') or {}
     check = line['config'].get('schedule_check')
     return {'metric': line['metric'], 'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'],

@@ -206,40 +206,63 @@ __global__ __launch_bounds__(256, 2) void hconv2x2_kernel(const HConv2Params pp,
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      if constexpr (PREC == 0) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        // registers 4 qd .. 4 qd + 3 = the four consecutive channels o .. o + 3: half a slot of the 16-bit forms, a whole
-        // slot (group o / 4) of the fp32 form
-        const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
-        const int group = PREC == 0 ? o / 4 : o / 8;
-        if (group >= p.CGO) continue;
-        const int64_t slot = ((int64_t)n * p.CGO + group) * OHW + pixel;
-        float v[4];
+        for (int qd = 0; qd < 4; ++qd) {
+          // registers 4 qd .. 4 qd + 3 = the four consecutive channels o .. o + 3 = a whole slot (group o / 4) of the fp32 form
+          const int o = m0 + mi * 32 + 8 * qd + 4 * lhi;
+          const int group = o / 4;
+          if (group >= p.CGO) continue;
+          const int64_t slot = ((int64_t)n * p.CGO + group) * OHW + pixel;
+          float v[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) v[jj] = acc[mi][ni][4 * qd + jj];
-        if (p.epi == 1) {
-          const float4 b4 = bias4[mi][qd];
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+          for (int jj = 0; jj < 4; ++jj) v[jj] = acc[mi][ni][4 * qd + jj];
+          if (p.epi == 1) {
+            const float4 b4 = bias4[mi][qd];
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) v[jj] = v[jj] > 0.f ? v[jj] : v[jj] * p.slope;
-        }
-        if constexpr (PREC == 0) {
-          if (p.epi == 2) {
+            for (int jj = 0; jj < 4; ++jj) v[jj] = v[jj] > 0.f ? v[jj] : v[jj] * p.slope;
+          } else if (p.epi == 2) {
             const float4 r = refs[mi][qd];
             v[0] *= r.x > 0.f ? 1.f : p.slope; v[1] *= r.y > 0.f ? 1.f : p.slope;
             v[2] *= r.z > 0.f ? 1.f : p.slope; v[3] *= r.w > 0.f ? 1.f : p.slope;
           }
           *reinterpret_cast<float4*>(p.out + slot) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          if (p.epi == 2) {
-            const uint2 r = refs[mi][qd];
-            v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
-            v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
+        }
+      } else {
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          // two register quads = this lane's half (channels 4 lhi .. 4 lhi + 3) of the slots of groups g0 and g0 + 1; the halves
+          // change places between the half-waves (v_permlane32_swap, blocked16.hip hconv3_epilogue) and every lane stores a whole slot
+          const int g0 = (m0 + mi * 32) / 8 + 2 * qp;
+          uint2 packed[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int qd = 2 * qp + h;
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = acc[mi][ni][4 * qd + jj];
+            if (p.epi == 1) {
+              const float4 b4 = bias4[mi][qd];
+              v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) v[jj] = v[jj] > 0.f ? v[jj] : v[jj] * p.slope;
+            } else if (p.epi == 2) {
+              const uint2 r = refs[mi][qd];
+              v[0] *= h_mask(r.x & 0xFFFFu, p.slope); v[1] *= h_mask(r.x >> 16, p.slope);
+              v[2] *= h_mask(r.y & 0xFFFFu, p.slope); v[3] *= h_mask(r.y >> 16, p.slope);
+            }
+            packed[h].x = h_pack2<PREC>(v[0], v[1]);
+            packed[h].y = h_pack2<PREC>(v[2], v[3]);
           }
-          uint2 packed;
-          packed.x = h_pack2<PREC>(v[0], v[1]);
-          packed.y = h_pack2<PREC>(v[2], v[3]);
-          *(reinterpret_cast<uint2*>(p.out + slot) + lhi) = packed;
+          const auto first = __builtin_amdgcn_permlane32_swap(packed[0].x, packed[1].x, false, false);
+          const auto second = __builtin_amdgcn_permlane32_swap(packed[0].y, packed[1].y, false, false);
+          const int group = g0 + lhi;
+          if (group < p.CGO) {
+            uint4 whole;
+            whole.x = first[0]; whole.y = second[0]; whole.z = first[1]; whole.w = second[1];
+            *reinterpret_cast<uint4*>(p.out + ((int64_t)n * p.CGO + group) * OHW + pixel) = whole;
+          }
         }
       }
     }
