@@ -84,11 +84,17 @@ __global__ __launch_bounds__(256) void h_add_kernel(const Slot* __restrict__ a, 
 
 // Channel sums (a bias gradient): part[(g * parts + part) * 8 + j] = sum over this block's share of (n, pixel) of channel
 // 8g + j; h_channel_sums_finish_kernel adds the parts of a channel in part order into the fp32 gradient (bit-reproducible).
+// `tickets` != NULL: ONE launch -- the group's last workgroup (a ticket per group and stream, split_finish.h) adds the parts in a
+// fixed order and accumulates into `out` itself (the second launch was 47 launches of ~7 us per step of age-vgg-bf16).
+__device__ unsigned int g_h_sum_tickets[SPLIT_TICKET_SETS * ROW_FINISH_ROWS];
+
 template <int PREC>
 __global__ __launch_bounds__(256) void h_channel_sums_kernel(const Slot* __restrict__ x, float* __restrict__ part, int32_t N,
-                                                             int32_t CG, int32_t HW, int32_t parts) {
+                                                             int32_t CG, int32_t HW, int32_t parts, unsigned int* tickets,
+                                                             float* __restrict__ out, int32_t C) {
   constexpr int G = HGroup<PREC>::N;
   __shared__ float scratch[4 * 8];
+  __shared__ float finish_scratch[4];
   const int g = (int)blockIdx.x, part_id = (int)blockIdx.y;
   const int64_t total = (int64_t)N * HW;
   float sum[G];
@@ -109,9 +115,20 @@ __global__ __launch_bounds__(256) void h_channel_sums_kernel(const Slot* __restr
     if (lane == 0) scratch[wave * 8 + j] = w;
   }
   __syncthreads();
-  if (threadIdx.x < G) {
-    const int j = threadIdx.x;
-    part[((int64_t)g * parts + part_id) * 8 + j] = (scratch[j] + scratch[8 + j]) + (scratch[16 + j] + scratch[24 + j]);
+  if (tickets == nullptr) {
+    if (threadIdx.x < G) {
+      const int j = threadIdx.x;
+      part[((int64_t)g * parts + part_id) * 8 + j] = (scratch[j] + scratch[8 + j]) + (scratch[16 + j] + scratch[24 + j]);
+    }
+    return;
+  }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = j < G ? (scratch[j] + scratch[8 + j]) + (scratch[16 + j] + scratch[24 + j]) : 0.f;
+  if (ordered_row_finish<8>(v, part + (int64_t)g * parts * 8, part_id, parts, tickets + g, finish_scratch)) {
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+      if (g * G + j < C) out[g * G + j] += v[j];
   }
 }
 
@@ -1011,13 +1028,19 @@ int srgan_h_channel_sums(const void* x, float* out, int32_t N, int32_t C, int64_
   if (parts > 256) parts = 256;
   if (parts < 1) parts = 1;
   while (parts > 1 && (int64_t)parts * CG > 4096) parts >>= 1;
-  float* part = partial_workspace((size_t)CG * parts * 8 * sizeof(float), stream);
+  unsigned int* tickets = nullptr;
+  static const bool two_launches = getenv("SRGAN_H_SUMS_TWO_LAUNCHES") != nullptr;
+  float* part = two_launches ? nullptr : row_finish_workspace(CG, parts, 8, g_h_sum_tickets, stream, &tickets);
+  if (!part) {
+    tickets = nullptr;
+    part = partial_workspace((size_t)CG * parts * 8 * sizeof(float), stream);
+  }
   SRGAN_REQUIRE(part, SRGAN_EINVAL, "srgan_h_channel_sums: register a workspace for this stream first (srgan_set_workspace)");
   const dim3 grid((unsigned)CG, (unsigned)parts);
-  if (dtype == 0) hipLaunchKernelGGL(h_channel_sums_kernel<0>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
-  else if (dtype == 1) hipLaunchKernelGGL(h_channel_sums_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
-  else hipLaunchKernelGGL(h_channel_sums_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts);
-  hipLaunchKernelGGL(h_channel_sums_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, out, C, parts, group);
+  if (dtype == 0) hipLaunchKernelGGL(h_channel_sums_kernel<0>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts, tickets, out, C);
+  else if (dtype == 1) hipLaunchKernelGGL(h_channel_sums_kernel<1>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts, tickets, out, C);
+  else hipLaunchKernelGGL(h_channel_sums_kernel<2>, grid, dim3(256), 0, stream, (const Slot*)x, part, N, CG, (int32_t)HW, parts, tickets, out, C);
+  if (!tickets) hipLaunchKernelGGL(h_channel_sums_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, out, C, parts, group);
   return launch_status();
 }
 

@@ -320,12 +320,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const Conv3Params p
           previous[r] = o < p.CO ? out_n[(int64_t)o * p.out_plane + y * p.out_sy + x * p.out_sx + p.out_off] : 0.f;
         }
       }
+      float bias_values[16];                 // (in front of the stores, like the old values)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        bias_values[r] = (add_bias && o < p.CO) ? p.bias[o] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         if (o >= p.CO) continue;
-        float v = acc[mi][ni][r];
-        if (add_bias) v += p.bias[o];
+        const float v = acc[mi][ni][r] + bias_values[r];
         float* dst = out_n + (int64_t)o * p.out_plane + y * p.out_sy + x * p.out_sx + p.out_off;
         if (mode == 0) __builtin_nontemporal_store(v, dst);      // consumed by a later kernel, not by this one
         else if (mode == 1) *dst = previous[r] + v;

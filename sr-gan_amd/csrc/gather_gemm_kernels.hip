@@ -296,6 +296,17 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
   Side sn[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) sn[ni] = decode(p.cn, n0 + wn0 + ni * 32 + l31);
+  // bias values in front of every store (a load behind a store waits for it: one in-order vmcnt)
+  float row_bias_all[MI][16], col_bias[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Side sm = decode(p.cm, m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+      row_bias_all[mi][r] = (add_bias && !p.bias_cols && sm.valid) ? p.bias[sm.c] : 0.f;
+    }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) col_bias[ni] = (add_bias && p.bias_cols && sn[ni].valid) ? p.bias[sn[ni].c] : 0.f;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -320,12 +331,11 @@ __global__ __launch_bounds__(256, 2) void gg_mfma_kernel(const GatherGemm p) {
         const int i = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const Side sm = decode(p.cm, i);
         if (!sm.valid) continue;
-        const float row_bias = (add_bias && !p.bias_cols) ? p.bias[sm.c] : 0.f;
+        const float row_bias = row_bias_all[mi][r];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           if (!sn[ni].valid) continue;
-          float v = acc[mi][ni][r] + row_bias;
-          if (add_bias && p.bias_cols) v += p.bias[sn[ni].c];
+          const float v = (acc[mi][ni][r] + row_bias) + col_bias[ni];
           if (mode == GG_PARTIAL) {
             p.partial[((int64_t)blockIdx.y * p.M + i) * p.N + (n0 + wn0 + ni * 32 + l31)] = v;
             continue;
