@@ -503,7 +503,7 @@ def committed_cpu_baseline(image_size, batch, cpu):
             'cpu': entry.get('cpu'), 'same_cpu_model': entry.get('cpu') == cpu,
             'seconds_per_iteration': entry.get('seconds_per_iteration'),
             'provenance': f'profiles/{os.path.basename(path)} (python bench.py --cpu-baseline-child --cpu-baseline-batch {batch}, '
-                          'measured on a GPU box of this pool in round 4; not re-timed in this run)'}
+                          f'measured on a GPU box of this pool in {entry.get("measured", "round 4")}; not re-timed in this run)'}
 
 
 def cpu_baseline_child(image_size, batch=1, warmup=1, timed=3):
